@@ -1,0 +1,134 @@
+"""Pin the oracle (oracle/*.py) against golden vectors produced by the reference itself
+(tools/make_golden.py, run in the build container).  CPU only."""
+import numpy
+import pytest
+import torch
+
+from oracle import nerf_oracle as oracle
+from oracle import raygen_oracle
+from simplenerf_amd import synth
+from tests import util
+
+torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+
+
+# ---------------------------------------------------------------- G1 ray generation
+@pytest.mark.parametrize('scene', ['fern', 're10k'])
+def test_raygen_matches_reference(scene):
+    g = util.load(f'raygen_{scene}.npz')
+    cams = synth.load_cameras()[scene]
+    pix = g['pixel_indices']
+    for pi in range(3):
+        pose = raygen_oracle.process_pose(numpy.array(cams['raw_poses'][pi]), numpy.array(cams['average_pose']),
+                                          cams['translation_scale'])
+        assert util.linf(pose, numpy.array(cams['processed_poses'][pi], dtype=numpy.float32)) == 0.0
+        batch = raygen_oracle.full_frame_batch(cams['resolution'], numpy.array(cams['intrinsic']), pose, cams['near'],
+                                               cams['far'], True, cams['near_ndc'], cams['far_ndc'])
+        for k in ('rays_o', 'rays_d', 'view_dirs', 'rays_o_ndc', 'rays_d_ndc', 'near', 'far', 'near_ndc', 'far_ndc'):
+            assert batch[k].dtype == numpy.float32
+            assert util.linf(batch[k][pix], g[f'pose{pi}_{k}']) == 0.0, k
+
+
+# ---------------------------------------------------------------- G2 coarse depths
+def test_coarse_depths_match_reference():
+    g = util.load('zvals.npz')
+    near_w, far_w = torch.from_numpy(g['near_world']), torch.from_numpy(g['far_world'])
+    n = near_w.shape[0]
+    for key, ref in g.items():
+        if not (key.startswith('eval_') or key.startswith('train_')):
+            continue
+        parts = key.split('_')
+        ndc = parts[-3] == 'ndc1'
+        lindisp = parts[-2] == 'lindisp1'
+        s = int(parts[-1][1:])
+        near, far = (torch.zeros(n, 1), torch.ones(n, 1)) if ndc else (near_w, far_w)
+        t_rand = None
+        if key.startswith('train_'):
+            gen = torch.Generator().manual_seed(1234)
+            t_rand = torch.rand((n, s), generator=gen)
+        z = oracle.coarse_depths(near, far, s, lindisp, t_rand)
+        assert util.linf(z, ref) == 0.0, key
+
+
+# ---------------------------------------------------------------- G3 MLP layouts
+@pytest.mark.parametrize('layout', ['main', 'ptsaug', 'viewsaug'])
+@pytest.mark.parametrize('size', ['8x256', '4x128'])
+@pytest.mark.parametrize('mode', ['plain', 'dense'])
+def test_mlp_matches_reference(layout, size, mode):
+    g = util.load(f'mlp_{layout}_{size}_{mode}.npz')
+    kw = {'main': {}, 'ptsaug': dict(sigma_pe_degree=3),
+          'viewsaug': dict(use_view_dirs=False, view_dependent_rgb=False)}[layout]
+    cfg = synth.mlp_config(64, depth=int(g['depth']), width=int(g['width']), views_width=int(g['views_width']), **kw)
+    sd = synth.synth_state_dict(util.mlp_param_shapes(cfg), int(g['seed']), float(g['sigma_gain']), float(g['sigma_shift']))
+    params = {k: torch.from_numpy(v) for k, v in sd.items()}
+    out = oracle.mlp_forward(params, '', cfg, torch.from_numpy(g['pts']), torch.from_numpy(g['view_dirs']))
+    assert util.rel_linf(out['sigma'], g['out_sigma']) < 2e-6
+    assert util.linf(out['rgb'], g['out_rgb']) < 1e-6
+    for k in ('rgb_view_dependent', 'rgb_view_independent'):
+        assert (k in out) == (f'out_{k}' in g)
+        if k in out:
+            assert util.linf(out[k], g[f'out_{k}']) < 1e-6
+
+
+# ---------------------------------------------------------------- G4 compositing
+CASES_G4 = [('ndc_s64', True, False), ('ndc_s192', True, False), ('ndc_s256', True, False), ('world_s64', False, False),
+            ('world_s192', False, False), ('world_white_s64', False, True), ('ndc_white_s128', True, True)]
+
+
+@pytest.mark.parametrize('case,ndc,white', CASES_G4)
+def test_composite_matches_reference(case, ndc, white):
+    g = util.load('composite.npz')
+    t = lambda k: torch.from_numpy(g[f'{case}_{k}'])
+    if ndc:
+        out = oracle.composite(t('sigma'), t('rgb'), t('z'), t('rays_d_ndc'), True, white, t('rays_o'), t('rays_d'))
+    else:
+        out = oracle.composite(t('sigma'), t('rgb'), t('z'), t('rays_d'), False, white)
+    ref_keys = sorted(k[len(case) + 5:] for k in g if k.startswith(f'{case}_out_'))
+    assert sorted(out.keys()) == ref_keys
+    for k in ref_keys:
+        assert util.rel_linf(out[k], g[f'{case}_out_{k}']) < 1e-6, k
+
+
+# ---------------------------------------------------------------- G5 hierarchical resampling
+@pytest.mark.parametrize('case,s_f', [('c64_f128', 128), ('c128_f128', 128), ('c64_f64', 64)])
+def test_resample_matches_reference(case, s_f):
+    g = util.load('resample.npz')
+    z, w = torch.from_numpy(g[f'{case}_z_coarse']), torch.from_numpy(g[f'{case}_weights'])
+    assert util.linf(oracle.resample_depths(z, w, s_f), g[f'{case}_det']) == 0.0
+    u = torch.from_numpy(g[f'{case}_u_seed77'])
+    assert util.linf(oracle.resample_depths(z, w, s_f, u), g[f'{case}_seed77']) == 0.0
+    # the replayed draw is the reference's draw
+    gen = torch.Generator().manual_seed(77)
+    assert torch.equal(torch.rand(u.shape, generator=gen), u)
+
+
+# ---------------------------------------------------------------- G6 end to end
+@pytest.mark.parametrize('kind', ['config1', 'config2', 'headline', 'headline_world'])
+@pytest.mark.parametrize('profile', ['plain', 'dense'])
+def test_render_eval_matches_reference(kind, profile):
+    g = util.load(f'e2e_{kind}_{profile}.npz')
+    cfg = synth.make_configs(kind)
+    params = util.golden_params(cfg, g)
+    batch = util.golden_batch(g)
+    out = oracle.render(params, cfg, batch, training=False, retraw=True)
+    ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
+    assert sorted(out.keys()) == sorted(ref.keys())
+    for k, v in ref.items():
+        assert util.rel_linf(out[k], v) < 2e-5, k
+    plain = oracle.render(params, cfg, batch, training=False, retraw=False)
+    assert sorted(plain.keys()) == sorted(g['eval_keys'].tolist())
+
+
+@pytest.mark.parametrize('variant,profile', [('det', 'dense'), ('rand', 'dense'), ('rand', 'plain')])
+def test_render_train_matches_reference(variant, profile):
+    g = util.load(f'e2e_config3_train_{variant}_{profile}.npz')
+    cfg = synth.with_overrides(synth.make_configs('config3'), perturb=bool(g['perturb']),
+                               raw_noise_std=float(g['raw_noise_std']))
+    params = util.golden_params(cfg, g)
+    batch = util.golden_batch(g)
+    draws = oracle.replay_reference_draws(cfg, batch['rays_o'].shape[0], int(g['torch_seed']))
+    out = oracle.render(params, cfg, batch, training=True, rand_per_chunk=draws)
+    ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
+    assert sorted(out.keys()) == sorted(ref.keys())
+    for k, v in ref.items():
+        assert util.rel_linf(out[k], v) < 2e-5, k

@@ -1,0 +1,102 @@
+"""Shared helpers for the test-suite: golden loading, weight reconstruction, error metrics."""
+import os
+
+import numpy
+import torch
+
+from simplenerf_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+MLP_PREFIXES = ('coarse_model.', 'fine_model.', 'pts_aug_coarse_model.', 'pts_aug_fine_model.',
+                'views_aug_coarse_model.', 'views_aug_fine_model.')
+
+
+def load(name):
+    with numpy.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def mlp_param_shapes(mlp_cfg: dict, prefix: str = '') -> dict:
+    """Parameter shapes of one MLP, derived from its config the way the reference's constructor does
+    (src/models/SimpleNeRF01.py:567-609).  Independent restatement used by the tests to build weights."""
+    dp, wp = mlp_cfg['points_net_depth'], mlp_cfg['points_net_width']
+    dv, wv = mlp_cfg['views_net_depth'], mlp_cfg['views_net_width']
+    full_pe = 3 + 6 * mlp_cfg['points_positional_encoding_degree']
+    pts_in = full_pe
+    views_in = (3 + 6 * mlp_cfg['views_positional_encoding_degree']) if mlp_cfg['use_view_dirs'] else 0
+    if 'points_sigma_positional_encoding_degree' in mlp_cfg:
+        pts_in = (2 * mlp_cfg['points_sigma_positional_encoding_degree'] + 1) * 3
+        views_in += full_pe - pts_in
+    shapes = {}
+
+    def lin(name, fin, fout):
+        shapes[f'{prefix}{name}.weight'] = (fout, fin)
+        shapes[f'{prefix}{name}.bias'] = (fout,)
+
+    lin('pts_linears.0', pts_in, wp)
+    for i in range(dp - 1):
+        lin(f'pts_linears.{i + 1}', wp + pts_in if i == 4 else wp, wp)
+    view_dep = mlp_cfg['view_dependent_rgb']
+    if view_dep:
+        lin('views_linears.0', views_in + wp, wv)
+        for i in range(dv - 1):
+            lin(f'views_linears.{i + 1}', wv, wv)
+    lin('pts_output_linear', wp, 1 if view_dep else 4)
+    if view_dep:
+        lin('feature_linear', wp, wp)
+        lin('views_output_linear', wv, 3)
+    return shapes
+
+
+def model_param_shapes(configs: dict) -> dict:
+    m = configs['model']
+    shapes = {}
+    if 'coarse_mlp' in m:
+        shapes.update(mlp_param_shapes(m['coarse_mlp'], 'coarse_model.'))
+    if 'fine_mlp' in m:
+        shapes.update(mlp_param_shapes(m['fine_mlp'], 'fine_model.'))
+    for key, short in (('points_augmentation', 'pts_aug'), ('views_augmentation', 'views_aug')):
+        if key in m:
+            for level in ('coarse', 'fine'):
+                if f'{level}_mlp' in m[key]:
+                    shapes.update(mlp_param_shapes(m[key][f'{level}_mlp'], f'{short}_{level}_model.'))
+    return shapes
+
+
+def golden_params(configs: dict, golden: dict) -> dict:
+    """Weights for an e2e golden: synth(seed) + the density-head overrides stored in the fixture."""
+    sd = synth.synth_state_dict(model_param_shapes(configs), int(golden['seed']))
+    for k, v in golden.items():
+        if k.startswith('ovr_'):
+            sd[k[4:]] = v
+    return {k: torch.from_numpy(numpy.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+def golden_batch(golden: dict) -> dict:
+    return {k[3:]: torch.from_numpy(v) for k, v in golden.items() if k.startswith('in_')}
+
+
+def linf(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else numpy.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else numpy.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size == 0:
+        return 0.0
+    return float(numpy.max(numpy.abs(a.astype(numpy.float64) - b.astype(numpy.float64))))
+
+
+def rel_linf(a, b, floor=1.0):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else numpy.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else numpy.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    d = numpy.abs(a.astype(numpy.float64) - b.astype(numpy.float64))
+    return float(numpy.max(d / numpy.maximum(numpy.abs(b.astype(numpy.float64)), floor)))
+
+
+def outlier_fraction(a, b, tol):
+    """Fraction of entries that differ by more than ``tol`` (resampled depths sit on rounding-sensitive
+    thresholds, SURVEY 8a row 8: compare them outlier-tolerantly)."""
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else numpy.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else numpy.asarray(b)
+    return float(numpy.mean(numpy.abs(a.astype(numpy.float64) - b.astype(numpy.float64)) > tol))
