@@ -1,0 +1,135 @@
+/*
+ * simplenerf_hip.h -- C ABI of the MI355X (gfx950) volumetric renderer for SimpleNeRF's ray-marching path.
+ *
+ * Drop-in boundary: every entry point replaces one function of the reference's Python path (file:line below are
+ * relative to the reference checkout).  All pointers marked "device" are HIP device pointers to contiguous fp32
+ * arrays in the reference's row-major layouts; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * Calls only enqueue work on `stream`; they never synchronise, allocate or free (safe under hipGraph capture).
+ *
+ * Return value: 0 on success, negative snerf_status on failure; snerf_last_error() returns a thread-local
+ * message for the last failure on the calling thread.  There is no CPU fallback: without a HIP device every
+ * compute entry point fails with SNERF_E_HIP.
+ */
+#ifndef SIMPLENERF_HIP_H
+#define SIMPLENERF_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* snerf_stream_t; /* hipStream_t */
+
+enum snerf_status {
+    SNERF_OK = 0,
+    SNERF_E_INVALID = -1,     /* bad argument (null pointer, non-positive size, ...) */
+    SNERF_E_UNSUPPORTED = -2, /* configuration outside what the kernels are built for */
+    SNERF_E_HIP = -3          /* HIP runtime error (message carries hipGetErrorString) */
+};
+
+/* ABI version of this header; bumped on any signature change. */
+#define SNERF_ABI_VERSION 1
+int snerf_abi_version(void);
+const char* snerf_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K1  ray generation.  Replaces DataPreprocessor.get_rays (src/data_preprocessors/DataPreprocessor01.py:351-368),
+ * get_view_dirs (:392-394) and get_ndc_rays (:371-389) for the pixel range [first_ray, first_ray+num_rays) of an
+ * height x width frame (row-major pixel index, x fastest), so that each rank of a sharded render generates only
+ * its own rays.
+ *   intrinsic   host, 3x3 row-major        pose  host, 4x4 row-major *processed* camera-to-world (the matrix
+ *               the reference hands to get_rays; see create_test_data :816-831)
+ *   pixel_offset  0 (reference default) or 0.5 (its 'mip_nerf' switch, :357-359)
+ *   near        world near plane used by the NDC warp (model_configs['near'])
+ *   outputs     device, (num_rays,3) each; rays_o_ndc / rays_d_ndc may be NULL when ndc == 0; view_dirs may be NULL
+ */
+int snerf_generate_rays(int height, int width, const float* intrinsic, const float* pose, float pixel_offset,
+                        int ndc, float near, long long first_ray, long long num_rays, float* rays_o, float* rays_d,
+                        float* view_dirs, float* rays_o_ndc, float* rays_d_ndc, snerf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K2  coarse depths.  Replaces SimpleNeRF.get_z_vals_coarse (src/models/SimpleNeRF01.py:272-302).
+ *   near, far   device (num_rays)           t_rand  device (num_rays, num_samples) uniform [0,1) draws for the
+ *               stratified jitter of :293-301, or NULL for the unperturbed (eval) depths
+ *   depths      device (num_rays, num_samples)
+ */
+int snerf_coarse_depths(const float* near, const float* far, long long num_rays, int num_samples, int lindisp,
+                        const float* t_rand, float* depths, snerf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K3  positional encoding + MLP.  Replaces run_network/batchify + MLP.forward (src/models/SimpleNeRF01.py:363-428,
+ * :560-715) including the sample-position computation of render_rays (:139-142, :203-206).
+ */
+typedef struct snerf_mlp_desc {
+    int points_net_depth;    /* number of trunk Linear layers (skip re-injection after layer index 4, :580) */
+    int points_net_width;    /* 128 or 256 */
+    int views_net_depth;     /* 1 (only value any shipped config uses) when view_dependent_rgb, else ignored */
+    int views_net_width;     /* 64 or 128 */
+    int points_pe_degree;    /* <= 10 */
+    int views_pe_degree;     /* <= 4; ignored unless use_view_dirs */
+    int sigma_pe_degree;     /* points_sigma_positional_encoding_degree (:576-578), or -1 when the key is absent */
+    int use_view_dirs;
+    int view_dependent_rgb;
+} snerf_mlp_desc;
+
+/* Number of entries of the `params` array below for this descriptor (0 if unsupported):
+ *   [2i], [2i+1]  pts_linears.i.weight (out,in), .bias           i = 0 .. points_net_depth-1
+ *   then          pts_output_linear.weight, .bias
+ *   then, if view_dependent_rgb: feature_linear.weight, .bias; views_linears.0.weight, .bias;
+ *                 views_output_linear.weight, .bias
+ * i.e. the reference state_dict tensors (MLP.__init__ :586-608), each a device pointer. */
+int snerf_mlp_num_params(const snerf_mlp_desc* desc);
+
+/* Size in floats of the packed (MFMA-operand-ordered) weight stream; 0 if the descriptor is unsupported. */
+size_t snerf_mlp_packed_floats(const snerf_mlp_desc* desc);
+
+/* Re-order the reference-layout parameters into the packed stream (device -> device).  Call after every
+ * parameter update; the stream is what snerf_mlp_forward consumes. */
+int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* params, int num_params, float* packed,
+                   snerf_stream_t stream);
+
+enum snerf_precision {
+    SNERF_PRECISION_FP32 = 0 /* fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 FMA chains: the parity path */
+};
+
+/*   origins, dirs   device (num_rays,3): the rays the depths are measured along (NDC rays when ndc)
+ *   view_dirs       device (num_rays,3) or NULL when !use_view_dirs
+ *   depths          device (num_rays, num_samples)
+ *   sigma_noise     device (num_rays, num_samples) added to the raw density before the ReLU (:669-672), or NULL
+ *   sigma           device (num_rays, num_samples)      = 'sigma' of MLP.forward, post-ReLU
+ *   rgb             device (num_rays, num_samples, 3)   = 'rgb' of MLP.forward, post-sigmoid
+ */
+int snerf_mlp_forward(const snerf_mlp_desc* desc, const float* packed, const float* origins, const float* dirs,
+                      const float* view_dirs, const float* depths, long long num_rays, int num_samples,
+                      const float* sigma_noise, float* sigma, float* rgb, int precision, snerf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K4  alpha compositing.  Replaces SimpleNeRF.volume_rendering (src/models/SimpleNeRF01.py:430-483) and
+ * convert_depth_from_ndc (:486-502).
+ *   sigma (n,S), rgb (n,S,3), depths (n,S)      device
+ *   march_dirs (n,3)   rays_d, or rays_d_ndc when ndc      rays_o, rays_d (n,3) world rays, used only when ndc
+ *   out_rgb (n,3), out_acc (n), out_depth (n), out_depth_var (n)             device, required
+ *   out_depth_ndc (n), out_depth_var_ndc (n)                                  device, required when ndc
+ *   out_alpha, out_visibility, out_weights (n,S)                              device, each may be NULL
+ */
+int snerf_composite(const float* sigma, const float* rgb, const float* depths, const float* march_dirs,
+                    const float* rays_o, const float* rays_d, long long num_rays, int num_samples, int ndc,
+                    int white_bkgd, float* out_rgb, float* out_acc, float* out_alpha, float* out_visibility,
+                    float* out_weights, float* out_depth, float* out_depth_var, float* out_depth_ndc,
+                    float* out_depth_var_ndc, snerf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K5  hierarchical resampling.  Replaces SimpleNeRF.get_z_vals_fine (src/models/SimpleNeRF01.py:304-315) and
+ * sample_pdf (:329-361): inverse-CDF samples of the coarse weights merged with the coarse depths, ascending.
+ *   depths_coarse, weights_coarse  device (n, num_coarse)
+ *   u            device (n, num_fine) uniform draws (:341), or NULL for the deterministic linspace of :338
+ *   depths_fine  device (n, num_coarse + num_fine)
+ */
+int snerf_resample_depths(const float* depths_coarse, const float* weights_coarse, long long num_rays,
+                          int num_coarse, int num_fine, const float* u, float* depths_fine, snerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMPLENERF_HIP_H */

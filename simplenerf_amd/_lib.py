@@ -1,0 +1,68 @@
+"""ctypes binding of the C-ABI shared library (include/simplenerf_hip.h).
+
+The HIP library is the only implementation of the path: if it is missing or a call fails, a RuntimeError is raised --
+there is no PyTorch or CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsimplenerf_hip.so')
+ABI_VERSION = 1
+
+
+class MlpDesc(ctypes.Structure):
+    """struct snerf_mlp_desc"""
+    _fields_ = [(name, c_int) for name in (
+        'points_net_depth', 'points_net_width', 'views_net_depth', 'views_net_width', 'points_pe_degree',
+        'views_pe_degree', 'sigma_pe_degree', 'use_view_dirs', 'view_dependent_rgb')]
+
+
+_FP = c_void_p  # device (or host, where the header says so) float*
+
+SIGNATURES = {
+    'snerf_abi_version': (c_int, []),
+    'snerf_last_error': (c_char_p, []),
+    'snerf_generate_rays': (c_int, [c_int, c_int, POINTER(c_float), POINTER(c_float), c_float, c_int, c_float,
+                                    c_longlong, c_longlong, _FP, _FP, _FP, _FP, _FP, c_void_p]),
+    'snerf_coarse_depths': (c_int, [_FP, _FP, c_longlong, c_int, c_int, _FP, _FP, c_void_p]),
+    'snerf_mlp_num_params': (c_int, [POINTER(MlpDesc)]),
+    'snerf_mlp_packed_floats': (c_size_t, [POINTER(MlpDesc)]),
+    'snerf_mlp_pack': (c_int, [POINTER(MlpDesc), POINTER(c_void_p), c_int, _FP, c_void_p]),
+    'snerf_mlp_forward': (c_int, [POINTER(MlpDesc), _FP, _FP, _FP, _FP, _FP, c_longlong, c_int, _FP, _FP, _FP, c_int,
+                                  c_void_p]),
+    'snerf_composite': (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_longlong, c_int, c_int, c_int, _FP, _FP, _FP, _FP, _FP,
+                                _FP, _FP, _FP, _FP, c_void_p]),
+    'snerf_resample_depths': (c_int, [_FP, _FP, c_longlong, c_int, c_int, _FP, _FP, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: the HIP renderer has not been built. Run `python -m simplenerf_amd.build` '
+            f'(needs hipcc; cross-compiles for gfx950 without a GPU). There is no fallback implementation.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.snerf_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f'{LIB_PATH}: ABI version {got}, binding expects {ABI_VERSION}; rebuild the library')
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().snerf_last_error()
+        raise RuntimeError(f'{what} failed ({status}): {msg.decode() if msg else "unknown error"}')

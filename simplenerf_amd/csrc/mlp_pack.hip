@@ -1,0 +1,73 @@
+// Weight packer: reference-layout parameters (nn.Linear weight (out,in) row-major + bias) -> the MFMA-operand-
+// ordered stream described in mlp_layout.h.  A pure permutation with zero fill; HBM-bound and tiny (2.4 MB per
+// 8x256 MLP), run once per parameter update.
+#include "mlp_plan.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) pack_segment_kernel(const float* __restrict__ w, snerf::Segment s,
+                                                           float* __restrict__ packed) {
+    const long long total = (long long)s.ksteps * s.tiles * 64;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        // idx = ((g * tiles + u) * 64 + lane) * 4 + q
+        const int q = (int)(idx & 3);
+        const int lane = (int)((idx >> 2) & 63);
+        const long long gu = idx >> 8;
+        const int u = (int)(gu % s.tiles);
+        const int g = (int)(gu / s.tiles);
+        const int row = 32 * u + (lane & 31);
+        const int col = snerf::segment_column(s, 4 * g + q, lane >> 5);
+        float v = 0.0f;
+        if (row < s.out_dim && col >= 0 && col < s.ld) v = w[(long long)row * s.ld + col];
+        packed[s.dst + idx] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int snerf_mlp_num_params(const snerf_mlp_desc* desc) {
+    snerf::MlpPlan plan;
+    if (snerf::build_plan(desc, &plan) != SNERF_OK) return 0;
+    return plan.num_params;
+}
+
+extern "C" size_t snerf_mlp_packed_floats(const snerf_mlp_desc* desc) {
+    snerf::MlpPlan plan;
+    if (snerf::build_plan(desc, &plan) != SNERF_OK) return 0;
+    return (size_t)plan.total_floats;
+}
+
+extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* params, int num_params, float* packed,
+                              snerf_stream_t stream) {
+    snerf::MlpPlan plan;
+    const int st = snerf::build_plan(desc, &plan);
+    if (st != SNERF_OK) return st;
+    SNERF_REQUIRE(params && packed, "mlp_pack: NULL pointer");
+    SNERF_REQUIRE(num_params == plan.num_params, "mlp_pack: expected %d parameter tensors, got %d", plan.num_params,
+                  num_params);
+    for (int i = 0; i < num_params; ++i) SNERF_REQUIRE(params[i], "mlp_pack: parameter %d is NULL", i);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(packed, 0, sizeof(float) * (size_t)plan.total_floats, s);
+    if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_pack: memset: %s", hipGetErrorString(e));
+    for (const snerf::Segment& seg : plan.segments) {
+        const long long total = (long long)seg.ksteps * seg.tiles * 64;
+        hipLaunchKernelGGL(pack_segment_kernel, dim3(snerf::stride_grid(total, 256)), dim3(256), 0, s,
+                           params[seg.param], seg, packed);
+    }
+    auto copy = [&](long long dst, const float* src, long long n) {
+        if (e == hipSuccess) e = hipMemcpyAsync(packed + dst, src, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, s);
+    };
+    const int d = plan.depth;
+    for (int l = 0; l < d; ++l) copy(plan.trunk_bias(l), params[2 * l + 1], plan.width);
+    copy(plan.pts_out_w(), params[2 * d], (long long)plan.pts_out_rows * plan.width);
+    copy(plan.pts_out_b(), params[2 * d + 1], plan.pts_out_rows);
+    if (plan.view_dependent) {
+        copy(plan.feature_bias(), params[2 * d + 3], plan.width);
+        copy(plan.views_bias(), params[2 * d + 5], plan.views_width);
+        copy(plan.views_out_w(), params[2 * d + 6], 3LL * plan.views_width);
+        copy(plan.views_out_b(), params[2 * d + 7], 3);
+    }
+    if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_pack: copy: %s", hipGetErrorString(e));
+    return snerf::check_launch("mlp_pack");
+}

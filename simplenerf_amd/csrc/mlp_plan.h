@@ -1,0 +1,119 @@
+// Host-side plan of one MLP's packed parameter buffer: which K-segments exist, in stream order, and where the
+// bias and head blocks live.  Built from the C-ABI descriptor; used by snerf_mlp_packed_floats, snerf_mlp_pack and
+// snerf_mlp_forward so the three can never disagree.
+#pragma once
+#include <vector>
+
+#include "mlp_layout.h"
+#include "snerf_common.h"
+
+namespace snerf {
+
+struct MlpPlan {
+    int depth = 0, width = 0, views_width = 0;
+    int wt = 0, vt = 0;          // 32-row output tiles of the trunk / views layer
+    bool view_dependent = false;  // feature + views layer + rgb head exist
+    bool sigma_pe = false;        // points-augmentation layout: trunk sees a low-degree encoding
+    int points_degree = 0, views_degree = 0;
+    int full_pe = 0, pts_in = 0, extra = 0, views_pe = 0;
+    int pts_out_rows = 1;
+    int num_params = 0;
+    std::vector<Segment> segments;
+    long long weight_floats = 0;  // all slabs + one maximum-size slab of zero padding (the prefetcher runs one ahead)
+    long long bias_offset = 0;    // trunk biases [depth][width], feature bias [width], views bias [views_width]
+    long long head_offset = 0;    // pts_output W [rows][width], b [4]; views_output W [3][views_width], b [4]
+    long long total_floats = 0;
+
+    long long trunk_bias(int layer) const { return bias_offset + (long long)layer * width; }
+    long long feature_bias() const { return bias_offset + (long long)depth * width; }
+    long long views_bias() const { return bias_offset + (long long)(depth + 1) * width; }
+    long long pts_out_w() const { return head_offset; }
+    long long pts_out_b() const { return head_offset + (long long)pts_out_rows * width; }
+    long long views_out_w() const { return pts_out_b() + 4; }
+    long long views_out_b() const { return views_out_w() + 3LL * views_width; }
+};
+
+inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
+    if (!d) return fail(SNERF_E_INVALID, "mlp: NULL descriptor");
+    MlpPlan plan;
+    plan.depth = d->points_net_depth;
+    plan.width = d->points_net_width;
+    plan.view_dependent = d->view_dependent_rgb != 0;
+    plan.views_width = plan.view_dependent ? d->views_net_width : 0;
+    plan.points_degree = d->points_pe_degree;
+    plan.views_degree = plan.view_dependent ? d->views_pe_degree : 0;
+    plan.sigma_pe = d->sigma_pe_degree >= 0;
+    if (plan.width != 128 && plan.width != 256)
+        return fail(SNERF_E_UNSUPPORTED, "mlp: points_net_width %d not built (128 or 256)", plan.width);
+    if (plan.depth < 1 || plan.depth == 5 || plan.depth > 64)
+        return fail(SNERF_E_UNSUPPORTED, "mlp: points_net_depth %d unsupported (the reference itself cannot build depth 5: "
+                    "the skip concat would feed pts_output_linear)", plan.depth);
+    if (plan.points_degree < 1 || plan.points_degree > kMaxPointsDegree)
+        return fail(SNERF_E_UNSUPPORTED, "mlp: points positional-encoding degree %d outside 1..%d", plan.points_degree,
+                    kMaxPointsDegree);
+    if (plan.view_dependent) {
+        if (!d->use_view_dirs) return fail(SNERF_E_UNSUPPORTED, "mlp: view_dependent_rgb without use_view_dirs");
+        if (d->views_net_depth != 1)
+            return fail(SNERF_E_UNSUPPORTED, "mlp: views_net_depth %d not built (1)", d->views_net_depth);
+        if (plan.views_width != 64 && plan.views_width != 128)
+            return fail(SNERF_E_UNSUPPORTED, "mlp: views_net_width %d not built (64 or 128)", plan.views_width);
+        if (plan.views_degree < 1 || plan.views_degree > kMaxViewsDegree)
+            return fail(SNERF_E_UNSUPPORTED, "mlp: views positional-encoding degree %d outside 1..%d", plan.views_degree,
+                        kMaxViewsDegree);
+    }
+    plan.full_pe = 3 + 6 * plan.points_degree;
+    plan.pts_in = plan.full_pe;
+    if (plan.sigma_pe) {
+        if (d->sigma_pe_degree > plan.points_degree)
+            return fail(SNERF_E_UNSUPPORTED, "mlp: sigma encoding degree %d exceeds the points degree %d",
+                        d->sigma_pe_degree, plan.points_degree);
+        if (!plan.view_dependent)
+            return fail(SNERF_E_UNSUPPORTED, "mlp: points_sigma_positional_encoding_degree needs view-dependent colour");
+        plan.pts_in = (2 * d->sigma_pe_degree + 1) * 3;
+        plan.extra = plan.full_pe - plan.pts_in;
+    }
+    plan.views_pe = plan.view_dependent ? 3 + 6 * plan.views_degree : 0;
+    plan.wt = plan.width / 32;
+    plan.vt = plan.views_width / 32;
+    plan.pts_out_rows = plan.view_dependent ? 1 : 4;
+    plan.num_params = 2 * plan.depth + 2 + (plan.view_dependent ? 6 : 0);
+
+    long long off = 0;
+    auto add = [&](int param, int ld, int out_dim, int tiles, int ksteps, int kind, int col_offset, int lo, int hi,
+                   int degree) {
+        Segment s{param, ld, out_dim, tiles, ksteps, kind, col_offset, lo, hi, degree, off};
+        plan.segments.push_back(s);
+        off += (long long)ksteps * tiles * 64;
+    };
+    const int acc_ks = plan.width / 2;
+    add(0, plan.pts_in, plan.width, plan.wt, kPointsKSteps, SEG_POINTS_PE, 0, 0, plan.pts_in, plan.points_degree);
+    for (int l = 1; l < plan.depth; ++l) {
+        const bool skip_in = (l == 5);
+        const int ld = plan.width + (skip_in ? plan.pts_in : 0);
+        if (skip_in)
+            add(2 * l, ld, plan.width, plan.wt, kPointsKSteps, SEG_POINTS_PE, 0, 0, plan.pts_in, plan.points_degree);
+        add(2 * l, ld, plan.width, plan.wt, acc_ks, SEG_ACC, skip_in ? plan.pts_in : 0, 0, 0, 0);
+    }
+    if (plan.view_dependent) {
+        const int pf = 2 * plan.depth + 2, pv = pf + 2;
+        add(pf, plan.width, plan.width, plan.wt, acc_ks, SEG_ACC, 0, 0, 0, 0);
+        const int ldv = plan.width + plan.extra + plan.views_pe;
+        add(pv, ldv, plan.views_width, plan.vt, acc_ks, SEG_ACC, 0, 0, 0, 0);
+        if (plan.sigma_pe)
+            add(pv, ldv, plan.views_width, plan.vt, kPointsKSteps, SEG_POINTS_PE, plan.width, plan.pts_in, plan.full_pe,
+                plan.points_degree);
+        add(pv, ldv, plan.views_width, plan.vt, kViewsKSteps, SEG_VIEWS_PE, plan.width + plan.extra, 0, 0,
+            plan.views_degree);
+    }
+    off += (long long)kSlabKSteps * plan.wt * 64;  // prefetch runway (zeros)
+    plan.weight_floats = off;
+    plan.bias_offset = off;
+    off += (long long)(plan.depth + 1) * plan.width + 128;
+    plan.head_offset = off;
+    off += (long long)plan.pts_out_rows * plan.width + 4 + 3LL * 128 + 4;
+    plan.total_floats = (off + 63) / 64 * 64;
+    *p = plan;
+    return SNERF_OK;
+}
+
+}  // namespace snerf

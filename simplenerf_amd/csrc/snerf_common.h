@@ -1,0 +1,41 @@
+// Shared host-side helpers for the C-ABI entry points (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/simplenerf_hip.h"
+
+namespace snerf {
+
+char* error_buffer();  // thread-local, 512 bytes (api.hip)
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SNERF_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    return SNERF_OK;
+}
+
+// Grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8 blocks, never more than the work.
+inline unsigned stride_grid(long long work, int block) {
+    long long blocks = (work + block - 1) / block;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace snerf
+
+#define SNERF_REQUIRE(cond, ...) \
+    do {                         \
+        if (!(cond)) return snerf::fail(SNERF_E_INVALID, __VA_ARGS__); \
+    } while (0)

@@ -1,0 +1,213 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against the reference's golden vectors (and the
+oracle).  Tolerances: bit-exact for the elementwise stages that must round like the reference; for floating-point
+reductions rgb/alpha-like quantities within 1e-5 absolute (10x inside north_star's 1e-4), depths 1e-5 relative."""
+import numpy
+import pytest
+import torch
+
+from oracle import nerf_oracle as oracle
+from simplenerf_amd import ops, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+    return torch.from_numpy(numpy.ascontiguousarray(a)).to(DEV)
+
+
+# ---------------------------------------------------------------- K1
+@pytest.mark.parametrize('scene', ['fern', 're10k'])
+def test_generate_rays_bit_exact(scene):
+    g = util.load(f'raygen_{scene}.npz')
+    cams = synth.load_cameras()[scene]
+    pix = torch.from_numpy(g['pixel_indices']).to(DEV)
+    h, w = cams['resolution']
+    for pi in range(3):
+        out = ops.generate_rays((h, w), numpy.array(cams['intrinsic']), numpy.array(cams['processed_poses'][pi]),
+                                cams['near'], True, DEV)
+        for k in ('rays_o', 'rays_d', 'view_dirs', 'rays_o_ndc', 'rays_d_ndc'):
+            assert out[k].shape == (h * w, 3)
+            assert util.linf(out[k][pix], g[f'pose{pi}_{k}']) == 0.0, (k, pi)
+    # a shard of the frame is the same rays (multi-GPU block partition)
+    first, count = 12345, 4097
+    part = ops.generate_rays((h, w), numpy.array(cams['intrinsic']), numpy.array(cams['processed_poses'][2]),
+                             cams['near'], True, DEV, first_ray=first, num_rays=count)
+    for k in part:
+        assert torch.equal(part[k], out[k][first:first + count])
+
+
+def test_generate_rays_rejects_bad_range():
+    cams = synth.load_cameras()['fern']
+    with pytest.raises(RuntimeError, match='outside'):
+        ops.generate_rays((8, 8), numpy.array(cams['intrinsic']), numpy.eye(4), 1.0, False, DEV, first_ray=60, num_rays=10)
+
+
+# ---------------------------------------------------------------- K2
+def test_coarse_depths_bit_exact():
+    g = util.load('zvals.npz')
+    near_w, far_w = dev(g['near_world']), dev(g['far_world'])
+    n = near_w.shape[0]
+    for key, ref in g.items():
+        if not (key.startswith('eval_') or key.startswith('train_')):
+            continue
+        parts = key.split('_')
+        ndc, lindisp, s = parts[-3] == 'ndc1', parts[-2] == 'lindisp1', int(parts[-1][1:])
+        near, far = (torch.zeros(n, 1, device=DEV), torch.ones(n, 1, device=DEV)) if ndc else (near_w, far_w)
+        t_rand = None
+        if key.startswith('train_'):
+            t_rand = torch.rand((n, s), generator=torch.Generator().manual_seed(1234)).to(DEV)
+        z = ops.coarse_depths(near, far, s, lindisp, t_rand)
+        assert util.linf(z, ref) == 0.0, key
+
+
+@pytest.mark.parametrize('steps', [1, 2, 3, 7, 33, 65, 100, 192, 255, 1000])
+def test_coarse_depths_ragged_sizes_match_oracle(steps):
+    n = 37
+    rng = numpy.random.RandomState(steps)
+    near = torch.from_numpy(rng.uniform(0.5, 2, (n, 1)).astype(numpy.float32))
+    far = near + torch.from_numpy(rng.uniform(1, 5, (n, 1)).astype(numpy.float32))
+    t_rand = torch.from_numpy(rng.uniform(0, 1, (n, steps)).astype(numpy.float32))
+    for lindisp in (False, True):
+        for tr in (None, t_rand):
+            if steps == 1 and tr is not None:
+                continue
+            ref = oracle.coarse_depths(near, far, steps, lindisp, tr)
+            got = ops.coarse_depths(near.to(DEV), far.to(DEV), steps, lindisp, None if tr is None else tr.to(DEV))
+            assert util.linf(got, ref) == 0.0
+
+
+# ---------------------------------------------------------------- K3
+LAYOUTS = {'main': {}, 'ptsaug': dict(sigma_pe_degree=3), 'viewsaug': dict(use_view_dirs=False, view_dependent_rgb=False)}
+
+
+def abi_param_list(params: dict, prefix: str = ''):
+    names = []
+    i = 0
+    while f'{prefix}pts_linears.{i}.weight' in params:
+        names += [f'pts_linears.{i}.weight', f'pts_linears.{i}.bias']
+        i += 1
+    names += ['pts_output_linear.weight', 'pts_output_linear.bias']
+    if f'{prefix}feature_linear.weight' in params:
+        names += ['feature_linear.weight', 'feature_linear.bias', 'views_linears.0.weight', 'views_linears.0.bias',
+                  'views_output_linear.weight', 'views_output_linear.bias']
+    return [params[prefix + n] for n in names]
+
+
+@pytest.mark.parametrize('layout', ['main', 'ptsaug', 'viewsaug'])
+@pytest.mark.parametrize('size', ['8x256', '4x128'])
+@pytest.mark.parametrize('mode', ['plain', 'dense'])
+def test_mlp_forward_matches_reference(layout, size, mode):
+    g = util.load(f'mlp_{layout}_{size}_{mode}.npz')
+    cfg = synth.mlp_config(64, depth=int(g['depth']), width=int(g['width']), views_width=int(g['views_width']),
+                           **LAYOUTS[layout])
+    sd = synth.synth_state_dict(util.mlp_param_shapes(cfg), int(g['seed']), float(g['sigma_gain']), float(g['sigma_shift']))
+    params = {k: dev(v) for k, v in sd.items()}
+    mlp = ops.PackedMlp(cfg, DEV)
+    mlp.pack(abi_param_list(params))
+    # the golden evaluates B points directly; present them as B rays with one sample at depth 1 from origin 0
+    pts = g['pts']
+    b = pts.shape[0]
+    origins = torch.zeros((b, 3), device=DEV)
+    sigma, rgb = mlp.forward(origins, dev(pts), dev(g['view_dirs']), torch.ones((b, 1), device=DEV))
+    assert util.rel_linf(sigma[:, 0], g['out_sigma']) < 1e-5
+    assert util.linf(rgb[:, 0], g['out_rgb']) < 1e-5
+
+
+def test_mlp_forward_noise_tail_and_multi_sample():
+    """Sample counts that are not a multiple of the 128-sample workgroup tile, several samples per ray, injected
+    density noise: against the oracle on identical inputs."""
+    cfg = synth.mlp_config(64)
+    sd = synth.synth_state_dict(util.mlp_param_shapes(cfg), 5, 300.0, -5.0)
+    params = {k: torch.from_numpy(v) for k, v in sd.items()}
+    mlp = ops.PackedMlp(cfg, DEV)
+    mlp.pack(abi_param_list({k: v.to(DEV) for k, v in params.items()}))
+    rng = numpy.random.RandomState(0)
+    for n, s in ((1, 1), (3, 7), (5, 67), (2, 192)):
+        o = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(numpy.float32))
+        d = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(numpy.float32))
+        v = d / d.norm(dim=1, keepdim=True)
+        z = torch.from_numpy(numpy.sort(rng.uniform(0, 1, (n, s)).astype(numpy.float32), axis=1))
+        noise = torch.from_numpy(rng.standard_normal((n, s, 1)).astype(numpy.float32))
+        ref = oracle.run_mlp(params, '', cfg, oracle.ray_points(o, d, z), v, None, noise)
+        sigma, rgb = mlp.forward(o.to(DEV), d.to(DEV), v.to(DEV), z.to(DEV), noise.to(DEV))
+        assert util.rel_linf(sigma, ref['sigma']) < 1e-5
+        assert util.linf(rgb, ref['rgb']) < 1e-5
+
+
+def test_mlp_unsupported_config_fails_loudly():
+    with pytest.raises(NotImplementedError, match='not built'):
+        ops.PackedMlp(synth.mlp_config(64, width=192), DEV)
+    with pytest.raises(RuntimeError, match='GPU'):
+        ops.coarse_depths(torch.zeros(4, 1), torch.ones(4, 1), 8)
+
+
+# ---------------------------------------------------------------- K4
+CASES_G4 = [('ndc_s64', True, False), ('ndc_s192', True, False), ('ndc_s256', True, False), ('world_s64', False, False),
+            ('world_s192', False, False), ('world_white_s64', False, True), ('ndc_white_s128', True, True)]
+
+
+@pytest.mark.parametrize('case,ndc,white', CASES_G4)
+def test_composite_matches_reference(case, ndc, white):
+    g = util.load('composite.npz')
+    t = lambda k: dev(g[f'{case}_{k}'])
+    if ndc:
+        out = ops.composite(t('sigma'), t('rgb'), t('z'), t('rays_d_ndc'), True, white, t('rays_o'), t('rays_d'))
+    else:
+        out = ops.composite(t('sigma'), t('rgb'), t('z'), t('rays_d'), False, white)
+    ref_keys = sorted(k[len(case) + 5:] for k in g if k.startswith(f'{case}_out_'))
+    assert sorted(out.keys()) == ref_keys
+    for k in ref_keys:
+        assert util.rel_linf(out[k], g[f'{case}_out_{k}']) < 1e-5, k
+
+
+@pytest.mark.parametrize('s', [1, 2, 63, 65, 130, 300, 513, 1024])
+def test_composite_ragged_sample_counts(s):
+    rng = numpy.random.RandomState(s)
+    n = 9
+    z = torch.from_numpy(numpy.sort(rng.uniform(2, 6, (n, s)).astype(numpy.float32), axis=1))
+    sigma = torch.from_numpy(rng.gamma(0.5, 4.0, (n, s)).astype(numpy.float32))
+    rgb = torch.from_numpy(rng.uniform(0, 1, (n, s, 3)).astype(numpy.float32))
+    d = torch.from_numpy(rng.standard_normal((n, 3)).astype(numpy.float32))
+    ref = oracle.composite(sigma, rgb, z, d, False)
+    out = ops.composite(sigma.to(DEV), rgb.to(DEV), z.to(DEV), d.to(DEV), False)
+    for k, v in ref.items():
+        assert util.rel_linf(out[k], v) < 1e-5, k
+
+
+# ---------------------------------------------------------------- K5
+def check_resample(got, ref, z_coarse):
+    """Resampled depths sit on rounding-sensitive thresholds (searchsorted ties, denom < 1e-5): the wave scan and the
+    reference's sequential cumsum may legitimately pick neighbouring bins for a few samples.  Require: sorted,
+    coarse depths contained, at most 0.5 % of entries off by more than 1e-6 relative, none by more than one bin."""
+    got = got.cpu()
+    assert torch.all(got[:, 1:] >= got[:, :-1])
+    scale = float(ref.abs().max())
+    assert util.outlier_fraction(got, ref, 2e-6 * scale) < 5e-3
+    width = float((z_coarse[:, 1:] - z_coarse[:, :-1]).max())
+    assert util.linf(got, ref) <= width * 1.001
+
+
+@pytest.mark.parametrize('case,s_f', [('c64_f128', 128), ('c128_f128', 128), ('c64_f64', 64)])
+def test_resample_matches_reference(case, s_f):
+    g = util.load('resample.npz')
+    z, w = dev(g[f'{case}_z_coarse']), dev(g[f'{case}_weights'])
+    check_resample(ops.resample_depths(z, w, s_f), torch.from_numpy(g[f'{case}_det']), torch.from_numpy(g[f'{case}_z_coarse']))
+    u = dev(g[f'{case}_u_seed77'])
+    check_resample(ops.resample_depths(z, w, s_f, u), torch.from_numpy(g[f'{case}_seed77']),
+                   torch.from_numpy(g[f'{case}_z_coarse']))
+
+
+@pytest.mark.parametrize('s_c,s_f', [(3, 1), (4, 5), (17, 100), (200, 31), (256, 256)])
+def test_resample_ragged_sizes(s_c, s_f):
+    rng = numpy.random.RandomState(s_c * 1000 + s_f)
+    n = 11
+    z = torch.from_numpy(numpy.sort(rng.uniform(0, 1, (n, s_c)).astype(numpy.float32), axis=1))
+    w = torch.from_numpy(rng.gamma(0.4, 0.1, (n, s_c)).astype(numpy.float32))
+    u = torch.from_numpy(rng.uniform(0, 1, (n, s_f)).astype(numpy.float32))
+    for uu in (None, u):
+        ref = oracle.resample_depths(z, w, s_f, uu)
+        got = ops.resample_depths(z.to(DEV), w.to(DEV), s_f, None if uu is None else uu.to(DEV))
+        assert got.shape == (n, s_c + s_f)
+        check_resample(got, ref, z)
