@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
         if (j0 + c == s - 1) z[c + 1] = far_cap;
 
     const float* md = a.march_dirs + ray * 3;
-    const float norm = __fsqrt_rn((md[0] * md[0] + md[1] * md[1]) + md[2] * md[2]);
+    const float norm = sqrtf((md[0] * md[0] + md[1] * md[1]) + md[2] * md[2]);
 
     float alpha[C], keep = 1.0f;
 #pragma unroll

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) raygen_kernel(RaygenConst c, long long fi
         po[0] = o[0]; po[1] = o[1]; po[2] = o[2];
         pd[0] = d[0]; pd[1] = d[1]; pd[2] = d[2];
         if (view_dirs) {
-            const float nrm = __fsqrt_rn((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+            const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
             float* pv = view_dirs + 3 * i;
             pv[0] = __fdiv_rn(d[0], nrm); pv[1] = __fdiv_rn(d[1], nrm); pv[2] = __fdiv_rn(d[2], nrm);
         }

@@ -1,0 +1,196 @@
+"""MI355X renderer behind the reference's model interface.
+
+``SimpleNeRFHip(configs, model_configs)`` is a ``torch.nn.Module`` whose constructor arguments, parameter names and
+shapes, ``forward(input_batch, retraw=False, sec_views_vis=False) -> dict`` signature and output keys are those of
+the reference's ``SimpleNeRF`` (src/models/SimpleNeRF01.py:11-75, :108-270), so the reference's Trainer/Tester call
+sites (src/Trainer01.py:93,194,328; src/Tester01.py:63) work unchanged.  All arithmetic runs in the HIP library
+(simplenerf_amd/csrc) through the C ABI in include/simplenerf_hip.h; PyTorch only owns device memory, the stream and
+the parameters.  There is no eager/CPU fallback: CPU tensors or an unbuilt library raise.
+
+Differences from the reference that a caller can observe:
+  * ``model.chunk`` / ``model.netchunk`` are accepted and ignored -- the kernels tile the work themselves and the
+    results do not depend on chunking;
+  * training-mode randomness (stratified jitter, inverse-CDF ``u``, density noise) is drawn on the device
+    (``torch.rand``/``randn`` on the GPU generator) instead of on the CPU generator; ``set_random_draws`` injects
+    explicit draws (used by the parity tests to replay the reference's CPU stream);
+  * ``predict_visibility`` (off in every shipped config) is not built;
+  * backward kernels are not built yet: a training-mode forward under ``torch.enable_grad()`` raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import ops
+
+Tensor = torch.Tensor
+_SKIP_AFTER = 4  # reference: self.skips = [4]
+
+
+class MlpParameters(torch.nn.Module):
+    """Parameters of one NeRF MLP under the reference's names, shapes and construction order (MLP.__init__
+    src/models/SimpleNeRF01.py:561-609), so ``state_dict()`` round-trips with reference checkpoints and the default
+    initialisation consumes the RNG identically."""
+
+    def __init__(self, configs: dict, mlp_configs: dict):
+        super().__init__()
+        self.mlp_configs = mlp_configs
+        if mlp_configs.get('predict_visibility', False):
+            raise NotImplementedError('predict_visibility is not built in the HIP renderer')
+        dp, wp = mlp_configs['points_net_depth'], mlp_configs['points_net_width']
+        full_pe = 3 + 6 * mlp_configs['points_positional_encoding_degree']
+        pts_in = full_pe
+        views_in = 0
+        if mlp_configs['use_view_dirs']:
+            views_in = 3 + 6 * mlp_configs['views_positional_encoding_degree']
+        if 'points_sigma_positional_encoding_degree' in mlp_configs:
+            pts_in = (2 * mlp_configs['points_sigma_positional_encoding_degree'] + 1) * 3
+            views_in += full_pe - pts_in
+        self.view_dependent = bool(mlp_configs['view_dependent_rgb'])
+        lin = torch.nn.Linear
+        self.pts_linears = torch.nn.ModuleList(
+            [lin(pts_in, wp)] + [lin(wp + pts_in if i == _SKIP_AFTER else wp, wp) for i in range(dp - 1)])
+        if self.view_dependent:
+            dv, wv = mlp_configs['views_net_depth'], mlp_configs['views_net_width']
+            self.views_linears = torch.nn.ModuleList([lin(views_in + wp, wv)] + [lin(wv, wv) for _ in range(dv - 1)])
+        self.pts_output_linear = lin(wp, 1 if self.view_dependent else 4)
+        if self.view_dependent:
+            self.feature_linear = lin(wp, wp)
+            self.views_output_linear = lin(wv, 3)
+
+    def abi_params(self) -> List[Tensor]:
+        out = []
+        for layer in self.pts_linears:
+            out += [layer.weight, layer.bias]
+        out += [self.pts_output_linear.weight, self.pts_output_linear.bias]
+        if self.view_dependent:
+            out += [self.feature_linear.weight, self.feature_linear.bias, self.views_linears[0].weight,
+                    self.views_linears[0].bias, self.views_output_linear.weight, self.views_output_linear.bias]
+        return out
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError('MlpParameters only holds weights; evaluation happens in the fused HIP kernel')
+
+
+class SimpleNeRFHip(torch.nn.Module):
+    def __init__(self, configs: dict, model_configs: dict = None):
+        super().__init__()
+        self.configs = configs
+        self.model_configs = model_configs
+        mcfg = configs['model']
+        self.ndc = configs['data_loader']['ndc']
+        self.coarse_mlp_needed = 'coarse_mlp' in mcfg
+        self.fine_mlp_needed = 'fine_mlp' in mcfg
+        if not self.coarse_mlp_needed:
+            raise NotImplementedError('a coarse_mlp is required (the reference cannot sample a fine pass without one)')
+        # sub-model presence and construction order follow the reference (:45-65)
+        self.coarse_model = MlpParameters(configs, mcfg['coarse_mlp'])
+        self.fine_model = MlpParameters(configs, mcfg['fine_mlp']) if self.fine_mlp_needed else None
+        self._train_only: List[tuple] = []  # (output prefix, level, attribute name)
+        for key, short in (('points_augmentation', 'pts_aug'), ('views_augmentation', 'views_aug')):
+            if key in mcfg:
+                for level in ('coarse', 'fine'):
+                    if f'{level}_mlp' in mcfg[key]:
+                        name = f'{short}_{level}_model'
+                        setattr(self, name, MlpParameters(configs, mcfg[key][f'{level}_mlp']))
+                        self._train_only.append((f'{key}_', level, name))
+        self._packed: Dict[str, tuple] = {}
+        self._draws: Optional[dict] = None
+
+    # ------------------------------------------------------------------------------------------
+    def set_random_draws(self, draws: Optional[dict]) -> None:
+        """Use these tensors for the next training-mode forward instead of device RNG.  Keys (all optional):
+        ``t_rand`` (N,S_c); ``u`` (N,S_f); ``noise_coarse``, ``noise_points_augmentation``,
+        ``noise_views_augmentation`` (N,S_c,1); ``noise_fine`` (N,S_c+S_f,1) -- noise already scaled by
+        raw_noise_std.  A missing key means that draw is skipped (no jitter / no noise)."""
+        self._draws = draws
+
+    def _packed_mlp(self, name: str) -> ops.PackedMlp:
+        module: MlpParameters = getattr(self, name)
+        params = module.abi_params()
+        stamp = tuple((p.data_ptr(), p._version) for p in params)
+        entry = self._packed.get(name)
+        if entry is None or entry[0] != stamp or entry[1].buffer.device != params[0].device:
+            packed = entry[1] if entry is not None and entry[1].buffer.device == params[0].device \
+                else ops.PackedMlp(module.mlp_configs, params[0].device)
+            packed.pack(params)
+            self._packed[name] = (stamp, packed)
+        return self._packed[name][1]
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, input_batch: dict, retraw: bool = False, sec_views_vis: bool = False) -> Dict[str, Tensor]:
+        batch = dict(input_batch)  # the caller's dict is never mutated (reference: deep_dict_copy :68)
+        training = self.training
+        retraw = retraw or training
+        if training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                'SimpleNeRFHip: the backward kernels (composite + MLP gradients) are not built yet; run training-mode '
+                'forwards under torch.no_grad()')
+        mcfg = self.configs['model']
+        rays_o, rays_d = batch['rays_o'], batch['rays_d']
+        if self.ndc:
+            march_o, march_d = batch['rays_o_ndc'], batch['rays_d_ndc']
+            near, far = batch['near_ndc'], batch['far_ndc']
+        else:
+            march_o, march_d = rays_o, rays_d
+            near, far = batch['near'], batch['far']
+        need_dirs = mcfg['coarse_mlp']['use_view_dirs'] or (self.fine_mlp_needed and mcfg['fine_mlp']['use_view_dirs'])
+        view_dirs = batch['view_dirs'] if need_dirs else batch.get('view_dirs')
+        n = rays_o.shape[0]
+        dev = rays_o.device
+        draws = self._draws
+        self._draws = None
+        noise_std = float(mcfg['raw_noise_std'])
+        perturb = bool(mcfg['perturb'] > 0.) and training
+
+        def draw(key, shape, normal):
+            if not training:
+                return None
+            if draws is not None:
+                t = draws.get(key)
+                return None if t is None else t.to(dev)
+            if normal:
+                return torch.randn(shape, device=dev) * noise_std if noise_std > 0. else None
+            return torch.rand(shape, device=dev) if perturb else None
+
+        out: Dict[str, Tensor] = {}
+
+        def shade(name, prefix, level, depths, noise_key):
+            s = depths.shape[1]
+            packed = self._packed_mlp(name)
+            sigma, rgb = packed.forward(march_o, march_d, view_dirs, depths, draw(noise_key, (n, s, 1), True))
+            comp = ops.composite(sigma, rgb, depths, march_d, self.ndc, mcfg['white_bkgd'], rays_o, rays_d)
+            # key order as volume_rendering's return_dict (:465-477)
+            for k in ('rgb', 'acc', 'alpha', 'visibility', 'weights', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc'):
+                if k in comp:
+                    out[f'{prefix}{k}_{level}'] = comp[k]
+            if retraw:
+                out[f'{prefix}raw_sigma_{level}'] = sigma
+                variant = 'rgb_view_dependent' if packed.use_view_dirs else 'rgb_view_independent'
+                out[f'{prefix}raw_{variant}_{level}'] = rgb
+                out[f'{prefix}raw_rgb_{level}'] = rgb
+            return comp
+
+        s_c = mcfg['coarse_mlp']['num_samples']
+        z_coarse = ops.coarse_depths(near, far, s_c, mcfg['lindisp'], draw('t_rand', (n, s_c), False))
+        comp_c = shade('coarse_model', '', 'coarse', z_coarse, 'noise_coarse')
+        out['z_vals_coarse'] = z_coarse
+        if training:
+            for prefix, level, name in self._train_only:
+                if level == 'coarse':
+                    shade(name, prefix, 'coarse', z_coarse, f'noise_{prefix[:-1]}')
+        if self.fine_mlp_needed:
+            s_f = mcfg['fine_mlp']['num_samples']
+            z_fine = ops.resample_depths(z_coarse, comp_c['weights'], s_f, draw('u', (n, s_f), False))
+            shade('fine_model', '', 'fine', z_fine, 'noise_fine')
+            out['z_vals_fine'] = z_fine
+            if training:
+                for prefix, level, name in self._train_only:
+                    if level == 'fine':
+                        shade(name, prefix, 'fine', z_fine, f'noise_{prefix[:-1]}_fine')
+        if not retraw:
+            for level in ('coarse', 'fine'):
+                for k in ('z_vals', 'visibility', 'weights'):
+                    out.pop(f'{k}_{level}', None)
+        return out

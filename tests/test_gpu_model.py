@@ -1,0 +1,201 @@
+"""End-to-end parity of the drop-in model on a real MI355X against the reference's golden outputs (G6) at
+north_star's tolerance -- colour-like quantities within 1e-4, depths within 1e-3 (L-infinity) -- through the
+reference's own call signature ``model(input_batch[, retraw])``.
+
+What is gated how:
+  * coarse-pass outputs and both augmented models (which run on the coarse samples): every ray, every profile;
+  * fine-pass outputs of the 'consistent' profile (fine MLP = coarse MLP, i.e. both passes see one geometry, as in
+    a trained model): every ray;
+  * fine-pass outputs when coarse and fine MLPs are two INDEPENDENT random fields ('plain', 'dense'): at most 5 %
+    of rays may exceed the bound.  Cause: the reference's sample_pdf replaces ``denom < 1e-5`` by 1
+    (src/models/SimpleNeRF01.py:357) and the pdf of an EMPTY coarse bin is 0.9994e-5 -- within half an ulp of the
+    running fp32 cumsum of that threshold -- so which empty bins collapse to their left edge is decided by the last
+    bit of the reference's own sequential cumsum (SURVEY 8a row 8 measured 0.26 % of samples moving a full bin
+    between two fp32 implementations).  With independent random fields a moved sample can land in dense fine
+    geometry; with consistent geometry it carries ~zero weight.  ``test_fine_pass_on_reference_samples`` removes the
+    resampling step and shows the fine MLP + compositing themselves match on every ray;
+  * per-sample fine arrays (alpha_fine, weights_fine, raw_*_fine) are index-aligned with the reference only when the
+    sorted fine depths agree to the last bit, which an independent fp32 evaluation of the coarse weights never gives
+    (t = (u - cdf_b)/denom amplifies a 1e-7 cdf difference by 1/denom); they are gated, on every ray, by the
+    intervention test, which feeds the reference's own fine depths to the kernels;
+  * world-space depth/depth_var of NDC scenes multiply every weight by 1/(1 - z) (up to 1e3): one low-weight far
+    sample that moves shifts them past 1e-3 on a few rays even with consistent geometry, so for the fine pass they
+    are gated outlier-tolerantly (<= 5 % of rays) while depth_ndc / depth_var_ndc are gated on every ray;
+  * depth = sum(w z)/(acc + 1e-6) is only gated on rays with acc > 1e-2: for an almost-empty ray the reference's own
+    alpha = 1 - exp(-1e-5) has ~1e-3 relative rounding noise.
+"""
+import numpy
+import pytest
+import torch
+
+from oracle import nerf_oracle as oracle
+from simplenerf_amd import ops, synth
+from simplenerf_amd.models.ModelFactory import get_model
+from tests import util
+from tests.test_gpu_kernels import abi_param_list
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+RGB_TOL, DEPTH_TOL = 1e-4, 1e-3
+MAX_OUTLIER_RAYS = 0.05
+
+
+def build(configs, golden):
+    model = get_model(configs, None)
+    res = model.load_state_dict(util.golden_params(configs, golden), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return model.to(DEV)
+
+
+def per_ray_violation(key, got, ref, acc_ref):
+    """bool (N,): rays on which `key` exceeds its bound.  None -> key not gated."""
+    base = key.replace('points_augmentation_', '').replace('views_augmentation_', '')
+    a = got.detach().cpu().numpy().astype(numpy.float64)
+    b = ref.astype(numpy.float64)
+    n = b.shape[0]
+    d = numpy.abs(a - b).reshape(n, -1)
+    bm = numpy.abs(b).reshape(n, -1)
+    if base.startswith(('rgb_', 'acc_', 'alpha_', 'raw_rgb', 'weights_', 'visibility_')):
+        return d.max(1) > RGB_TOL
+    if base.startswith('raw_sigma'):
+        return (d / numpy.maximum(bm, 1.0)).max(1) > 1e-3
+    if base.startswith(('depth_var_ndc', 'depth_ndc')):
+        return (d.max(1) > DEPTH_TOL) & (acc_ref > 1e-2)
+    if base.startswith('depth_var'):
+        # un-normalised second moment sum w (z - depth)^2 of world depths up to ~1e3: a difference of large numbers
+        # that no reference loss reads; bounded relatively, 10x looser
+        return ((d / numpy.maximum(bm, 1.0)).max(1) > 10 * DEPTH_TOL) & (acc_ref > 1e-2)
+    if base.startswith('depth_'):
+        return ((d / numpy.maximum(bm, 1.0)).max(1) > DEPTH_TOL) & (acc_ref > 1e-2)
+    return None  # z_vals_*: checked separately
+
+
+def check_outputs(out, ref, strict_fine, tag=''):
+    assert sorted(out.keys()) == sorted(ref.keys()), sorted(set(out) ^ set(ref))
+    for k, v in ref.items():
+        assert tuple(out[k].shape) == tuple(v.shape), k
+        assert out[k].dtype == torch.float32 and out[k].device.type == 'cuda', k
+        assert torch.isfinite(out[k]).all(), k
+    for k, v in ref.items():
+        level = 'fine' if k.endswith('_fine') else 'coarse'
+        acc_key = next(c for c in (f'{p}acc_{level}' for p in ('points_augmentation_', 'views_augmentation_', ''))
+                       if k.startswith(c.split('acc_')[0]) and c in ref)
+        bad = per_ray_violation(k, out[k], v, ref[acc_key].astype(numpy.float64))
+        if bad is None:
+            continue
+        per_sample = v.ndim >= 2 and v.shape[1] > 3
+        world_depth = k in ('depth_fine', 'depth_var_fine')
+        if level == 'coarse':
+            assert not bad.any(), (tag, k, int(bad.sum()), util.linf(out[k], v))
+        elif per_sample:
+            continue  # not index-aligned unless the fine depths are bit-identical: see test_fine_pass_on_reference_samples
+        elif strict_fine and not world_depth:
+            assert not bad.any(), (tag, k, int(bad.sum()), util.linf(out[k], v))
+        else:
+            assert bad.mean() <= MAX_OUTLIER_RAYS, (tag, k, float(bad.mean()))
+    assert util.linf(out['z_vals_coarse'], ref['z_vals_coarse']) == 0.0
+    if 'z_vals_fine' in ref:
+        zr = ref['z_vals_fine']
+        assert util.outlier_fraction(out['z_vals_fine'], zr, 1e-5 * float(numpy.abs(zr).max())) < 0.01
+        z = out['z_vals_fine']
+        assert torch.all(z[:, 1:] >= z[:, :-1])
+
+
+EVAL_CASES = [(k, p) for k in ('config1', 'config2', 'headline', 'headline_world') for p in ('plain', 'dense', 'consistent')
+              if not (k == 'config1' and p == 'consistent')]
+
+
+@pytest.mark.parametrize('kind,profile', EVAL_CASES)
+def test_eval_forward_matches_reference(kind, profile):
+    g = util.load(f'e2e_{kind}_{profile}.npz')
+    cfg = synth.make_configs(kind)
+    model = build(cfg, g).eval()
+    batch = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
+    before = {k: v.clone() for k, v in batch.items()}
+    with torch.no_grad():
+        out = model(batch, retraw=True)
+        plain = model(batch)
+    ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
+    check_outputs(out, ref, strict_fine=(profile == 'consistent'), tag=f'{kind}/{profile}')
+    assert sorted(plain.keys()) == sorted(g['eval_keys'].tolist())
+    assert all(torch.equal(plain[k], out[k]) for k in plain)
+    assert list(batch.keys()) == list(before.keys()) and all(torch.equal(batch[k], before[k]) for k in batch)
+
+
+TRAIN_CASES = [('det', 'dense'), ('rand', 'dense'), ('rand', 'plain'), ('det', 'consistent'), ('rand', 'consistent')]
+
+
+@pytest.mark.parametrize('variant,profile', TRAIN_CASES)
+def test_train_forward_matches_reference(variant, profile):
+    """Training-mode forward (both augmented MLPs active, config 3) with the reference's CPU-generator draws
+    (stratified jitter, inverse-CDF u, density noise) replayed in its order and injected."""
+    g = util.load(f'e2e_config3_train_{variant}_{profile}.npz')
+    cfg = synth.with_overrides(synth.make_configs('config3'), perturb=bool(g['perturb']),
+                               raw_noise_std=float(g['raw_noise_std']))
+    model = build(cfg, g).train()
+    batch = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
+    draws = oracle.replay_reference_draws(cfg, batch['rays_o'].shape[0], int(g['torch_seed']))
+    assert len(draws) == 1
+    model.set_random_draws(draws[0])
+    with torch.no_grad():
+        out = model(batch)
+    ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
+    check_outputs(out, ref, strict_fine=(profile == 'consistent'), tag=f'train/{variant}/{profile}')
+
+
+@pytest.mark.parametrize('kind,profile', [('config2', 'dense'), ('headline', 'dense'), ('headline_world', 'dense'),
+                                          ('config2', 'plain')])
+def test_fine_pass_on_reference_samples(kind, profile):
+    """Intervention: give the fine MLP + compositing kernels the REFERENCE's fine depths (skipping only the
+    rounding-sensitive resampling) -- every ray must then match at the full tolerance, for independent fields too."""
+    g = util.load(f'e2e_{kind}_{profile}.npz')
+    cfg = synth.make_configs(kind)
+    params = {k: v.to(DEV) for k, v in util.golden_params(cfg, g).items()}
+    mlp = ops.PackedMlp(cfg['model']['fine_mlp'], DEV)
+    mlp.pack(abi_param_list(params, 'fine_model.'))
+    b = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
+    ndc = cfg['data_loader']['ndc']
+    mo, md = (b['rays_o_ndc'], b['rays_d_ndc']) if ndc else (b['rays_o'], b['rays_d'])
+    z = torch.from_numpy(g['out_z_vals_fine']).to(DEV)
+    sigma, rgb = mlp.forward(mo, md, b['view_dirs'], z)
+    comp = ops.composite(sigma, rgb, z, md, ndc, False, b['rays_o'], b['rays_d'])
+    acc = g['out_acc_fine'].astype(numpy.float64)
+    for k, v in comp.items():
+        bad = per_ray_violation(f'{k}_fine', v, g[f'out_{k}_fine'], acc)
+        assert bad is not None and not bad.any(), (k, util.linf(v, g[f'out_{k}_fine']))
+    assert not per_ray_violation('raw_sigma_fine', sigma, g['out_raw_sigma_fine'], acc).any()
+    assert not per_ray_violation('raw_rgb_fine', rgb, g['out_raw_rgb_fine'], acc).any()
+
+
+def test_train_forward_with_device_rng_is_statistically_sane():
+    cfg = synth.make_configs('config3')
+    g = util.load('e2e_config3_train_rand_plain.npz')
+    model = build(cfg, g).train()
+    batch = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
+    with torch.no_grad():
+        a = model(batch)
+        b = model(batch)
+    assert not torch.equal(a['z_vals_coarse'], b['z_vals_coarse'])
+    z = a['z_vals_coarse']
+    assert torch.all(z[:, 1:] >= z[:, :-1]) and float(z.min()) >= 0 and float(z.max()) <= 1
+    assert all(torch.isfinite(v).all() for v in a.values())
+    # density noise ~ N(0, raw_noise_std): the two draws of the pre-ReLU perturbation differ on most samples
+    assert float((a['raw_sigma_coarse'] != b['raw_sigma_coarse']).float().mean()) > 0.3
+
+
+def test_grad_enabled_training_forward_raises_until_backward_exists():
+    cfg = synth.make_configs('config2')
+    model = get_model(cfg, None).to(DEV).train()
+    g = util.load('e2e_config2_plain.npz')
+    batch = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
+    with pytest.raises(NotImplementedError, match='backward'):
+        model(batch)
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    cfg = synth.make_configs('config1')
+    model = get_model(cfg, None).eval()  # parameters left on the CPU
+    batch = {k: torch.from_numpy(v) for k, v in synth.random_world_rays(8).items()}
+    with pytest.raises(RuntimeError, match='GPU'):
+        with torch.no_grad():
+            model(batch)

@@ -1,0 +1,78 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol, the plugin factory
+follows the reference's naming rule, and the parameter container reproduces the reference's state_dict layout."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from simplenerf_amd import _lib, ops, synth
+from simplenerf_amd.models.ModelFactory import get_model
+from tests import util
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, 'include', 'simplenerf_hip.h')).read()
+    declared = set(re.findall(r'\b(snerf_[a-z_0-9]+)\s*\(', header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.snerf_abi_version() == _lib.ABI_VERSION
+
+
+def test_descriptor_queries_need_no_gpu():
+    lib = _lib.load()
+    d = ops.mlp_desc(synth.mlp_config(64))
+    assert lib.snerf_mlp_num_params(ctypes.byref(d)) == 24
+    assert lib.snerf_mlp_packed_floats(ctypes.byref(d)) > 593408  # at least the MAC count of the main MLP
+    d = ops.mlp_desc(synth.mlp_config(64, use_view_dirs=False, view_dependent_rgb=False))
+    assert lib.snerf_mlp_num_params(ctypes.byref(d)) == 18
+    bad = ops.mlp_desc(synth.mlp_config(64, width=192))
+    assert lib.snerf_mlp_packed_floats(ctypes.byref(bad)) == 0
+    assert b'points_net_width' in lib.snerf_last_error()
+
+
+def test_invalid_arguments_return_errors_without_touching_the_gpu():
+    lib = _lib.load()
+    st = lib.snerf_coarse_depths(None, None, 4, 8, 0, None, None, None)
+    assert st == -1 and b'NULL' in lib.snerf_last_error()
+    st = lib.snerf_resample_depths(ctypes.c_void_p(16), ctypes.c_void_p(16), 4, 2, 8, None, ctypes.c_void_p(16), None)
+    assert st == -1 and b'coarse' in lib.snerf_last_error()
+
+
+@pytest.mark.parametrize('name', ['SimpleNeRFHip01', 'SimpleNeRF01'])
+def test_factory_naming_rule(name):
+    cfg = synth.make_configs('config3', model_name=name)
+    model = get_model(cfg, None)
+    assert type(model).__name__ == 'SimpleNeRFHip'
+    assert isinstance(model, torch.nn.Module)
+    with pytest.raises(RuntimeError, match='Unknown model'):
+        get_model(synth.make_configs('config1', model_name='NoSuchModel07'), None)
+
+
+@pytest.mark.parametrize('kind', ['config1', 'config2', 'config3'])
+def test_state_dict_layout_matches_reference(kind):
+    cfg = synth.make_configs(kind)
+    model = get_model(cfg, None)
+    expect = util.model_param_shapes(cfg)
+    got = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert got == expect
+    # checkpoints written through DataParallel carry the 'module.' prefix (src/Trainer01.py:352-366)
+    wrapped = torch.nn.DataParallel(model) if torch.cuda.is_available() else None
+    if wrapped is not None:
+        assert all(k.startswith('module.') for k in wrapped.state_dict())
+
+
+def test_default_init_consumes_rng_like_reference_constructor_order():
+    """Same seed -> same initial weights as a model whose Linear layers are created in the reference's order."""
+    cfg = synth.make_configs('config2')
+    torch.manual_seed(3)
+    a = get_model(cfg, None).state_dict()
+    torch.manual_seed(3)
+    lin = torch.nn.Linear
+    first = lin(63, 256)
+    assert torch.equal(a['coarse_model.pts_linears.0.weight'], first.weight)

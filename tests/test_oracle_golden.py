@@ -104,8 +104,10 @@ def test_resample_matches_reference(case, s_f):
 
 # ---------------------------------------------------------------- G6 end to end
 @pytest.mark.parametrize('kind', ['config1', 'config2', 'headline', 'headline_world'])
-@pytest.mark.parametrize('profile', ['plain', 'dense'])
+@pytest.mark.parametrize('profile', ['plain', 'dense', 'consistent'])
 def test_render_eval_matches_reference(kind, profile):
+    if kind == 'config1' and profile == 'consistent':
+        pytest.skip('config1 has no fine pass')
     g = util.load(f'e2e_{kind}_{profile}.npz')
     cfg = synth.make_configs(kind)
     params = util.golden_params(cfg, g)
@@ -119,7 +121,8 @@ def test_render_eval_matches_reference(kind, profile):
     assert sorted(plain.keys()) == sorted(g['eval_keys'].tolist())
 
 
-@pytest.mark.parametrize('variant,profile', [('det', 'dense'), ('rand', 'dense'), ('rand', 'plain')])
+@pytest.mark.parametrize('variant,profile', [('det', 'dense'), ('rand', 'dense'), ('rand', 'plain'),
+                                             ('det', 'consistent'), ('rand', 'consistent')])
 def test_render_train_matches_reference(variant, profile):
     g = util.load(f'e2e_config3_train_{variant}_{profile}.npz')
     cfg = synth.with_overrides(synth.make_configs('config3'), perturb=bool(g['perturb']),

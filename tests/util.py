@@ -70,6 +70,10 @@ def golden_params(configs: dict, golden: dict) -> dict:
     for k, v in golden.items():
         if k.startswith('ovr_'):
             sd[k[4:]] = v
+    if int(golden.get('fine_equals_coarse', 0)):
+        for k in list(sd):
+            if k.startswith('coarse_model.'):
+                sd['fine_model.' + k[len('coarse_model.'):]] = sd[k]
     return {k: torch.from_numpy(numpy.ascontiguousarray(v)) for k, v in sd.items()}
 
 

@@ -338,19 +338,35 @@ def calibrate_density(model, batch, train_mode):
     return overrides
 
 
+def tie_fine_to_coarse(model):
+    """'consistent' profile: the fine MLP gets the coarse MLP's (calibrated) weights, so both passes see the same
+    geometry -- as in a trained model, and unlike two independent random fields.  This matters because sample_pdf
+    has a rounding-dependent discontinuity (denom < 1e-5 -> 1, :357) exactly on EMPTY coarse bins: which of those
+    bins collapse to their left edge depends on the last bit of the running cumsum, so no other implementation (nor
+    the reference on another BLAS) reproduces it sample-for-sample.  With consistent geometry the affected samples
+    carry ~zero weight in the fine pass and the rendered outputs are well defined."""
+    model.fine_model.load_state_dict(model.coarse_model.state_dict())
+    return {'fine_equals_coarse': 1}
+
+
 def make_e2e(cams):
     # eval-mode: config1 (world rays), config2 and headline (fern NDC rays)
     for kind, n, seed in (('config1', 512, 101), ('config2', 160, 102), ('headline', 128, 103),
                           ('headline_world', 64, 104)):
-        for profile in ('plain', 'dense'):
+        for profile in ('plain', 'dense', 'consistent'):
             cfg = synth.make_configs(kind)
+            if profile == 'consistent' and 'fine_mlp' not in cfg['model']:
+                continue
             model = ref_model(cfg, seed, training=False)
             if cfg['data_loader']['ndc']:
                 batch, pix = fern_batch(41, n, cams)
             else:
                 batch = {k: torch.from_numpy(v) for k, v in synth.random_world_rays(n, seed=1).items()}
                 pix = numpy.arange(n)
-            overrides = calibrate_density(model, batch, train_mode=False) if profile == 'dense' else {}
+            overrides = calibrate_density(model, batch, train_mode=False) if profile != 'plain' else {}
+            if profile == 'consistent':
+                overrides = {k: v for k, v in overrides.items() if not k.startswith('ovr_fine_model')}
+                overrides.update(tie_fine_to_coarse(model))
             with torch.no_grad():
                 out = model(batch, retraw=True)
                 out_plain = model(batch)
@@ -365,11 +381,15 @@ def make_e2e(cams):
     # train-mode: config3 (augmented MLPs run only when training)
     n = 96
     for variant, perturb, noise_std, profile in (('det', False, 0.0, 'dense'), ('rand', True, 1.0, 'dense'),
-                                                 ('rand', True, 1.0, 'plain')):
+                                                 ('rand', True, 1.0, 'plain'), ('det', False, 0.0, 'consistent'),
+                                                 ('rand', True, 1.0, 'consistent')):
         cfg = synth.with_overrides(synth.make_configs('config3'), perturb=perturb, raw_noise_std=noise_std)
         model = ref_model(cfg, 105, training=True)
         batch, pix = fern_batch(43, n, cams)
-        overrides = calibrate_density(model, batch, train_mode=True) if profile == 'dense' else {}
+        overrides = calibrate_density(model, batch, train_mode=True) if profile != 'plain' else {}
+        if profile == 'consistent':
+            overrides = {k: v for k, v in overrides.items() if not k.startswith('ovr_fine_model')}
+            overrides.update(tie_fine_to_coarse(model))
         torch.manual_seed(2024)
         with torch.no_grad():
             out = model(batch)
