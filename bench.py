@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/sec of the ray-marching hot path (coarse+fine, 128+128 samples, 8x256 MLPs).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over one batch of 1024 rays per GPU: on-device ray generation for the
+rank's pixel block of a fern frame, coarse depths, coarse MLP, compositing, inverse-CDF resampling + merge, fine MLP,
+compositing (eval mode, every reference output incl. alpha), and -- for N > 1 -- the single gather of the per-ray
+colour/depth to rank 0.  Inputs (camera, weights) are resident in HBM before the timed region.  Weak scaling: each
+rank renders its own 1024-ray block; `value` is the whole-job rays/s = N*1024*K / max-over-ranks time.
+
+Printed JSON (rank 0, one line) also carries
+  roofline      fp32-MFMA roofline of the dominant kernel (fused PE+MLP forward): algorithmic FLOPs of its launches
+                inside the timed region / their HIP-event durations, against 157.3 TFLOP/s (MI355X_MICROARCH.md)
+  cpu_baseline  the oracle (torch CPU fp32 restatement of the reference path, reference chunking) timed on this
+                host on the same 1024-ray batch, best of 5 after one warm-up
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from simplenerf_amd import harness, ops, synth  # noqa: E402
+from simplenerf_amd.models.ModelFactory import get_model  # noqa: E402
+
+RAYS_PER_GPU = 1024
+FLOP_PER_SAMPLE = 2 * 593408          # main 8x256 MLP, Linear layers only
+PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+WORKLOAD = ('headline: 1024 rays/GPU x (128 coarse + 128 fine -> 256 merged) samples, 8x256 coarse+fine MLPs, '
+            'LLFF fern NDC rays, eval')
+
+
+def synthetic_model(configs, seed, device):
+    model = get_model(configs, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed, sigma_gain=200.0, sigma_shift=8.0).items()})
+    return model.to(device).eval()
+
+
+def host_cores():
+    """Threads for the CPU leg: the cores this process may run on, capped at the GPU box's per-GPU CPU share (16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(configs, camera, first_ray):
+    """Oracle on the host CPU, same rays and weights as the GPU step; bounded: 1 warm-up + 5 runs of 1024 rays."""
+    from oracle import nerf_oracle, raygen_oracle
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    shapes = {k: tuple(v.shape) for k, v in get_model(configs, None).state_dict().items()}
+    params = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, sigma_gain=200.0, sigma_shift=8.0).items()}
+    full = raygen_oracle.full_frame_batch(camera['resolution'], camera['intrinsic'], camera['pose'], camera['near'],
+                                          camera['far'], True, camera['near_ndc'], camera['far_ndc'])
+    batch = {k: torch.from_numpy(numpy.ascontiguousarray(v[first_ray:first_ray + RAYS_PER_GPU])) for k, v in full.items()}
+    best = float('inf')
+    with torch.no_grad():
+        for i in range(6):
+            t0 = time.perf_counter()
+            nerf_oracle.render(params, configs, batch, training=False)
+            dt = time.perf_counter() - t0
+            if i > 0:
+                best = min(best, dt)
+    return {'value': RAYS_PER_GPU / best, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{RAYS_PER_GPU} rays of the same workload, best of 5 after 1 warm-up ({best:.3f} s each), '
+                      f'torch {torch.__version__} CPU fp32, chunk 4096 / netchunk 16384'}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run (profiles/), or None."""
+    path = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f).get('mlp_forward_hbm_bytes_per_launch')
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP renderer has no CPU path')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    configs = synth.make_configs('headline')
+    camera = synth.camera('fern', 0)
+    h, w = camera['resolution']
+    model = synthetic_model(configs, 7, device)
+    # rank r renders pixels [base + r*1024, base + (r+1)*1024) from the middle of the frame
+    base = (h // 2) * w
+    first = base + rank * RAYS_PER_GPU
+    keys = ('rgb_fine', 'depth_fine')
+
+    def step():
+        batch = harness.frame_batch(camera, True, device, first, RAYS_PER_GPU)
+        out = model(batch)
+        local = {k: out[k] for k in keys}
+        if world > 1:
+            return harness.gather_rays(local, world * RAYS_PER_GPU, rank, world)
+        return local
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        fence()
+        ops.PackedMlp.event_log = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    log, ops.PackedMlp.event_log = ops.PackedMlp.event_log, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        kernel_ms = sum(a.elapsed_time(b) for a, b, _ in log)
+        kernel_flop = sum(n for _, _, n in log) * FLOP_PER_SAMPLE
+        achieved = kernel_flop / (kernel_ms * 1e-3) / 1e12
+        result = {
+            'metric': 'rays/sec (coarse+fine, 128+128 samples)',
+            'value': world * RAYS_PER_GPU * args.steps / elapsed,
+            'unit': 'rays/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': WORKLOAD, 'rays_per_gpu': RAYS_PER_GPU, 'samples': '128+128',
+                       'parallelism': f'ray-shard x{world}' + (' + 1 gather/step' if world > 1 else '')},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(),
+                         'kernel': 'mlp_forward_kernel<8,4,true,false>', 'launches': len(log),
+                         'avg_launch_ms': kernel_ms / max(1, len(log)),
+                         'kernel_share_of_step': kernel_ms / (elapsed * 1e3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(configs, camera, first)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

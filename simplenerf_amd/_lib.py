@@ -50,6 +50,10 @@ def load() -> ctypes.CDLL:
         raise RuntimeError(
             f'{LIB_PATH} is missing: the HIP renderer has not been built. Run `python -m simplenerf_amd.build` '
             f'(needs hipcc; cross-compiles for gfx950 without a GPU). There is no fallback implementation.')
+    # The process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as
+    # /opt/rocm's); importing torch first makes the dynamic linker bind this library to that already-loaded copy, so
+    # device pointers, streams and the primary context are shared with torch's allocator.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -1,0 +1,97 @@
+"""Minimal counterpart of the reference's Tester call path around the model (last row):
+full-frame input batch -> ``model(batch)`` under no_grad -> display post-processing, plus the ray-sharded
+multi-GPU variant (one process per GPU, contiguous block of rays per rank, one gather of the per-ray outputs).
+
+Reference call sites restated here: DataPreprocessor.create_test_data (src/data_preprocessors/DataPreprocessor01.py
+:807-895), NerfTester.predict_frame (src/Tester01.py:57-66), post_process_image/depth (:1106-1114).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Optional, Tuple
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+DEFAULT_KEYS = ('rgb_fine', 'depth_fine', 'depth_var_fine')
+
+
+def shard_range(num_rays: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous block partition: rank r owns rays [r*ceil(N/R), min(N, (r+1)*ceil(N/R)))  (SURVEY 8e)."""
+    per = -(-num_rays // world_size)
+    first = min(num_rays, rank * per)
+    return first, min(num_rays, first + per) - first
+
+
+def frame_batch(camera: dict, ndc: bool, device, first_ray: int = 0, num_rays: Optional[int] = None) -> Dict[str, Tensor]:
+    """Input dictionary for rays [first_ray, first_ray+num_rays) of a frame, generated on the device (K1)."""
+    h, w = camera['resolution']
+    if num_rays is None:
+        num_rays = h * w - first_ray
+    batch = ops.generate_rays((h, w), camera['intrinsic'], camera['pose'], camera['near'], ndc, device, first_ray, num_rays)
+    col = lambda v: torch.full((num_rays, 1), float(v), dtype=torch.float32, device=device)
+    batch['near'], batch['far'] = col(camera['near']), col(camera['far'])
+    if ndc:
+        batch['near_ndc'], batch['far_ndc'] = col(camera.get('near_ndc', 0.0)), col(camera.get('far_ndc', 1.0))
+    return batch
+
+
+@torch.no_grad()
+def render_rays_blockwise(model, camera: dict, ndc: bool, device, first_ray: int, num_rays: int,
+                          keys: Iterable[str] = DEFAULT_KEYS, ray_block: int = 65536) -> Dict[str, Tensor]:
+    """Render a ray range in blocks (bounding the per-sample buffers), keeping only ``keys``."""
+    keys = tuple(keys)
+    pieces = {k: [] for k in keys}
+    for start in range(first_ray, first_ray + num_rays, ray_block):
+        count = min(ray_block, first_ray + num_rays - start)
+        out = model(frame_batch(camera, ndc, device, start, count))
+        for k in keys:
+            pieces[k].append(out[k])
+    if num_rays == 0:
+        return {k: torch.empty((0,), device=device) for k in keys}
+    return {k: torch.cat(v, 0) for k, v in pieces.items()}
+
+
+def gather_rays(local: Dict[str, Tensor], num_rays: int, rank: int, world_size: int, dst: int = 0,
+                group=None) -> Optional[Dict[str, Tensor]]:
+    """One gather of the per-ray outputs of every rank's block to ``dst`` (all keys packed into one buffer, so it
+    is a single collective).  Returns the full-frame tensors on ``dst`` and None elsewhere."""
+    import torch.distributed as dist
+    per = -(-num_rays // world_size)
+    keys = sorted(local)
+    cols = [local[k].reshape(local[k].shape[0], -1) for k in keys]
+    widths = [c.shape[1] for c in cols]
+    packed = torch.cat(cols, 1) if cols else torch.empty((0, 0))
+    pad = torch.zeros((per, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+    pad[:packed.shape[0]] = packed
+    bucket = [torch.empty_like(pad) for _ in range(world_size)] if rank == dst else None
+    dist.gather(pad, bucket, dst=dst, group=group)
+    if rank != dst:
+        return None
+    full = torch.cat(bucket, 0)[:num_rays]
+    out, c0 = {}, 0
+    for k, wdt in zip(keys, widths):
+        out[k] = full[:, c0:c0 + wdt].reshape((num_rays,) + tuple(local[k].shape[1:]))
+        c0 += wdt
+    return out
+
+
+@torch.no_grad()
+def render_frame(model, camera: dict, ndc: bool, device, keys: Iterable[str] = DEFAULT_KEYS, rank: int = 0,
+                 world_size: int = 1, ray_block: int = 65536) -> Optional[Dict[str, Tensor]]:
+    """Full frame, (h*w, .) per key.  With world_size > 1 every rank renders its block and rank 0 receives the
+    frame through one gather (returns None on the other ranks)."""
+    h, w = camera['resolution']
+    n = h * w
+    first, count = shard_range(n, rank, world_size)
+    local = render_rays_blockwise(model, camera, ndc, device, first, count, keys, ray_block)
+    if world_size == 1:
+        return local
+    return gather_rays(local, n, rank, world_size)
+
+
+def to_display(rgb: Tensor, depth: Tensor):
+    """clip -> round(255 x) -> uint8 colour; depth clipped at 0 (post_process_image / post_process_depth)."""
+    img = torch.round(torch.clamp(rgb, 0, 1) * 255).to(torch.uint8)
+    return img, torch.clamp(depth, min=0)

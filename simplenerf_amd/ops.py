@@ -92,6 +92,10 @@ def mlp_desc(mlp_cfg: dict) -> MlpDesc:
 class PackedMlp:
     """Device-resident packed weight stream of one MLP (see csrc/mlp_layout.h)."""
 
+    # When set to a list, every forward() brackets its kernel launch with a pair of events recorded on the launch
+    # stream and appends (start, end, num_samples) -- bench.py uses this to time the dominant kernel in situ.
+    event_log = None
+
     def __init__(self, mlp_cfg: dict, device):
         lib = _lib.load()
         self.desc = mlp_desc(mlp_cfg)
@@ -130,10 +134,17 @@ class PackedMlp:
             sigma_noise = _dev(sigma_noise.reshape(n, s), 'sigma_noise', (n, s))
         sigma = torch.empty((n, s, 1), dtype=torch.float32, device=depths.device)
         rgb = torch.empty((n, s, 3), dtype=torch.float32, device=depths.device)
+        log = PackedMlp.event_log
         with torch.cuda.device(depths.device):
+            if log is not None:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
             st = lib.snerf_mlp_forward(ctypes.byref(self.desc), _ptr(self.buffer), _ptr(origins), _ptr(dirs),
                                        _ptr(view_dirs), _ptr(depths), n, s, _ptr(sigma_noise), _ptr(sigma), _ptr(rgb), 0,
                                        _stream())
+            if log is not None:
+                t1.record()
+                log.append((t0, t1, n * s))
         _lib.check(st, 'snerf_mlp_forward')
         return sigma, rgb
 
