@@ -29,7 +29,7 @@ enum snerf_status {
 };
 
 /* ABI version of this header; bumped on any signature change. */
-#define SNERF_ABI_VERSION 1
+#define SNERF_ABI_VERSION 2
 int snerf_abi_version(void);
 const char* snerf_last_error(void);
 
@@ -104,6 +104,27 @@ int snerf_mlp_forward(const snerf_mlp_desc* desc, const float* packed, const flo
                       const float* view_dirs, const float* depths, long long num_rays, int num_samples,
                       const float* sigma_noise, float* sigma, float* rgb, int precision, snerf_stream_t stream);
 
+/* ---- training: forward that keeps the per-layer activations, and the parameter-gradient backward (K7) -----------
+ * Together they replace what autograd records and replays for MLP.forward (src/models/SimpleNeRF01.py:626-715).
+ *   saved_acts   device, snerf_mlp_saved_floats(desc, num_rays, num_samples) floats, written by forward_train and
+ *                read by backward ([32-sample block][feature][32] tiles: encodings and every layer's input)
+ *   d_sigma (n,S), d_rgb (n,S,3)   device: gradients w.r.t. the `sigma` / `rgb` outputs of the forward
+ *   sigma, rgb                      device: those outputs themselves (ReLU / sigmoid derivatives)
+ *   workspace    device, snerf_mlp_backward_workspace_floats(...) floats of scratch
+ *   param_grads  num_params device pointers, same order and shapes as snerf_mlp_pack's `params`; each tensor is
+ *                OVERWRITTEN with dL/dparam (sums over samples are taken in a fixed order: bit-reproducible)
+ * Inputs (rays, depths, view directions) receive no gradient -- the reference detaches the sample depths (:312).
+ */
+size_t snerf_mlp_saved_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples);
+int snerf_mlp_forward_train(const snerf_mlp_desc* desc, const float* packed, const float* origins, const float* dirs,
+                            const float* view_dirs, const float* depths, long long num_rays, int num_samples,
+                            const float* sigma_noise, float* sigma, float* rgb, float* saved_acts, int precision,
+                            snerf_stream_t stream);
+size_t snerf_mlp_backward_workspace_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples);
+int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packed, const float* saved_acts, const float* sigma,
+                       const float* rgb, const float* d_sigma, const float* d_rgb, long long num_rays, int num_samples,
+                       float* workspace, float* const* param_grads, int num_params, snerf_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * K4  alpha compositing.  Replaces SimpleNeRF.volume_rendering (src/models/SimpleNeRF01.py:430-483) and
  * convert_depth_from_ndc (:486-502).
@@ -118,6 +139,15 @@ int snerf_composite(const float* sigma, const float* rgb, const float* depths, c
                     int white_bkgd, float* out_rgb, float* out_acc, float* out_alpha, float* out_visibility,
                     float* out_weights, float* out_depth, float* out_depth_var, float* out_depth_ndc,
                     float* out_depth_var_ndc, snerf_stream_t stream);
+
+/* K6  backward of the compositing (autograd of volume_rendering :446-460): per-ray gradients of rgb / acc / depth /
+ * depth_ndc (each (n,3) or (n), any may be NULL = zero) -> d_sigma (n,S), d_rgb (n,S,3).  `depth` is the world depth
+ * for NDC scenes, as in the forward.  No gradient is produced for depth_var* (no reference loss reads them).
+ */
+int snerf_composite_backward(const float* sigma, const float* rgb, const float* depths, const float* march_dirs,
+                             const float* rays_o, const float* rays_d, long long num_rays, int num_samples, int ndc,
+                             int white_bkgd, const float* grad_rgb, const float* grad_acc, const float* grad_depth,
+                             const float* grad_depth_ndc, float* d_sigma, float* d_rgb, snerf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * K5  hierarchical resampling.  Replaces SimpleNeRF.get_z_vals_fine (src/models/SimpleNeRF01.py:304-315) and

@@ -73,7 +73,7 @@ def resample_depths(z_coarse: Tensor, weights_coarse: Tensor, num_fine: int, u: 
     denom = cdf_a - cdf_b
     denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
     t = (u - cdf_b) / denom
-    samples = bin_b + t * (bin_a - bin_b)
+    samples = (bin_b + t * (bin_a - bin_b)).detach()  # no gradient through the sample positions (:312)
     z_fine, _ = torch.sort(torch.cat([z_coarse, samples], -1), -1)
     return z_fine
 

@@ -143,6 +143,132 @@ void launch(const CompositeArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(composite_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// K6 -- backward of the compositing: (d rgb, d acc, d depth, d depth_ndc) per ray -> d sigma, d rgb per sample.
+// Autograd of volume_rendering (:446-460) in closed form:
+//   g_j = dL/dw_j = g_rgb . c_j + g_acc + g_depth (zd_j - depth)/(acc+1e-6) + g_depth_ndc (z_j - depth_ndc)/(acc+1e-6)
+//   dL/dalpha_j = g_j T_j - (sum_{k>j} g_k w_k) / (1 - alpha_j + 1e-10)        (reverse wavefront scan)
+//   dL/dsigma_j = dL/dalpha_j . delta_j . (1 - alpha_j);      dL/dc_j = w_j g_rgb
+// Same wave-per-ray, lane-blocked layout as the forward; the forward quantities are recomputed, not stored.
+struct CompositeBwdArgs {
+    const float* sigma; const float* rgb; const float* z; const float* march_dirs; const float* rays_o; const float* rays_d;
+    const float* g_rgb; const float* g_acc; const float* g_depth; const float* g_depth_ndc;
+    float* d_sigma; float* d_rgb;
+    long long num_rays; int s; int ndc; int white;
+};
+
+template <int C>
+__global__ void __launch_bounds__(256) composite_backward_kernel(CompositeBwdArgs a) {
+    const int lane = snerf::lane_id();
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= a.num_rays) return;
+    const int s = a.s;
+    const float* zr = a.z + ray * s;
+    const float* sr = a.sigma + ray * s;
+    const float* cr = a.rgb + ray * s * 3;
+    const int j0 = lane * C;
+    float z[C + 1], sg[C], col[C][3];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int j = j0 + c;
+        const bool in = j < s;
+        z[c] = in ? zr[j] : 0.0f;
+        sg[c] = in ? sr[j] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) col[c][k] = in ? cr[3 * j + k] : 0.0f;
+    }
+    const float far_cap = a.ndc ? 1.0f : 1e10f;
+    z[C] = __shfl_down(z[0], 1, 64);
+    if (j0 + C >= s) z[C] = far_cap;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        if (j0 + c == s - 1) z[c + 1] = far_cap;
+    const float* md = a.march_dirs + ray * 3;
+    const float norm = sqrtf((md[0] * md[0] + md[1] * md[1]) + md[2] * md[2]);
+
+    float alpha[C], delta[C], keep = 1.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const bool in = j0 + c < s;
+        delta[c] = (z[c + 1] - z[c]) * norm;
+        alpha[c] = in ? 1.0f - expf(-sg[c] * delta[c]) : 0.0f;
+        keep *= in ? (1.0f - alpha[c]) + 1e-10f : 1.0f;
+    }
+    const float incl = snerf::wave_inclusive_mul(keep);
+    float trans = __shfl_up(incl, 1, 64);
+    if (lane == 0) trans = 1.0f;
+    float T[C], w[C], acc = 0.0f, dzm = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        T[c] = trans;
+        w[c] = alpha[c] * trans;
+        trans *= (1.0f - alpha[c]) + 1e-10f;
+        acc += w[c];
+        dzm += w[c] * z[c];
+    }
+    acc = snerf::wave_sum(acc);
+    dzm = snerf::wave_sum(dzm);
+    const float inv = __fdiv_rn(1.0f, acc + 1e-6f);
+    const float depth_march = dzm * inv;
+    // depth the loss sees as 'depth': world depth for NDC scenes
+    float zd[C];
+    float depth = depth_march;
+    if (a.ndc) {
+        const float oz = a.rays_o[ray * 3 + 2], dzw = a.rays_d[ray * 3 + 2];
+        const float tn = __fdiv_rn(-(1.0f + oz), dzw);
+        const float scale = __fdiv_rn(oz + tn * dzw, dzw);
+        float dw = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float cst = (z[c] == 1.0f) ? 1e-3f : 0.0f;
+            zd[c] = scale * (__fdiv_rn(1.0f, (1.0f - z[c]) + cst) - 1.0f) + tn;
+            dw += w[c] * zd[c];
+        }
+        depth = snerf::wave_sum(dw) * inv;
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) zd[c] = z[c];
+    }
+    const float gr = a.g_rgb ? a.g_rgb[ray * 3 + 0] : 0.0f;
+    const float gg = a.g_rgb ? a.g_rgb[ray * 3 + 1] : 0.0f;
+    const float gb = a.g_rgb ? a.g_rgb[ray * 3 + 2] : 0.0f;
+    float gacc = a.g_acc ? a.g_acc[ray] : 0.0f;
+    if (a.white) gacc -= (gr + gg) + gb;  // rgb += 1 - acc
+    const float gdep = (a.g_depth ? a.g_depth[ray] : 0.0f) * inv;
+    const float gdn = (a.ndc && a.g_depth_ndc ? a.g_depth_ndc[ray] : 0.0f) * inv;
+
+    float g[C], local = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        g[c] = ((gr * col[c][0] + gg * col[c][1]) + gb * col[c][2]) + gacc + gdep * (zd[c] - depth) + gdn * (z[c] - depth_march);
+        local += g[c] * w[c];
+    }
+    // sum over strictly later samples of g_k w_k: later lanes via the suffix scan, later samples of this lane locally
+    const float suffix_incl = snerf::wave_suffix_add(local);
+    float after = __shfl_down(suffix_incl, 1, 64);  // everything owned by later lanes
+    if (lane == 63) after = 0.0f;
+#pragma unroll
+    for (int c = C - 1; c >= 0; --c) {
+        const int j = j0 + c;
+        if (j < s) {
+            const float u = (1.0f - alpha[c]) + 1e-10f;
+            const float dalpha = g[c] * T[c] - __fdiv_rn(after, u);
+            a.d_sigma[ray * s + j] = dalpha * (delta[c] * (1.0f - alpha[c]));
+            a.d_rgb[(ray * s + j) * 3 + 0] = w[c] * gr;
+            a.d_rgb[(ray * s + j) * 3 + 1] = w[c] * gg;
+            a.d_rgb[(ray * s + j) * 3 + 2] = w[c] * gb;
+        }
+        after += g[c] * w[c];
+    }
+}
+
+template <int C>
+void launch_bwd(const CompositeBwdArgs& a, hipStream_t stream) {
+    const long long blocks = (a.num_rays + 3) / 4;
+    hipLaunchKernelGGL(composite_backward_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+}
+
 }  // namespace
 
 extern "C" int snerf_composite(const float* sigma, const float* rgb, const float* depths, const float* march_dirs,
@@ -174,4 +300,32 @@ extern "C" int snerf_composite(const float* sigma, const float* rgb, const float
         default: launch<16>(a, st); break;
     }
     return snerf::check_launch("composite");
+}
+
+extern "C" int snerf_composite_backward(const float* sigma, const float* rgb, const float* depths, const float* march_dirs,
+                                        const float* rays_o, const float* rays_d, long long num_rays, int num_samples,
+                                        int ndc, int white_bkgd, const float* grad_rgb, const float* grad_acc,
+                                        const float* grad_depth, const float* grad_depth_ndc, float* d_sigma, float* d_rgb,
+                                        snerf_stream_t stream) {
+    SNERF_REQUIRE(sigma && rgb && depths && march_dirs && d_sigma && d_rgb, "composite_backward: NULL pointer");
+    SNERF_REQUIRE(!ndc || (rays_o && rays_d), "composite_backward: ndc needs the world rays");
+    SNERF_REQUIRE(num_rays >= 0 && num_samples >= 1, "composite_backward: bad sizes n=%lld S=%d", num_rays, num_samples);
+    if (num_samples > 64 * 16)
+        return snerf::fail(SNERF_E_UNSUPPORTED, "composite_backward: at most 1024 samples per ray (got %d)", num_samples);
+    if (num_rays == 0) return SNERF_OK;
+    if ((num_rays + 3) / 4 > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "composite_backward: too many rays");
+    CompositeBwdArgs a{sigma, rgb, depths, march_dirs, rays_o, rays_d, grad_rgb, grad_acc, grad_depth, grad_depth_ndc,
+                       d_sigma, d_rgb, num_rays, num_samples, ndc, white_bkgd};
+    hipStream_t st = (hipStream_t)stream;
+    const int c = (num_samples + 63) / 64;
+    switch (c) {
+        case 1: launch_bwd<1>(a, st); break;
+        case 2: launch_bwd<2>(a, st); break;
+        case 3: launch_bwd<3>(a, st); break;
+        case 4: launch_bwd<4>(a, st); break;
+        case 5: case 6: launch_bwd<6>(a, st); break;
+        case 7: case 8: launch_bwd<8>(a, st); break;
+        default: launch_bwd<16>(a, st); break;
+    }
+    return snerf::check_launch("composite_backward");
 }

@@ -1,0 +1,432 @@
+// K7 -- backward of the fused NeRF MLP: parameter gradients from d(sigma), d(rgb).
+//
+// Autograd of MLP.forward (src/models/SimpleNeRF01.py:626-715) restated as three kernel families, all on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32):
+//
+//  B1  mlp_backward_chain_kernel   "dgrad": the same register-resident transposed chain as the forward, run in
+//      reverse.  dX^T[in, sample] = W^T[in, out] . dY^T[out, sample]; dY^T lives in accumulator layout, so it is the
+//      B operand of the next (earlier) layer's product without leaving registers.  ReLU masks come from the
+//      activations saved by snerf_mlp_forward_train.  Every dY_l is also written as a [feature][32-sample] tile
+//      for B2.  Heads (1-4 rows) are VALU work.
+//  B2  wgrad_kernel<TPW>           dW[out, in] = sum_samples dY^T[out, s] . X^T[in, s] -- contraction over samples,
+//      so both operands are re-read from their tiles through LDS (padded rows, conflict-free ds_read_b128) with the
+//      feature index on the lanes.  One workgroup owns one (job, chunk of wave blocks); partial sums per chunk are
+//      written out and
+//  B3  reduce_kernel               sums the chunks in a fixed order (bit-reproducible; no float atomics) and scatters
+//      into the reference-layout gradient tensors (weight (out,in) row-major, bias).
+//
+// Bound: MFMA fp32; algorithmic FLOPs = 2x the forward's (dgrad + wgrad).  HBM per sample: reads ~10 KB of saved
+// activations + ~10 KB of dY tiles twice (B1 writes, B2 reads) -- about 40 KB/sample, i.e. ~2.5 TB/s at the full MFMA
+// rate: under the HBM roofline, overlapped with the matrix work.
+#include "mlp_device.h"
+
+namespace {
+
+struct ChainArgs {
+    const float* packed;
+    const float* acts;      // saved activation tiles
+    const float* sigma;     // (M)   post-ReLU density from the forward (mask of the density ReLU)
+    const float* rgb;       // (M,3) post-sigmoid colour from the forward
+    const float* d_sigma;   // (M)
+    const float* d_rgb;     // (M,3)
+    float* grads;           // dY tiles
+    long long total;
+    int depth, width;
+    long long dgrad_offset, pts_out_w, views_out_w;
+    int act_rows, act_h1, act_hv;
+    int grad_rows, grad_feature, grad_yv, grad_head;
+};
+
+template <int U>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+}
+
+// dy[n] = (saved activation of the same feature > 0) ? acc : 0, in accumulator order
+template <int U>
+__device__ __forceinline__ void relu_backward(const f32x16 (&acc)[U], const float* __restrict__ act_tile, int lane,
+                                              float (&dy)[U * 16]) {
+    const int j = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int n = 0; n < U * 16; ++n) {
+        const int f = 32 * (n >> 4) + (n & 3) + 8 * ((n & 15) >> 2) + 4 * half;
+        dy[n] = act_tile[f * 32 + j] > 0.0f ? acc[n >> 4][n & 15] : 0.0f;
+    }
+}
+
+template <int WT, int VT, bool VIEWDEP>
+__global__ void __launch_bounds__(256, 1) mlp_backward_chain_kernel(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    SlabStream<WT> st;
+    st.start(a.packed + a.dgrad_offset, lds, lane, wave);
+
+    const long long block = (long long)blockIdx.x * 4 + wave;
+    const long long first = block * 32 + (lane & 31);
+    const bool live = first < a.total;
+    const float* acts = a.acts + block * a.act_rows * 32;
+    float* grads = a.grads + block * a.grad_rows * 32;
+
+    // ---- head gradients (pre-activation), stored as rows 0..3 of the head tile -----------------------------------
+    float dhead[4];
+    dhead[0] = live && a.sigma[first] > 0.0f ? a.d_sigma[first] : 0.0f;     // ReLU of the density (:672)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float col = live ? a.rgb[first * 3 + c] : 0.0f;
+        dhead[c + 1] = live ? a.d_rgb[first * 3 + c] * (col * (1.0f - col)) : 0.0f;  // sigmoid' = y (1 - y)
+    }
+    if (half == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) grads[(a.grad_head + c) * 32 + (lane & 31)] = dhead[c];
+    }
+
+    f32x16 acc[WT];
+    zero_acc<WT>(acc);
+    float dy[WT * 16];
+    if (VIEWDEP) {
+        // d hv = W_rgb^T dpre, masked by the views-layer ReLU (:699-706)
+        const float* wv = a.packed + a.views_out_w;
+        const float* hv_tile = acts + a.act_hv * 32;
+        float dyv[VT * 16];
+#pragma unroll
+        for (int g = 0; g < VT * 4; ++g) {
+            f32x4 w0 = *reinterpret_cast<const f32x4*>(wv + 0 * VT * 32 + 8 * g + 4 * half);
+            f32x4 w1 = *reinterpret_cast<const f32x4*>(wv + 1 * VT * 32 + 8 * g + 4 * half);
+            f32x4 w2 = *reinterpret_cast<const f32x4*>(wv + 2 * VT * 32 + 8 * g + 4 * half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = 8 * g + 4 * half + q;
+                const float v = fmaf(w2[q], dhead[3], fmaf(w1[q], dhead[2], w0[q] * dhead[1]));
+                dyv[4 * g + q] = hv_tile[f * 32 + (lane & 31)] > 0.0f ? v : 0.0f;
+            }
+        }
+        store_acc_tile(dyv, grads + a.grad_yv * 32, lane);
+        // d feature = Wv[:, :width]^T dYv
+        gemm_segment<WT, VT, WT>(acc, dyv, st);
+        to_operand<WT, false>(acc, dy);
+        store_acc_tile(dy, grads + a.grad_feature * 32, lane);
+        // d h_depth = W_feature^T dfeature   (feature_linear has no activation, :683)
+        zero_acc<WT>(acc);
+        gemm_segment<WT, WT, WT>(acc, dy, st);
+    }
+    // + density head (and, without a views layer, the colour rows of pts_output_linear): d h += W_out^T dhead
+    {
+        const float* wo = a.packed + a.pts_out_w;
+#pragma unroll
+        for (int g = 0; g < WT * 4; ++g) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wo + 8 * g + 4 * half);
+            f32x4 w1 = {0, 0, 0, 0}, w2 = {0, 0, 0, 0}, w3 = {0, 0, 0, 0};
+            if (!VIEWDEP) {
+                w1 = *reinterpret_cast<const f32x4*>(wo + 1 * WT * 32 + 8 * g + 4 * half);
+                w2 = *reinterpret_cast<const f32x4*>(wo + 2 * WT * 32 + 8 * g + 4 * half);
+                w3 = *reinterpret_cast<const f32x4*>(wo + 3 * WT * 32 + 8 * g + 4 * half);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = w0[q] * dhead[0];
+                if (!VIEWDEP) v = fmaf(w3[q], dhead[3], fmaf(w2[q], dhead[2], fmaf(w1[q], dhead[1], v)));
+                acc[g >> 2][4 * (g & 3) + q] += v;
+            }
+        }
+    }
+    // ---- trunk, last layer first: dY_l = dh_{l+1} . [h_{l+1} > 0];  dh_l = W_l[:, h-columns]^T dY_l -------------
+#pragma unroll 1
+    for (int l = a.depth - 1; l >= 0; --l) {
+        relu_backward<WT>(acc, acts + (a.act_h1 + l * a.width) * 32, lane, dy);
+        store_acc_tile(dy, grads + (l * a.width) * 32, lane);
+        if (l == 0) break;
+        zero_acc<WT>(acc);
+        gemm_segment<WT, WT, WT>(acc, dy, st);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// B2: weight gradients
+// ------------------------------------------------------------------------------------------------
+struct WgradJob {
+    int dy_row0, out_rows, out_tiles;   // rows of the grads tile
+    int x_row0, in_rows, in_tiles;      // rows of the acts tile
+    int grad_rows, act_rows;            // tile heights (rows per wave block)
+    int chunks;
+    long long blocks;                   // wave blocks in total
+    long long partial_off;              // floats into the partial buffer: [chunk][out_tiles*32][in_tiles*32] then
+    long long bias_off;                 //                                  [chunk][out_tiles*32]
+    int w_param, w_ld, w_col;           // destination: grad of params[w_param] (out_rows x w_ld), columns from w_col
+    int b_param;                        // bias destination or -1
+};
+
+constexpr int kLdsRow = 36;  // 32 samples + 4 floats of padding: conflict-free ds_read_b128 over 16 consecutive rows
+
+template <int TPW>
+__global__ void __launch_bounds__(256, 1) wgrad_kernel(WgradJob job, const float* __restrict__ grads,
+                                                       const float* __restrict__ acts, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int chunk = blockIdx.x;
+    const int rows_dy = job.out_tiles * 32, rows_x = job.in_tiles * 32, rows = rows_dy + rows_x;
+    const int ntiles = job.out_tiles * job.in_tiles;
+    const long long per = (job.blocks + job.chunks - 1) / job.chunks;
+    const long long b0 = chunk * per, b1 = (b0 + per < job.blocks) ? b0 + per : job.blocks;
+
+    f32x16 acc[TPW];
+    float bsum[TPW];
+#pragma unroll
+    for (int n = 0; n < TPW; ++n) {
+        bsum[n] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+    }
+    float* lds_dy = lds;
+    float* lds_x = lds + rows_dy * kLdsRow;
+
+    constexpr int kMaxStage = 16;  // float4 per thread per block: (out_tiles + in_tiles) <= 16
+    f32x4 stage[kMaxStage];
+    auto fetch = [&](long long b) {
+#pragma unroll
+        for (int it = 0; it < kMaxStage; ++it) {
+            const int idx = it * 256 + tid;
+            const int row = idx >> 3, c4 = idx & 7;
+            f32x4 v = {0, 0, 0, 0};
+            if (row < rows) {
+                if (row < rows_dy) {
+                    if (row < job.out_rows) v = *reinterpret_cast<const f32x4*>(grads + (b * job.grad_rows + job.dy_row0 + row) * 32 + c4 * 4);
+                } else {
+                    const int xr = row - rows_dy;
+                    if (xr < job.in_rows) v = *reinterpret_cast<const f32x4*>(acts + (b * job.act_rows + job.x_row0 + xr) * 32 + c4 * 4);
+                }
+            }
+            stage[it] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < kMaxStage; ++it) {
+            const int idx = it * 256 + tid;
+            const int row = idx >> 3, c4 = idx & 7;
+            if (row < rows) *reinterpret_cast<f32x4*>(lds + row * kLdsRow + c4 * 4) = stage[it];
+        }
+    };
+
+    if (b0 < b1) fetch(b0);
+    for (long long b = b0; b < b1; ++b) {
+        __syncthreads();  // everyone finished reading the previous block's tiles
+        commit();
+        __syncthreads();
+        if (b + 1 < b1) fetch(b + 1);  // in flight during the MFMAs below
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int n = 0; n < TPW; ++n) {
+                const int t = wave + 4 * n;
+                if (t < ntiles) {
+                    const int o = t / job.in_tiles, i = t - o * job.in_tiles;
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(lds_dy + (o * 32 + (lane & 31)) * kLdsRow + 8 * g + 4 * half);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(lds_x + (i * 32 + (lane & 31)) * kLdsRow + 8 * g + 4 * half);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc[n], 0, 0, 0);
+                    if (i == 0) bsum[n] += (av[0] + av[1]) + (av[2] + av[3]);
+                }
+            }
+        }
+    }
+    // partial[chunk][o*32 + row][i*32 + col]
+    const int in_cols = job.in_tiles * 32;
+    float* out = partial + job.partial_off + (long long)chunk * rows_dy * in_cols;
+    float* bout = partial + job.bias_off + (long long)chunk * rows_dy;
+#pragma unroll
+    for (int n = 0; n < TPW; ++n) {
+        const int t = wave + 4 * n;
+        if (t < ntiles) {
+            const int o = t / job.in_tiles, i = t - o * job.in_tiles;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                out[(long long)(o * 32 + row) * in_cols + i * 32 + (lane & 31)] = acc[n][r];
+            }
+            if (i == 0) {
+                const float s = bsum[n] + __shfl_xor(bsum[n], 32, 64);
+                if (half == 0) bout[o * 32 + lane] = s;
+            }
+        }
+    }
+}
+
+// B3: fixed-order sum over chunks, scattered into the reference-layout gradient tensors
+__global__ void __launch_bounds__(256) reduce_kernel(WgradJob job, const float* __restrict__ partial,
+                                                     float* __restrict__ grad_w, float* __restrict__ grad_b) {
+    const int in_cols = job.in_tiles * 32, rows_dy = job.out_tiles * 32;
+    const long long nw = (long long)job.out_rows * job.in_rows;
+    const long long total = nw + (grad_b ? job.out_rows : 0);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        if (idx < nw) {
+            const int o = (int)(idx / job.in_rows), i = (int)(idx - (long long)o * job.in_rows);
+            const float* p = partial + job.partial_off + (long long)o * in_cols + i;
+            float s = 0.0f;
+            for (int c = 0; c < job.chunks; ++c) s += p[(long long)c * rows_dy * in_cols];
+            grad_w[(long long)o * job.w_ld + job.w_col + i] = s;
+        } else {
+            const int o = (int)(idx - nw);
+            const float* p = partial + job.bias_off + o;
+            float s = 0.0f;
+            for (int c = 0; c < job.chunks; ++c) s += p[(long long)c * rows_dy];
+            grad_b[o] = s;
+        }
+    }
+}
+
+struct Workspace {
+    long long grads_floats, partial_floats, total_floats;
+    std::vector<WgradJob> jobs;
+};
+
+Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples) {
+    Workspace w;
+    const long long blocks = (total_samples + 127) / 128 * 4;
+    w.grads_floats = blocks * p.grad_rows() * 32;
+    long long chunks = blocks / 8;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 128) chunks = 128;
+    long long off = 0;
+    auto add = [&](int dy_row0, int out_rows, int x_row0, int in_rows, int w_param, int w_ld, int w_col, int b_param) {
+        WgradJob j;
+        j.dy_row0 = dy_row0; j.out_rows = out_rows; j.out_tiles = (out_rows + 31) / 32;
+        j.x_row0 = x_row0; j.in_rows = in_rows; j.in_tiles = (in_rows + 31) / 32;
+        j.grad_rows = p.grad_rows(); j.act_rows = p.act_rows();
+        j.chunks = (int)chunks; j.blocks = blocks;
+        j.partial_off = off;
+        off += chunks * j.out_tiles * 32 * j.in_tiles * 32;
+        j.bias_off = off;
+        off += chunks * j.out_tiles * 32;
+        j.w_param = w_param; j.w_ld = w_ld; j.w_col = w_col; j.b_param = b_param;
+        w.jobs.push_back(j);
+    };
+    const int d = p.depth, wd = p.width;
+    // trunk layer l: dY_l x [encoding | h_l]
+    add(p.grad_y(0), wd, p.act_pe(), p.pts_in, 0, p.pts_in, 0, 1);
+    for (int l = 1; l < d; ++l) {
+        const bool skip_in = (l == 5);
+        const int ld = wd + (skip_in ? p.pts_in : 0);
+        add(p.grad_y(l), wd, p.act_h(l), wd, 2 * l, ld, skip_in ? p.pts_in : 0, 2 * l + 1);
+        if (skip_in) add(p.grad_y(l), wd, p.act_pe(), p.pts_in, 2 * l, ld, 0, -1);
+    }
+    // heads: rows of the head tile are [d sigma_raw, d rgb_pre(3)]
+    if (p.view_dependent) {
+        add(p.grad_head(), 1, p.act_h(d), wd, 2 * d, wd, 0, 2 * d + 1);                      // pts_output_linear (1 row)
+        add(p.grad_feature(), wd, p.act_h(d), wd, 2 * d + 2, wd, 0, 2 * d + 3);               // feature_linear
+        const int ldv = wd + p.extra + p.views_pe;
+        add(p.grad_yv(), p.views_width, p.act_feature(), wd, 2 * d + 4, ldv, 0, 2 * d + 5);    // views_linears.0 | feature
+        if (p.sigma_pe) add(p.grad_yv(), p.views_width, p.act_pe() + p.pts_in, p.extra, 2 * d + 4, ldv, wd, -1);
+        add(p.grad_yv(), p.views_width, p.act_pev(), p.views_pe, 2 * d + 4, ldv, wd + p.extra, -1);
+        add(p.grad_head() + 1, 3, p.act_hv(), p.views_width, 2 * d + 6, p.views_width, 0, 2 * d + 7);  // views_output_linear
+    } else {
+        add(p.grad_head(), 4, p.act_h(d), wd, 2 * d, wd, 0, 2 * d + 1);                      // pts_output_linear (4 rows)
+    }
+    w.partial_floats = off;
+    w.total_floats = w.grads_floats + w.partial_floats;
+    return w;
+}
+
+template <int WT, int VT, bool VIEWDEP>
+int launch_chain(const ChainArgs& a, hipStream_t stream) {
+    const long long blocks = (a.total + 127) / 128;
+    const size_t lds_bytes = 2 * sizeof(float) * SlabStream<WT>::kBufFloats;
+    auto kernel = mlp_backward_chain_kernel<WT, VT, VIEWDEP>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a);
+    return snerf::check_launch("mlp_backward(chain)");
+}
+
+template <int TPW>
+int launch_wgrad(const WgradJob& job, const float* grads, const float* acts, float* partial, hipStream_t stream) {
+    const size_t lds_bytes = sizeof(float) * (size_t)(job.out_tiles + job.in_tiles) * 32 * kLdsRow;
+    auto kernel = wgrad_kernel<TPW>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(sizeof(float) * 16 * 32 * kLdsRow));
+        if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)job.chunks), dim3(256), lds_bytes, stream, job, grads, acts, partial);
+    return snerf::check_launch("mlp_backward(wgrad)");
+}
+
+}  // namespace
+
+extern "C" size_t snerf_mlp_backward_workspace_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples) {
+    snerf::MlpPlan plan;
+    if (snerf::build_plan(desc, &plan) != SNERF_OK || num_rays < 0 || num_samples < 1) return 0;
+    return (size_t)plan_workspace(plan, num_rays * num_samples).total_floats;
+}
+
+extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packed, const float* saved_acts,
+                                  const float* sigma, const float* rgb, const float* d_sigma, const float* d_rgb,
+                                  long long num_rays, int num_samples, float* workspace, float* const* param_grads,
+                                  int num_params, snerf_stream_t stream) {
+    snerf::MlpPlan plan;
+    const int st = snerf::build_plan(desc, &plan);
+    if (st != SNERF_OK) return st;
+    SNERF_REQUIRE(packed && saved_acts && sigma && rgb && d_sigma && d_rgb && workspace && param_grads,
+                  "mlp_backward: NULL pointer");
+    SNERF_REQUIRE(num_params == plan.num_params, "mlp_backward: expected %d gradient tensors, got %d", plan.num_params,
+                  num_params);
+    for (int i = 0; i < num_params; ++i) SNERF_REQUIRE(param_grads[i], "mlp_backward: gradient tensor %d is NULL", i);
+    SNERF_REQUIRE(num_rays >= 1 && num_samples >= 1, "mlp_backward: bad sizes n=%lld S=%d", num_rays, num_samples);
+    const long long total = num_rays * num_samples;
+    if ((total + 127) / 128 > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many samples");
+    hipStream_t s = (hipStream_t)stream;
+    const Workspace ws = plan_workspace(plan, total);
+    float* grads = workspace;
+    float* partial = workspace + ws.grads_floats;
+
+    ChainArgs a;
+    a.packed = packed; a.acts = saved_acts; a.sigma = sigma; a.rgb = rgb; a.d_sigma = d_sigma; a.d_rgb = d_rgb;
+    a.grads = grads; a.total = total; a.depth = plan.depth; a.width = plan.width;
+    a.dgrad_offset = plan.dgrad_offset; a.pts_out_w = plan.pts_out_w(); a.views_out_w = plan.views_out_w();
+    a.act_rows = plan.act_rows(); a.act_h1 = plan.act_h(1); a.act_hv = plan.act_hv();
+    a.grad_rows = plan.grad_rows(); a.grad_feature = plan.grad_feature(); a.grad_yv = plan.grad_yv();
+    a.grad_head = plan.grad_head();
+    int rc;
+    const int key = plan.wt * 10 + plan.vt;
+    switch (key) {
+        case 84: rc = launch_chain<8, 4, true>(a, s); break;
+        case 80: rc = launch_chain<8, 4, false>(a, s); break;
+        case 42: rc = launch_chain<4, 2, true>(a, s); break;
+        case 40: rc = launch_chain<4, 2, false>(a, s); break;
+        default: return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: width %d / views width %d not built", plan.width,
+                                    plan.views_width);
+    }
+    if (rc != SNERF_OK) return rc;
+    for (const WgradJob& job : ws.jobs) {
+        const int tiles = job.out_tiles * job.in_tiles;
+        const int tpw = (tiles + 3) / 4;
+        if (tpw <= 1) rc = launch_wgrad<1>(job, grads, saved_acts, partial, s);
+        else if (tpw <= 2) rc = launch_wgrad<2>(job, grads, saved_acts, partial, s);
+        else if (tpw <= 4) rc = launch_wgrad<4>(job, grads, saved_acts, partial, s);
+        else if (tpw <= 8) rc = launch_wgrad<8>(job, grads, saved_acts, partial, s);
+        else rc = launch_wgrad<16>(job, grads, saved_acts, partial, s);
+        if (rc != SNERF_OK) return rc;
+        const long long work = (long long)job.out_rows * job.in_rows + job.out_rows;
+        hipLaunchKernelGGL(reduce_kernel, dim3(snerf::stride_grid(work, 256)), dim3(256), 0, s, job, partial,
+                           param_grads[job.w_param], job.b_param >= 0 ? param_grads[job.b_param] : nullptr);
+        rc = snerf::check_launch("mlp_backward(reduce)");
+        if (rc != SNERF_OK) return rc;
+    }
+    return SNERF_OK;
+}

@@ -1,0 +1,202 @@
+// Device-side building blocks shared by the fused MLP forward (mlp_forward.hip) and backward (mlp_backward.hip)
+// kernels: the LDS slab stream, the register-resident transposed GEMM segment, operand conversion, positional
+// encoding.  See mlp_layout.h for the operand algebra.
+#pragma once
+#include "mlp_plan.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MlpArgs {
+    const float* packed;
+    const float* origins;
+    const float* dirs;
+    const float* view_dirs;
+    const float* depths;
+    const float* noise;
+    float* sigma;
+    float* rgb;
+    long long total;  // rays * samples
+    int samples;
+    int depth;
+    int width;
+    long long bias_offset, feature_bias, views_bias, pts_out_w, pts_out_b, views_out_w, views_out_b;
+    // training only: saved-activation tiles, [wave block][act_rows][32 samples] (mlp_plan.h)
+    float* acts;
+    int act_rows, act_pev, act_h1, act_feature, act_hv;
+};
+
+// ---- [feature][32-sample] tile stores/loads of one wave block (rows in natural feature order) -------------------
+// accumulator-ordered registers: register 16u+r of lane (j, half) is feature 32u + (r&3) + 8(r>>2) + 4*half
+template <int N>
+__device__ __forceinline__ void store_acc_tile(const float (&h)[N], float* __restrict__ tile, int lane) {
+    const int j = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const int f = 32 * (n >> 4) + (n & 3) + 8 * ((n & 15) >> 2) + 4 * half;
+        tile[f * 32 + j] = h[n];
+    }
+}
+template <int N>
+__device__ __forceinline__ void load_acc_tile(float (&h)[N], const float* __restrict__ tile, int lane) {
+    const int j = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const int f = 32 * (n >> 4) + (n & 3) + 8 * ((n & 15) >> 2) + 4 * half;
+        h[n] = tile[f * 32 + j];
+    }
+}
+// positional-encoding registers -> rows in the reference's encoding order (pads skipped)
+template <int PAIRS, int NREG>
+__device__ __forceinline__ void store_pe_tile(const float (&pe)[NREG], float* __restrict__ tile, int lane) {
+    const int j = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int n = 0; n < NREG; ++n) {
+        const int e0 = snerf::pe_feature(n, 0, PAIRS, 16), e1 = snerf::pe_feature(n, 1, PAIRS, 16);
+        const int e = half ? e1 : e0;
+        if (e >= 0) tile[e * 32 + j] = pe[n];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight slab stream: L2 -> LDS by LDS-DMA, double buffered
+// ------------------------------------------------------------------------------------------------
+template <int WT>
+struct SlabStream {
+    static constexpr int kBufFloats = WT * 1024;  // 16 k-steps x WT tiles x 64 lanes x 4
+    const float* cur;                             // global address of the slab about to be consumed
+    float* lds;
+    int parity;
+    int lane, wave;
+
+    __device__ __forceinline__ void fetch(const float* src, float* dst) const {
+#pragma unroll
+        for (int i = 0; i < WT; ++i) {
+            const int chunk = i * 4 + wave;  // 1 KiB per wave-instruction
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + chunk * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(dst + chunk * 256), 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void start(const float* first, float* lds_base, int lane_, int wave_) {
+        cur = first; lds = lds_base; parity = 0; lane = lane_; wave = wave_;
+        fetch(cur, lds);
+    }
+    // Make the current slab (U tiles wide) readable and start fetching the one after it.
+    template <int U>
+    __device__ __forceinline__ const float* acquire() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of the current slab has landed
+        __syncthreads();                                  // everyone's has, and everyone left the other buffer
+        const float* ready = lds + parity * kBufFloats;
+        fetch(cur + U * 1024, lds + (parity ^ 1) * kBufFloats);
+        cur += U * 1024;
+        parity ^= 1;
+        return ready;
+    }
+};
+
+// acc[u] += W_segment[u-th 32 rows] . B, B = `b` (one register per k-step), NSLAB slabs of 16 k-steps.
+template <int U, int NSLAB, int WT, int NB>
+__device__ __forceinline__ void gemm_segment(f32x16 (&acc)[U], const float (&b)[NB], SlabStream<WT>& st) {
+    static_assert(NB >= NSLAB * 16, "B operand array too short");
+#pragma unroll
+    for (int sl = 0; sl < NSLAB; ++sl) {
+        const float* slab = st.template acquire<U>() + st.lane * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(slab + (g * U + u) * 256);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[sl * 16 + g * 4 + q], acc[u], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[U], const float* __restrict__ bias, int half) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(bias + 32 * u + 8 * g + 4 * half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[u][4 * g + q] = v[q];
+        }
+    }
+}
+
+template <int U, bool RELU>
+__device__ __forceinline__ void to_operand(const f32x16 (&acc)[U], float (&h)[U * 16]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[16 * u + r] = RELU ? fmaxf(acc[u][r], 0.0f) : acc[u][r];
+}
+
+// sum_f w[f] * x[f] over all features of one sample (both lane halves), features in accumulator order.
+template <int N>
+__device__ __forceinline__ float head_dot(const float (&h)[N], const float* __restrict__ w, int half) {
+    float s = 0.0f;
+#pragma unroll
+    for (int g = 0; g < N / 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + 8 * g + 4 * half);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s = fmaf(v[q], h[4 * g + q], s);
+    }
+    return s + __shfl_xor(s, 32, 64);
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return __fdiv_rn(1.0f, 1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// positional encoding
+// ------------------------------------------------------------------------------------------------
+// sin and cos of 2*pi*turns.  The frequencies are exact powers of two, so `turns` = x * 2^k / (2 pi) is formed once
+// per coordinate in fp64 and the reduction to [-1/8, 1/8] turns is exact; only the final polynomial is fp32.
+__device__ __forceinline__ void sincos_turns(double turns, float& s, float& c) {
+    const double f = turns - rint(turns);   // [-1/2, 1/2]
+    const double q = rint(4.0 * f);         // quadrant, -2 .. 2
+    const double g = f - 0.25 * q;          // [-1/8, 1/8]
+    const float th = (float)(g * 6.283185307179586476925);
+    const float t2 = th * th;
+    float sp = fmaf(t2, 2.7557319e-6f, -1.9841270e-4f);
+    sp = fmaf(sp, t2, 8.3333333e-3f);
+    sp = fmaf(sp, t2, -1.6666667e-1f);
+    sp = fmaf(th * t2, sp, th);
+    float cp = fmaf(t2, -2.7557319e-7f, 2.4801587e-5f);
+    cp = fmaf(cp, t2, -1.3888889e-3f);
+    cp = fmaf(cp, t2, 4.1666667e-2f);
+    cp = fmaf(cp, t2, -0.5f);
+    cp = fmaf(cp, t2, 1.0f);
+    const int qi = ((int)q) & 3;
+    const float s0 = (qi & 1) ? cp : sp;
+    const float c0 = (qi & 1) ? sp : cp;
+    s = (qi >= 2) ? -s0 : s0;
+    c = (qi == 1 || qi == 2) ? -c0 : c0;
+}
+
+// Fill the PE operand registers of this lane half (layout: mlp_layout.h pe_feature()).
+template <int PAIRS, int NREG>
+__device__ __forceinline__ void encode(const float (&x)[3], int half, float (&pe)[NREG]) {
+    constexpr double kInvTwoPi = 0.15915494309189533576888;
+    const double r0 = (double)x[0] * kInvTwoPi, r1 = (double)x[1] * kInvTwoPi, r2 = (double)x[2] * kInvTwoPi;
+#pragma unroll
+    for (int m = 0; m < PAIRS / 2; ++m) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int c0 = 2 * m, c1 = 2 * m + 1;           // pair index for half 0 / half 1
+        const int d0 = c0 % 3, d1 = c1 % 3;
+        const double a0 = d0 == 0 ? r0 : (d0 == 1 ? r1 : r2);
+        const double a1 = d1 == 0 ? r0 : (d1 == 1 ? r1 : r2);
+        const double f0 = (double)(1 << (c0 / 3)), f1 = (double)(1 << (c1 / 3));
+        const double turns = half ? a1 * f1 : a0 * f0;
+        sincos_turns(turns, pe[2 * m], pe[2 * m + 1]);
+    }
+    pe[PAIRS] = half ? x[2] : x[0];
+    pe[PAIRS + 1] = half ? 0.0f : x[1];
+#pragma unroll
+    for (int n = PAIRS + 2; n < NREG; ++n) pe[n] = 0.0f;
+}
+

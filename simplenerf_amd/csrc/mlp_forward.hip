@@ -22,175 +22,14 @@
 //
 // Bound: MFMA (fp32, 256 FLOP/clk/CU).  Algorithmic work 2*MAC of the Linear layers: 1 186 816 FLOP per sample for
 // the 8x256 view-dependent MLP.  HBM traffic per sample: 4 B depth read + 16 B written; weights (2.4 MB) stay in L2.
-#include "mlp_plan.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "mlp_device.h"
 
 namespace {
-
-struct MlpArgs {
-    const float* packed;
-    const float* origins;
-    const float* dirs;
-    const float* view_dirs;
-    const float* depths;
-    const float* noise;
-    float* sigma;
-    float* rgb;
-    long long total;  // rays * samples
-    int samples;
-    int depth;
-    int width;
-    long long bias_offset, feature_bias, views_bias, pts_out_w, pts_out_b, views_out_w, views_out_b;
-};
-
-// ------------------------------------------------------------------------------------------------
-// weight slab stream: L2 -> LDS by LDS-DMA, double buffered
-// ------------------------------------------------------------------------------------------------
-template <int WT>
-struct SlabStream {
-    static constexpr int kBufFloats = WT * 1024;  // 16 k-steps x WT tiles x 64 lanes x 4
-    const float* cur;                             // global address of the slab about to be consumed
-    float* lds;
-    int parity;
-    int lane, wave;
-
-    __device__ __forceinline__ void fetch(const float* src, float* dst) const {
-#pragma unroll
-        for (int i = 0; i < WT; ++i) {
-            const int chunk = i * 4 + wave;  // 1 KiB per wave-instruction
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + chunk * 256 + lane * 4),
-                                             (__attribute__((address_space(3))) void*)(dst + chunk * 256), 16, 0, 0);
-        }
-    }
-    __device__ __forceinline__ void start(const float* first, float* lds_base, int lane_, int wave_) {
-        cur = first; lds = lds_base; parity = 0; lane = lane_; wave = wave_;
-        fetch(cur, lds);
-    }
-    // Make the current slab (U tiles wide) readable and start fetching the one after it.
-    template <int U>
-    __device__ __forceinline__ const float* acquire() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of the current slab has landed
-        __syncthreads();                                  // everyone's has, and everyone left the other buffer
-        const float* ready = lds + parity * kBufFloats;
-        fetch(cur + U * 1024, lds + (parity ^ 1) * kBufFloats);
-        cur += U * 1024;
-        parity ^= 1;
-        return ready;
-    }
-};
-
-// acc[u] += W_segment[u-th 32 rows] . B, B = `b` (one register per k-step), NSLAB slabs of 16 k-steps.
-template <int U, int NSLAB, int WT, int NB>
-__device__ __forceinline__ void gemm_segment(f32x16 (&acc)[U], const float (&b)[NB], SlabStream<WT>& st) {
-    static_assert(NB >= NSLAB * 16, "B operand array too short");
-#pragma unroll
-    for (int sl = 0; sl < NSLAB; ++sl) {
-        const float* slab = st.template acquire<U>() + st.lane * 4;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(slab + (g * U + u) * 256);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[sl * 16 + g * 4 + q], acc[u], 0, 0, 0);
-            }
-        }
-    }
-}
-
-template <int U>
-__device__ __forceinline__ void load_bias(f32x16 (&acc)[U], const float* __restrict__ bias, int half) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(bias + 32 * u + 8 * g + 4 * half);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[u][4 * g + q] = v[q];
-        }
-    }
-}
-
-template <int U, bool RELU>
-__device__ __forceinline__ void to_operand(const f32x16 (&acc)[U], float (&h)[U * 16]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h[16 * u + r] = RELU ? fmaxf(acc[u][r], 0.0f) : acc[u][r];
-}
-
-// sum_f w[f] * x[f] over all features of one sample (both lane halves), features in accumulator order.
-template <int N>
-__device__ __forceinline__ float head_dot(const float (&h)[N], const float* __restrict__ w, int half) {
-    float s = 0.0f;
-#pragma unroll
-    for (int g = 0; g < N / 4; ++g) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(w + 8 * g + 4 * half);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s = fmaf(v[q], h[4 * g + q], s);
-    }
-    return s + __shfl_xor(s, 32, 64);
-}
-
-__device__ __forceinline__ float sigmoidf(float x) { return __fdiv_rn(1.0f, 1.0f + expf(-x)); }
-
-// ------------------------------------------------------------------------------------------------
-// positional encoding
-// ------------------------------------------------------------------------------------------------
-// sin and cos of 2*pi*turns.  The frequencies are exact powers of two, so `turns` = x * 2^k / (2 pi) is formed once
-// per coordinate in fp64 and the reduction to [-1/8, 1/8] turns is exact; only the final polynomial is fp32.
-__device__ __forceinline__ void sincos_turns(double turns, float& s, float& c) {
-    const double f = turns - rint(turns);   // [-1/2, 1/2]
-    const double q = rint(4.0 * f);         // quadrant, -2 .. 2
-    const double g = f - 0.25 * q;          // [-1/8, 1/8]
-    const float th = (float)(g * 6.283185307179586476925);
-    const float t2 = th * th;
-    float sp = fmaf(t2, 2.7557319e-6f, -1.9841270e-4f);
-    sp = fmaf(sp, t2, 8.3333333e-3f);
-    sp = fmaf(sp, t2, -1.6666667e-1f);
-    sp = fmaf(th * t2, sp, th);
-    float cp = fmaf(t2, -2.7557319e-7f, 2.4801587e-5f);
-    cp = fmaf(cp, t2, -1.3888889e-3f);
-    cp = fmaf(cp, t2, 4.1666667e-2f);
-    cp = fmaf(cp, t2, -0.5f);
-    cp = fmaf(cp, t2, 1.0f);
-    const int qi = ((int)q) & 3;
-    const float s0 = (qi & 1) ? cp : sp;
-    const float c0 = (qi & 1) ? sp : cp;
-    s = (qi >= 2) ? -s0 : s0;
-    c = (qi == 1 || qi == 2) ? -c0 : c0;
-}
-
-// Fill the PE operand registers of this lane half (layout: mlp_layout.h pe_feature()).
-template <int PAIRS, int NREG>
-__device__ __forceinline__ void encode(const float (&x)[3], int half, float (&pe)[NREG]) {
-    constexpr double kInvTwoPi = 0.15915494309189533576888;
-    const double r0 = (double)x[0] * kInvTwoPi, r1 = (double)x[1] * kInvTwoPi, r2 = (double)x[2] * kInvTwoPi;
-#pragma unroll
-    for (int m = 0; m < PAIRS / 2; ++m) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int c0 = 2 * m, c1 = 2 * m + 1;           // pair index for half 0 / half 1
-        const int d0 = c0 % 3, d1 = c1 % 3;
-        const double a0 = d0 == 0 ? r0 : (d0 == 1 ? r1 : r2);
-        const double a1 = d1 == 0 ? r0 : (d1 == 1 ? r1 : r2);
-        const double f0 = (double)(1 << (c0 / 3)), f1 = (double)(1 << (c1 / 3));
-        const double turns = half ? a1 * f1 : a0 * f0;
-        sincos_turns(turns, pe[2 * m], pe[2 * m + 1]);
-    }
-    pe[PAIRS] = half ? x[2] : x[0];
-    pe[PAIRS + 1] = half ? 0.0f : x[1];
-#pragma unroll
-    for (int n = PAIRS + 2; n < NREG; ++n) pe[n] = 0.0f;
-}
 
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE>
+template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE>
 __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -220,6 +59,14 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
         encode<snerf::kViewsPairs, snerf::kViewsKSteps>(v, half, pev);
     }
 
+    // training: every layer's input is kept for the backward pass as a [feature][32-sample] tile of this wave block
+    float* tile = nullptr;
+    if (STORE) {
+        tile = a.acts + ((long long)blockIdx.x * 4 + wave) * a.act_rows * 32;
+        store_pe_tile<snerf::kPointsPairs, snerf::kPointsKSteps>(pe, tile, lane);
+        if (VIEWDEP) store_pe_tile<snerf::kViewsPairs, snerf::kViewsKSteps>(pev, tile + a.act_pev * 32, lane);
+    }
+
     // ---- trunk ------------------------------------------------------------------------------------
     const float* bias = a.packed + a.bias_offset;
     f32x16 acc[WT];
@@ -227,12 +74,14 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
     load_bias<WT>(acc, bias, half);
     gemm_segment<WT, 2, WT>(acc, pe, st);
     to_operand<WT, true>(acc, h);
+    if (STORE) store_acc_tile(h, tile + a.act_h1 * 32, lane);
 #pragma unroll 1
     for (int l = 1; l < a.depth; ++l) {
         load_bias<WT>(acc, bias + (long long)l * a.width, half);
         if (l == 5) gemm_segment<WT, 2, WT>(acc, pe, st);  // skip connection: [encoding | h] (:662-663)
         gemm_segment<WT, WT, WT>(acc, h, st);
         to_operand<WT, true>(acc, h);
+        if (STORE) store_acc_tile(h, tile + (a.act_h1 + l * a.width) * 32, lane);
     }
 
     // ---- density (and view-independent colour) head -------------------------------------------------
@@ -250,6 +99,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
         load_bias<WT>(acc, a.packed + a.feature_bias, half);
         gemm_segment<WT, WT, WT>(acc, h, st);
         to_operand<WT, false>(acc, h);
+        if (STORE) store_acc_tile(h, tile + a.act_feature * 32, lane);
         // views layer over [feature | rest of the point encoding (points-aug only) | view encoding] (:633, :695-699)
         f32x16 accv[VT];
         load_bias<VT>(accv, a.packed + a.views_bias, half);
@@ -258,6 +108,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
         gemm_segment<VT, 1, WT>(accv, pev, st);
         float hv[VT * 16];
         to_operand<VT, true>(accv, hv);
+        if (STORE) store_acc_tile(hv, tile + a.act_hv * 32, lane);
         const float* wv = a.packed + a.views_out_w;
         const float* bv = a.packed + a.views_out_b;
 #pragma unroll
@@ -273,12 +124,12 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
     }
 }
 
-template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE>
+template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE>
 int launch(const MlpArgs& a, hipStream_t stream) {
     const long long blocks = (a.total + 127) / 128;
     if (blocks > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: too many samples in one call");
     const size_t lds_bytes = 2 * sizeof(float) * SlabStream<WT>::kBufFloats;
-    auto kernel = mlp_forward_kernel<WT, VT, VIEWDEP, SIGMA_PE>;
+    auto kernel = mlp_forward_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE>;
     static bool configured = false;  // raising the dynamic-LDS cap is idempotent; racing threads only repeat it
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -292,16 +143,17 @@ int launch(const MlpArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int snerf_mlp_forward(const snerf_mlp_desc* desc, const float* packed, const float* origins,
-                                 const float* dirs, const float* view_dirs, const float* depths, long long num_rays,
-                                 int num_samples, const float* sigma_noise, float* sigma, float* rgb, int precision,
-                                 snerf_stream_t stream) {
+static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const float* origins, const float* dirs,
+                        const float* view_dirs, const float* depths, long long num_rays, int num_samples,
+                        const float* sigma_noise, float* sigma, float* rgb, float* saved_acts, bool train, int precision,
+                        snerf_stream_t stream) {
     snerf::MlpPlan plan;
     const int st = snerf::build_plan(desc, &plan);
     if (st != SNERF_OK) return st;
     SNERF_REQUIRE(packed && origins && dirs && depths && sigma && rgb, "mlp_forward: NULL pointer");
     SNERF_REQUIRE(!plan.view_dependent || view_dirs, "mlp_forward: this MLP needs view_dirs");
     SNERF_REQUIRE(num_rays >= 0 && num_samples >= 1, "mlp_forward: bad sizes n=%lld S=%d", num_rays, num_samples);
+    SNERF_REQUIRE(!train || saved_acts, "mlp_forward_train: saved_acts is NULL");
     if (precision != SNERF_PRECISION_FP32)
         return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: precision %d not built", precision);
     if (num_rays == 0) return SNERF_OK;
@@ -312,17 +164,44 @@ extern "C" int snerf_mlp_forward(const snerf_mlp_desc* desc, const float* packed
     a.bias_offset = plan.bias_offset; a.feature_bias = plan.feature_bias(); a.views_bias = plan.views_bias();
     a.pts_out_w = plan.pts_out_w(); a.pts_out_b = plan.pts_out_b();
     a.views_out_w = plan.views_out_w(); a.views_out_b = plan.views_out_b();
+    a.acts = saved_acts; a.act_rows = plan.act_rows(); a.act_pev = plan.act_pev(); a.act_h1 = plan.act_h(1);
+    a.act_feature = plan.act_feature(); a.act_hv = plan.act_hv();
     hipStream_t s = (hipStream_t)stream;
     const int key = plan.wt * 100 + plan.vt * 10 + (plan.sigma_pe ? 1 : 0);
+#define SNERF_DISPATCH(WT_, VT_, VD_, SP_) return train ? launch<WT_, VT_, VD_, SP_, true>(a, s) : launch<WT_, VT_, VD_, SP_, false>(a, s)
     switch (key) {
-        case 840: return launch<8, 4, true, false>(a, s);
-        case 841: return launch<8, 4, true, true>(a, s);
-        case 800: return launch<8, 4, false, false>(a, s);
-        case 420: return launch<4, 2, true, false>(a, s);
-        case 421: return launch<4, 2, true, true>(a, s);
-        case 400: return launch<4, 2, false, false>(a, s);
+        case 840: SNERF_DISPATCH(8, 4, true, false);
+        case 841: SNERF_DISPATCH(8, 4, true, true);
+        case 800: SNERF_DISPATCH(8, 4, false, false);
+        case 420: SNERF_DISPATCH(4, 2, true, false);
+        case 421: SNERF_DISPATCH(4, 2, true, true);
+        case 400: SNERF_DISPATCH(4, 2, false, false);
         default:
             return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: width %d / views width %d combination not built "
                                "(256/128, 128/64, or 256|128 without a views layer)", plan.width, plan.views_width);
     }
+#undef SNERF_DISPATCH
+}
+
+extern "C" int snerf_mlp_forward(const snerf_mlp_desc* desc, const float* packed, const float* origins,
+                                 const float* dirs, const float* view_dirs, const float* depths, long long num_rays,
+                                 int num_samples, const float* sigma_noise, float* sigma, float* rgb, int precision,
+                                 snerf_stream_t stream) {
+    return forward_impl(desc, packed, origins, dirs, view_dirs, depths, num_rays, num_samples, sigma_noise, sigma, rgb,
+                        nullptr, false, precision, stream);
+}
+
+extern "C" int snerf_mlp_forward_train(const snerf_mlp_desc* desc, const float* packed, const float* origins,
+                                       const float* dirs, const float* view_dirs, const float* depths,
+                                       long long num_rays, int num_samples, const float* sigma_noise, float* sigma,
+                                       float* rgb, float* saved_acts, int precision, snerf_stream_t stream) {
+    return forward_impl(desc, packed, origins, dirs, view_dirs, depths, num_rays, num_samples, sigma_noise, sigma, rgb,
+                        saved_acts, true, precision, stream);
+}
+
+extern "C" size_t snerf_mlp_saved_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples) {
+    snerf::MlpPlan plan;
+    if (snerf::build_plan(desc, &plan) != SNERF_OK || num_rays < 0 || num_samples < 1) return 0;
+    const long long blocks = (num_rays * num_samples + 127) / 128 * 4;  // whole workgroups of 4 wave blocks
+    return (size_t)(blocks * plan.act_rows() * 32);
 }

@@ -67,7 +67,17 @@ struct Segment {
     int feat_hi;
     int degree;      // PE degree for SEG_*_PE
     long long dst;   // offset (floats) into the packed stream
+    int transposed;  // 0: forward operand (rows = out features).  1: dgrad operand W^T -- rows of the tile are IN
+                     //    features (col_offset + 32u + i) and the k-steps run over OUT features in accumulator order
 };
+
+// Element of W for (transposed segment, tile u, row i, k-step, lane half): W[acc_feature(ks,h)][col_offset+32u+i].
+__host__ __device__ inline long long transposed_index(const Segment& s, int u, int i, int ks, int h) {
+    const int out = acc_feature(ks, h);
+    const int in = 32 * u + i;
+    if (out >= s.out_dim || in >= s.feat_hi) return -1;  // feat_hi = number of input features wired (e.g. 256)
+    return (long long)out * s.ld + s.col_offset + in;
+}
 
 // Column of W for (segment, k-step, lane half), or -1 for a zero weight.
 __host__ __device__ inline int segment_column(const Segment& s, int ks, int h) {

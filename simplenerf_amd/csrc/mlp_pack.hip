@@ -16,10 +16,15 @@ __global__ void __launch_bounds__(256) pack_segment_kernel(const float* __restri
         const long long gu = idx >> 8;
         const int u = (int)(gu % s.tiles);
         const int g = (int)(gu / s.tiles);
-        const int row = 32 * u + (lane & 31);
-        const int col = snerf::segment_column(s, 4 * g + q, lane >> 5);
         float v = 0.0f;
-        if (row < s.out_dim && col >= 0 && col < s.ld) v = w[(long long)row * s.ld + col];
+        if (s.transposed) {
+            const long long src = snerf::transposed_index(s, u, lane & 31, 4 * g + q, lane >> 5);
+            if (src >= 0) v = w[src];
+        } else {
+            const int row = 32 * u + (lane & 31);
+            const int col = snerf::segment_column(s, 4 * g + q, lane >> 5);
+            if (row < s.out_dim && col >= 0 && col < s.ld) v = w[(long long)row * s.ld + col];
+        }
         packed[s.dst + idx] = v;
     }
 }
@@ -50,10 +55,12 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(packed, 0, sizeof(float) * (size_t)plan.total_floats, s);
     if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_pack: memset: %s", hipGetErrorString(e));
-    for (const snerf::Segment& seg : plan.segments) {
-        const long long total = (long long)seg.ksteps * seg.tiles * 64;
-        hipLaunchKernelGGL(pack_segment_kernel, dim3(snerf::stride_grid(total, 256)), dim3(256), 0, s,
-                           params[seg.param], seg, packed);
+    for (const std::vector<snerf::Segment>* list : {&plan.segments, &plan.dgrad_segments}) {
+        for (const snerf::Segment& seg : *list) {
+            const long long total = (long long)seg.ksteps * seg.tiles * 64;
+            hipLaunchKernelGGL(pack_segment_kernel, dim3(snerf::stride_grid(total, 256)), dim3(256), 0, s,
+                               params[seg.param], seg, packed);
+        }
     }
     auto copy = [&](long long dst, const float* src, long long n) {
         if (e == hipSuccess) e = hipMemcpyAsync(packed + dst, src, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, s);

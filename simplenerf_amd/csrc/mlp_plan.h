@@ -22,7 +22,25 @@ struct MlpPlan {
     long long weight_floats = 0;  // all slabs + one maximum-size slab of zero padding (the prefetcher runs one ahead)
     long long bias_offset = 0;    // trunk biases [depth][width], feature bias [width], views bias [views_width]
     long long head_offset = 0;    // pts_output W [rows][width], b [4]; views_output W [3][views_width], b [4]
+    long long dgrad_offset = 0;   // W^T stream consumed by the backward chain (views, feature, trunk depth-1 .. 1) + runway
+    std::vector<Segment> dgrad_segments;
     long long total_floats = 0;
+
+    // ---- saved-activation / gradient tiles of one 32-sample wave block (backward only) -----------------------
+    // Every tensor is stored [feature][32 samples] (feature-major inside the block), features in natural order.
+    // acts:  pe[64] | pev[32] | h_1 .. h_depth [width each] | feature[width] | hv[views_width]
+    // grads: dY_0 .. dY_{depth-1} [width each] | dfeature[width] | dYv[views_width] | dhead[32]
+    int act_pe() const { return 0; }
+    int act_pev() const { return 64; }
+    int act_h(int l) const { return 96 + (l - 1) * width; }  // l = 1 .. depth
+    int act_feature() const { return 96 + depth * width; }
+    int act_hv() const { return 96 + (depth + 1) * width; }
+    int act_rows() const { return 96 + (depth + 1) * width + (view_dependent ? views_width : 0); }
+    int grad_y(int l) const { return l * width; }             // l = 0 .. depth-1
+    int grad_feature() const { return depth * width; }
+    int grad_yv() const { return (depth + 1) * width; }
+    int grad_head() const { return (depth + 1) * width + (view_dependent ? views_width : 0); }
+    int grad_rows() const { return grad_head() + 32; }
 
     long long trunk_bias(int layer) const { return bias_offset + (long long)layer * width; }
     long long feature_bias() const { return bias_offset + (long long)depth * width; }
@@ -81,7 +99,7 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
     long long off = 0;
     auto add = [&](int param, int ld, int out_dim, int tiles, int ksteps, int kind, int col_offset, int lo, int hi,
                    int degree) {
-        Segment s{param, ld, out_dim, tiles, ksteps, kind, col_offset, lo, hi, degree, off};
+        Segment s{param, ld, out_dim, tiles, ksteps, kind, col_offset, lo, hi, degree, off, 0};
         plan.segments.push_back(s);
         off += (long long)ksteps * tiles * 64;
     };
@@ -111,6 +129,29 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
     off += (long long)(plan.depth + 1) * plan.width + 128;
     plan.head_offset = off;
     off += (long long)plan.pts_out_rows * plan.width + 4 + 3LL * 128 + 4;
+    off = (off + 1023) / 1024 * 1024;
+    plan.dgrad_offset = off;
+    {
+        long long doff = off;
+        auto addt = [&](int param, int ld, int out_dim, int in_tiles, int ksteps, int col_offset, int in_features) {
+            Segment s{param, ld, out_dim, in_tiles, ksteps, SEG_ACC, col_offset, 0, in_features, 0, doff, 1};
+            plan.dgrad_segments.push_back(s);
+            doff += (long long)ksteps * in_tiles * 64;
+        };
+        if (plan.view_dependent) {
+            const int pf = 2 * plan.depth + 2, pv = pf + 2;
+            const int ldv = plan.width + plan.extra + plan.views_pe;
+            addt(pv, ldv, plan.views_width, plan.wt, plan.views_width / 2, 0, plan.width);  // d feature  = Wv[:, :W]^T dYv
+            addt(pf, plan.width, plan.width, plan.wt, acc_ks, 0, plan.width);               // d h_depth  = Wf^T dfeature
+        }
+        for (int l = plan.depth - 1; l >= 1; --l) {                                         // d h_l = W_l[:, hcols]^T dY_l
+            const bool skip_in = (l == 5);
+            addt(2 * l, plan.width + (skip_in ? plan.pts_in : 0), plan.width, plan.wt, acc_ks, skip_in ? plan.pts_in : 0,
+                 plan.width);
+        }
+        doff += (long long)kSlabKSteps * plan.wt * 64;
+        off = doff;
+    }
     plan.total_floats = (off + 63) / 64 * 64;
     *p = plan;
     return SNERF_OK;

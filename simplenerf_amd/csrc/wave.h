@@ -33,6 +33,18 @@ __device__ __forceinline__ float wave_inclusive_mul(float v) {
     return v;
 }
 
+// Inclusive suffix sum: lane l receives v[l] + v[l+1] + ... + v[63] (only later lanes are ever added, so a tiny tail
+// is not contaminated by rounding of a large head -- needed by the compositing backward).
+__device__ __forceinline__ float wave_suffix_add(float v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float n = __shfl_down(v, off, 64);
+        if (lane + off < 64) v += n;
+    }
+    return v;
+}
+
 // Order this wave's LDS writes before its later LDS reads from other lanes.  LDS operations of one wave execute
 // in issue order, so only the compiler needs fencing (no s_barrier: a wave owns its LDS region).
 __device__ __forceinline__ void wave_lds_sync() {

@@ -14,7 +14,11 @@ Differences from the reference that a caller can observe:
     (``torch.rand``/``randn`` on the GPU generator) instead of on the CPU generator; ``set_random_draws`` injects
     explicit draws (used by the parity tests to replay the reference's CPU stream);
   * ``predict_visibility`` (off in every shipped config) is not built;
-  * backward kernels are not built yet: a training-mode forward under ``torch.enable_grad()`` raises.
+  * gradients flow from ``rgb_*``, ``acc_*``, ``depth_*``, ``depth_ndc_*`` (incl. the augmentation-prefixed ones) and
+    ``raw_sigma_*`` / ``raw_rgb*_*`` to the parameters -- a superset of what the shipped losses read (SURVEY 8a row
+    9); ``alpha_*``, ``visibility_*``, ``weights_*``, ``depth_var*`` and ``z_vals_*`` are returned without a
+    gradient path (the reference detaches the sample depths, :312; no loss reads the others), so a loss built only
+    on them raises instead of silently training nothing.
 """
 from __future__ import annotations
 
@@ -73,6 +77,42 @@ class MlpParameters(torch.nn.Module):
         raise RuntimeError('MlpParameters only holds weights; evaluation happens in the fused HIP kernel')
 
 
+class _ShadeFunction(torch.autograd.Function):
+    """One MLP evaluated on (N,S) samples + compositing, with hand-written backward kernels (K6, K7).
+
+    forward  = snerf_mlp_forward_train + snerf_composite
+    backward = snerf_composite_backward -> (d sigma, d rgb) -> snerf_mlp_backward -> parameter gradients
+    """
+    COMPOSITE_KEYS = ('rgb', 'acc', 'alpha', 'visibility', 'weights', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc')
+
+    @staticmethod
+    def forward(ctx, packed, ndc, white, march_o, march_d, view_dirs, depths, noise, rays_o, rays_d, *params):
+        sigma, rgb, saved = packed.forward_train(march_o, march_d, view_dirs, depths, noise)
+        comp = ops.composite(sigma, rgb, depths, march_d, ndc, white, rays_o, rays_d)
+        ctx.packed, ctx.ndc, ctx.white = packed, ndc, white
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.save_for_backward(sigma, rgb, saved, depths, march_d, rays_o, rays_d)
+        outs = [comp.get(k) for k in _ShadeFunction.COMPOSITE_KEYS if k in comp]
+        ctx.keys = [k for k in _ShadeFunction.COMPOSITE_KEYS if k in comp] + ['sigma', 'rgb_raw']
+        no_grad = [comp[k] for k in ('alpha', 'visibility', 'weights', 'depth_var', 'depth_var_ndc') if k in comp]
+        ctx.mark_non_differentiable(*no_grad)
+        ctx.set_materialize_grads(False)
+        return tuple(outs) + (sigma, rgb)
+
+    @staticmethod
+    def backward(ctx, *grad_outputs):
+        sigma, rgb, saved, depths, march_d, rays_o, rays_d = ctx.saved_tensors
+        g = dict(zip(ctx.keys, grad_outputs))
+        d_sigma, d_rgb = ops.composite_backward(sigma, rgb, depths, march_d, ctx.ndc, ctx.white, rays_o, rays_d,
+                                                g.get('rgb'), g.get('acc'), g.get('depth'), g.get('depth_ndc'))
+        if g.get('sigma') is not None:
+            d_sigma = d_sigma + g['sigma'].reshape(d_sigma.shape)
+        if g.get('rgb_raw') is not None:
+            d_rgb = d_rgb + g['rgb_raw']
+        grads = ctx.packed.backward(saved, sigma, rgb, d_sigma, d_rgb, ctx.param_shapes)
+        return (None,) * 10 + tuple(grads)
+
+
 class SimpleNeRFHip(torch.nn.Module):
     def __init__(self, configs: dict, model_configs: dict = None):
         super().__init__()
@@ -103,7 +143,9 @@ class SimpleNeRFHip(torch.nn.Module):
         """Use these tensors for the next training-mode forward instead of device RNG.  Keys (all optional):
         ``t_rand`` (N,S_c); ``u`` (N,S_f); ``noise_coarse``, ``noise_points_augmentation``,
         ``noise_views_augmentation`` (N,S_c,1); ``noise_fine`` (N,S_c+S_f,1) -- noise already scaled by
-        raw_noise_std.  A missing key means that draw is skipped (no jitter / no noise)."""
+        raw_noise_std.  A missing key means that draw is skipped (no jitter / no noise).
+        Parity-test hook: ``z_vals_fine`` (N,S_c+S_f) replaces the resampled fine depths altogether (the reference's
+        sample_pdf has a rounding-dependent discontinuity; works in eval mode too)."""
         self._draws = draws
 
     def _packed_mlp(self, name: str) -> ops.PackedMlp:
@@ -123,10 +165,7 @@ class SimpleNeRFHip(torch.nn.Module):
         batch = dict(input_batch)  # the caller's dict is never mutated (reference: deep_dict_copy :68)
         training = self.training
         retraw = retraw or training
-        if training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                'SimpleNeRFHip: the backward kernels (composite + MLP gradients) are not built yet; run training-mode '
-                'forwards under torch.no_grad()')
+        with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         mcfg = self.configs['model']
         rays_o, rays_d = batch['rays_o'], batch['rays_d']
         if self.ndc:
@@ -159,8 +198,16 @@ class SimpleNeRFHip(torch.nn.Module):
         def shade(name, prefix, level, depths, noise_key):
             s = depths.shape[1]
             packed = self._packed_mlp(name)
-            sigma, rgb = packed.forward(march_o, march_d, view_dirs, depths, draw(noise_key, (n, s, 1), True))
-            comp = ops.composite(sigma, rgb, depths, march_d, self.ndc, mcfg['white_bkgd'], rays_o, rays_d)
+            noise = draw(noise_key, (n, s, 1), True)
+            if with_grad:
+                res = _ShadeFunction.apply(packed, self.ndc, bool(mcfg['white_bkgd']), march_o, march_d, view_dirs, depths,
+                                           noise, rays_o, rays_d, *getattr(self, name).abi_params())
+                keys = [k for k in _ShadeFunction.COMPOSITE_KEYS if self.ndc or not k.endswith('_ndc')]
+                comp = dict(zip(keys, res[:len(keys)]))
+                sigma, rgb = res[len(keys)], res[len(keys) + 1]
+            else:
+                sigma, rgb = packed.forward(march_o, march_d, view_dirs, depths, noise)
+                comp = ops.composite(sigma, rgb, depths, march_d, self.ndc, mcfg['white_bkgd'], rays_o, rays_d)
             # key order as volume_rendering's return_dict (:465-477)
             for k in ('rgb', 'acc', 'alpha', 'visibility', 'weights', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc'):
                 if k in comp:
@@ -182,7 +229,10 @@ class SimpleNeRFHip(torch.nn.Module):
                     shade(name, prefix, 'coarse', z_coarse, f'noise_{prefix[:-1]}')
         if self.fine_mlp_needed:
             s_f = mcfg['fine_mlp']['num_samples']
-            z_fine = ops.resample_depths(z_coarse, comp_c['weights'], s_f, draw('u', (n, s_f), False))
+            if draws is not None and draws.get('z_vals_fine') is not None:
+                z_fine = draws['z_vals_fine'].to(dev)
+            else:
+                z_fine = ops.resample_depths(z_coarse, comp_c['weights'].detach(), s_f, draw('u', (n, s_f), False))
             shade('fine_model', '', 'fine', z_fine, 'noise_fine')
             out['z_vals_fine'] = z_fine
             if training:

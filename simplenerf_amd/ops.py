@@ -149,6 +149,61 @@ class PackedMlp:
         return sigma, rgb
 
 
+    # ---- training ------------------------------------------------------------------------------------------
+    def forward_train(self, origins: Tensor, dirs: Tensor, view_dirs: Optional[Tensor], depths: Tensor,
+                      sigma_noise: Optional[Tensor] = None):
+        """Forward that also keeps every layer's input for backward().  -> sigma (n,S,1), rgb (n,S,3), saved"""
+        lib = _lib.load()
+        n, s = depths.shape
+        origins = _dev(origins, 'origins', (n, 3))
+        dirs = _dev(dirs, 'dirs', (n, 3))
+        depths = _dev(depths, 'depths')
+        view_dirs = _dev(view_dirs, 'view_dirs', (n, 3)) if self.use_view_dirs else None
+        if self.use_view_dirs and view_dirs is None:
+            raise KeyError('view_dirs')
+        if sigma_noise is not None:
+            sigma_noise = _dev(sigma_noise.reshape(n, s), 'sigma_noise', (n, s))
+        dev = depths.device
+        sigma = torch.empty((n, s, 1), dtype=torch.float32, device=dev)
+        rgb = torch.empty((n, s, 3), dtype=torch.float32, device=dev)
+        saved = torch.empty(lib.snerf_mlp_saved_floats(ctypes.byref(self.desc), n, s), dtype=torch.float32, device=dev)
+        log = PackedMlp.event_log
+        with torch.cuda.device(dev):
+            if log is not None:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
+            st = lib.snerf_mlp_forward_train(ctypes.byref(self.desc), _ptr(self.buffer), _ptr(origins), _ptr(dirs),
+                                             _ptr(view_dirs), _ptr(depths), n, s, _ptr(sigma_noise), _ptr(sigma), _ptr(rgb),
+                                             _ptr(saved), 0, _stream())
+            if log is not None:
+                t1.record()
+                log.append((t0, t1, n * s))
+        _lib.check(st, 'snerf_mlp_forward_train')
+        return sigma, rgb, saved
+
+    def backward(self, saved: Tensor, sigma: Tensor, rgb: Tensor, d_sigma: Tensor, d_rgb: Tensor,
+                 param_shapes: List[tuple]) -> List[Tensor]:
+        """dL/dparam for every parameter (C-ABI order), given dL/dsigma (n,S[,1]) and dL/drgb (n,S,3)."""
+        lib = _lib.load()
+        n, s = sigma.shape[0], sigma.shape[1]
+        dev = sigma.device
+        sigma = _dev(sigma.reshape(n, s), 'sigma', (n, s))
+        rgb = _dev(rgb, 'rgb', (n, s, 3))
+        d_sigma = _dev(d_sigma.reshape(n, s), 'd_sigma', (n, s))
+        d_rgb = _dev(d_rgb, 'd_rgb', (n, s, 3))
+        if len(param_shapes) != self.num_params:
+            raise RuntimeError(f'expected {self.num_params} parameter shapes, got {len(param_shapes)}')
+        grads = [torch.empty(tuple(shape), dtype=torch.float32, device=dev) for shape in param_shapes]
+        work = torch.empty(lib.snerf_mlp_backward_workspace_floats(ctypes.byref(self.desc), n, s), dtype=torch.float32,
+                           device=dev)
+        arr = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        with torch.cuda.device(dev):
+            st = lib.snerf_mlp_backward(ctypes.byref(self.desc), _ptr(self.buffer), _ptr(saved), _ptr(sigma), _ptr(rgb),
+                                        _ptr(d_sigma), _ptr(d_rgb), n, s, _ptr(work), arr, len(grads), _stream())
+        _lib.check(st, 'snerf_mlp_backward')
+        return grads
+
+
 # ---------------------------------------------------------------------------------------------- K4
 def composite(sigma: Tensor, rgb: Tensor, depths: Tensor, march_dirs: Tensor, ndc: bool, white_bkgd: bool = False,
               rays_o: Optional[Tensor] = None, rays_d: Optional[Tensor] = None,
@@ -179,6 +234,36 @@ def composite(sigma: Tensor, rgb: Tensor, depths: Tensor, march_dirs: Tensor, nd
                                  _ptr(out.get('depth_ndc')), _ptr(out.get('depth_var_ndc')), _stream())
     _lib.check(st, 'snerf_composite')
     return out
+
+
+# ---------------------------------------------------------------------------------------------- K6
+def composite_backward(sigma: Tensor, rgb: Tensor, depths: Tensor, march_dirs: Tensor, ndc: bool, white_bkgd: bool,
+                       rays_o: Optional[Tensor], rays_d: Optional[Tensor], grad_rgb: Optional[Tensor],
+                       grad_acc: Optional[Tensor], grad_depth: Optional[Tensor], grad_depth_ndc: Optional[Tensor]):
+    """-> d_sigma (n,S), d_rgb (n,S,3) from the per-ray gradients (None = zero)."""
+    lib = _lib.load()
+    n, s = depths.shape
+    sigma = _dev(sigma.reshape(n, s), 'sigma', (n, s))
+    rgb = _dev(rgb, 'rgb', (n, s, 3))
+    depths = _dev(depths, 'depths')
+    march_dirs = _dev(march_dirs, 'march_dirs', (n, 3))
+    if ndc:
+        rays_o = _dev(rays_o, 'rays_o', (n, 3))
+        rays_d = _dev(rays_d, 'rays_d', (n, 3))
+    grad_rgb = _dev(grad_rgb, 'grad_rgb', (n, 3))
+    grad_acc = _dev(grad_acc, 'grad_acc', (n,))
+    grad_depth = _dev(grad_depth, 'grad_depth', (n,))
+    grad_depth_ndc = _dev(grad_depth_ndc, 'grad_depth_ndc', (n,))
+    dev = depths.device
+    d_sigma = torch.empty((n, s), dtype=torch.float32, device=dev)
+    d_rgb = torch.empty((n, s, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = lib.snerf_composite_backward(_ptr(sigma), _ptr(rgb), _ptr(depths), _ptr(march_dirs),
+                                          _ptr(rays_o if ndc else None), _ptr(rays_d if ndc else None), n, s,
+                                          int(bool(ndc)), int(bool(white_bkgd)), _ptr(grad_rgb), _ptr(grad_acc),
+                                          _ptr(grad_depth), _ptr(grad_depth_ndc), _ptr(d_sigma), _ptr(d_rgb), _stream())
+    _lib.check(st, 'snerf_composite_backward')
+    return d_sigma, d_rgb
 
 
 # ---------------------------------------------------------------------------------------------- K5

@@ -1,0 +1,153 @@
+"""Backward-pass parity on a real MI355X: K6 (compositing backward) and K7 (MLP parameter gradients) against autograd
+through the oracle, and the whole training-mode model against the reference's own gradients (golden G7).
+
+Bound: every gradient tensor within 1e-3 of its own largest magnitude (L-infinity relative to max|ref|); these are
+fp32 sums over 1e4..1e5 samples evaluated in a different order than the CPU BLAS, so ~1e-5 is what is observed."""
+import numpy
+import pytest
+import torch
+
+from oracle import nerf_oracle as oracle
+from simplenerf_amd import ops, synth
+from simplenerf_amd.models.ModelFactory import get_model
+from tests import util
+from tests.test_gpu_kernels import LAYOUTS, abi_param_list
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+GRAD_TOL = 1e-3
+
+
+def rel_to_max(got, ref):
+    ref = ref.detach().cpu().double()
+    got = got.detach().cpu().double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float((got - ref).abs().max() / max(float(ref.abs().max()), 1e-30))
+
+
+# ---------------------------------------------------------------- K6
+@pytest.mark.parametrize('ndc,white,s', [(False, False, 64), (True, False, 64), (True, False, 192), (False, True, 130),
+                                         (True, True, 256), (False, False, 7)])
+def test_composite_backward_matches_autograd(ndc, white, s):
+    rng = numpy.random.RandomState(s + 17 * ndc)
+    n = 23
+    if ndc:
+        g = util.load('composite.npz')
+        rays_o, rays_d = torch.from_numpy(g['ndc_s64_rays_o'][:n]), torch.from_numpy(g['ndc_s64_rays_d'][:n])
+        march = torch.from_numpy(g['ndc_s64_rays_d_ndc'][:n])
+        z = torch.from_numpy(numpy.sort(rng.uniform(0, 1, (n, s)).astype(numpy.float32), axis=1))
+        z[: n // 2] = torch.linspace(0, 1, s)
+    else:
+        rays_o = rays_d = None
+        march = torch.from_numpy(rng.standard_normal((n, 3)).astype(numpy.float32))
+        z = torch.from_numpy(numpy.sort(rng.uniform(2, 6, (n, s)).astype(numpy.float32), axis=1))
+    sigma = torch.from_numpy(rng.gamma(0.5, 8.0, (n, s)).astype(numpy.float32))
+    sigma[rng.uniform(size=sigma.shape) < 0.3] = 0
+    sigma[:2] = 0
+    sigma[2:4, 5 % s] = 1e4  # an opaque sample: 1 - alpha + 1e-10 = 1e-10
+    rgb = torch.from_numpy(rng.uniform(0, 1, (n, s, 3)).astype(numpy.float32))
+    grads = {k: torch.from_numpy(rng.standard_normal(shape).astype(numpy.float32))
+             for k, shape in (('rgb', (n, 3)), ('acc', (n,)), ('depth', (n,)), ('depth_ndc', (n,)))}
+    sg, cg = sigma.clone().requires_grad_(True), rgb.clone().requires_grad_(True)
+    out = oracle.composite(sg, cg, z, march, ndc, white, rays_o, rays_d)
+    loss = sum((out[k] * grads[k]).sum() for k in grads if k in out)
+    loss.backward()
+    d = lambda t: None if t is None else t.to(DEV)
+    d_sigma, d_rgb = ops.composite_backward(d(sigma), d(rgb), d(z), d(march), ndc, white, d(rays_o), d(rays_d),
+                                            d(grads['rgb']), d(grads['acc']), d(grads['depth']),
+                                            d(grads['depth_ndc']) if ndc else None)
+    assert rel_to_max(d_rgb, cg.grad) < 1e-5
+    assert rel_to_max(d_sigma, sg.grad) < 1e-4
+
+
+# ---------------------------------------------------------------- K7
+@pytest.mark.parametrize('layout', ['main', 'ptsaug', 'viewsaug'])
+@pytest.mark.parametrize('size', [(8, 256, 128), (4, 128, 64)])
+def test_mlp_backward_matches_autograd(layout, size):
+    depth, width, vwidth = size
+    cfg = synth.mlp_config(64, depth=depth, width=width, views_width=vwidth, **LAYOUTS[layout])
+    sd = synth.synth_state_dict(util.mlp_param_shapes(cfg), 31, 50.0, 1.0)
+    rng = numpy.random.RandomState(depth)
+    n, s = 7, 45  # 315 samples: not a multiple of the 128-sample workgroup tile
+    o = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(numpy.float32))
+    dd = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(numpy.float32))
+    v = dd / dd.norm(dim=1, keepdim=True)
+    z = torch.from_numpy(numpy.sort(rng.uniform(0, 1, (n, s)).astype(numpy.float32), axis=1))
+    noise = torch.from_numpy(rng.standard_normal((n, s, 1)).astype(numpy.float32))
+    g_sigma = torch.from_numpy(rng.standard_normal((n, s, 1)).astype(numpy.float32))
+    g_rgb = torch.from_numpy(rng.standard_normal((n, s, 3)).astype(numpy.float32))
+    params = {k: torch.from_numpy(v_).clone().requires_grad_(True) for k, v_ in sd.items()}
+    ref = oracle.run_mlp(params, '', cfg, oracle.ray_points(o, dd, z), v, None, noise)
+    ((ref['sigma'] * g_sigma).sum() + (ref['rgb'] * g_rgb).sum()).backward()
+
+    dev_params = {k: torch.from_numpy(v_).to(DEV) for k, v_ in sd.items()}
+    plist = abi_param_list(dev_params)
+    mlp = ops.PackedMlp(cfg, DEV)
+    mlp.pack(plist)
+    sigma, rgb, saved = mlp.forward_train(o.to(DEV), dd.to(DEV), v.to(DEV), z.to(DEV), noise.to(DEV))
+    assert util.rel_linf(sigma, ref['sigma']) < 1e-5 and util.linf(rgb, ref['rgb']) < 1e-5
+    grads = mlp.backward(saved, sigma, rgb, g_sigma.to(DEV), g_rgb.to(DEV), [tuple(p.shape) for p in plist])
+    names = [k for k in abi_param_list({k: k for k in sd})]
+    worst = {}
+    for name, got in zip(names, grads):
+        worst[name] = rel_to_max(got, params[name].grad)
+    bad = {k: e for k, e in worst.items() if not e < GRAD_TOL}
+    assert not bad, bad
+
+
+# ---------------------------------------------------------------- whole model
+@pytest.mark.parametrize('kind,profile', [('config3', 'consistent'), ('config2', 'consistent'), ('headline_world', 'dense'),
+                                          ('config1', 'dense')])
+@pytest.mark.parametrize('fine_depths', ['own', 'oracle'])
+def test_model_gradients_match_reference(kind, profile, fine_depths):
+    """loss.backward() through the drop-in model vs (a) autograd through the oracle, every element, and (b) the
+    reference's own gradients (strided sample in fixture G7).
+
+    'oracle': the fine pass runs on the oracle's fine depths, so every parameter gradient must agree to GRAD_TOL.
+    'own':    the model resamples itself; a fraction of a percent of its fine samples sit in other bins than the
+              reference's, which perturbs the FINE model's gradients at the percent level, so those
+              are bounded at 5e-2 while coarse and augmented models keep GRAD_TOL."""
+    g = util.load(f'grads_{kind}_{profile}.npz')
+    cfg = synth.with_overrides(synth.make_configs(kind), perturb=False, raw_noise_std=0.0)
+    params = {k: v.clone().requires_grad_(True) for k, v in util.golden_params(cfg, g).items()}
+    ref_out = oracle.render(params, cfg, util.golden_batch(g), training=True)
+    util.grad_loss(ref_out).backward()
+
+    model = get_model(cfg, None)
+    model.load_state_dict(util.golden_params(cfg, g))
+    model = model.to(DEV).train()
+    batch = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
+    if fine_depths == 'oracle':
+        if 'z_vals_fine' not in ref_out:
+            pytest.skip('no fine pass')
+        model.set_random_draws({'z_vals_fine': ref_out['z_vals_fine'].detach()})
+    out = model(batch)
+    loss = util.grad_loss(out)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-4 * max(1.0, abs(float(g['loss'])))
+    bad = {}
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+        fine = name.startswith('fine_model.')
+        tol = 5e-2 if (fine_depths == 'own' and fine) else 2 * GRAD_TOL
+        # the fixture was produced on the build container's CPU; the reference's fine depths are not reproducible
+        # across CPUs/BLAS builds either (same discontinuity), so its FINE-model gradients are only loosely comparable
+        tol_ref = 5e-2 if fine else 2 * GRAD_TOL
+        err = rel_to_max(p.grad, params[name].grad)
+        sample = p.grad.reshape(-1)[::util.GRAD_SAMPLE_STRIDE].cpu().double().numpy()
+        ref = g[f'gradsample_{name}'].astype(numpy.float64)
+        err_ref = float(numpy.abs(sample - ref).max() / max(float(params[name].grad.abs().max()), 1e-30))
+        if not (err < tol and err_ref < tol_ref):
+            bad[name] = (err, err_ref, tol, tol_ref)
+    assert not bad, bad
+
+
+def test_losses_on_outputs_without_gradient_path_fail_loudly():
+    cfg = synth.make_configs('config1')
+    model = get_model(cfg, None).to(DEV).train()
+    batch = {k: torch.from_numpy(v).to(DEV) for k, v in synth.random_world_rays(16).items()}
+    out = model(batch)
+    assert out['rgb_coarse'].requires_grad and out['depth_coarse'].requires_grad
+    assert not out['weights_coarse'].requires_grad and not out['depth_var_coarse'].requires_grad
+    with pytest.raises(RuntimeError):
+        out['depth_var_coarse'].sum().backward()

@@ -183,15 +183,6 @@ def test_train_forward_with_device_rng_is_statistically_sane():
     assert float((a['raw_sigma_coarse'] != b['raw_sigma_coarse']).float().mean()) > 0.3
 
 
-def test_grad_enabled_training_forward_raises_until_backward_exists():
-    cfg = synth.make_configs('config2')
-    model = get_model(cfg, None).to(DEV).train()
-    g = util.load('e2e_config2_plain.npz')
-    batch = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
-    with pytest.raises(NotImplementedError, match='backward'):
-        model(batch)
-
-
 def test_cpu_tensors_are_rejected_not_silently_computed():
     cfg = synth.make_configs('config1')
     model = get_model(cfg, None).eval()  # parameters left on the CPU

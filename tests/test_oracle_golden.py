@@ -135,3 +135,32 @@ def test_render_train_matches_reference(variant, profile):
     assert sorted(out.keys()) == sorted(ref.keys())
     for k, v in ref.items():
         assert util.rel_linf(out[k], v) < 2e-5, k
+
+
+# ---------------------------------------------------------------- G7 parameter gradients
+def oracle_grads(cfg, g):
+    """Autograd through the oracle's training-mode forward with the fixed scalar loss of tools/make_golden.py."""
+    params = {k: v.clone().requires_grad_(True) for k, v in util.golden_params(cfg, g).items()}
+    out = oracle.render(params, cfg, util.golden_batch(g), training=True)
+    loss = util.grad_loss(out)
+    loss.backward()
+    return loss.detach(), {k: v.grad for k, v in params.items()}, out
+
+
+@pytest.mark.parametrize('kind,profile', [('config3', 'consistent'), ('config2', 'consistent'), ('headline_world', 'dense'),
+                                          ('config1', 'dense')])
+def test_gradients_match_reference(kind, profile):
+    g = util.load(f'grads_{kind}_{profile}.npz')
+    cfg = synth.with_overrides(synth.make_configs(kind), perturb=False, raw_noise_std=0.0)
+    loss, grads, _ = oracle_grads(cfg, g)
+    assert abs(float(loss) - float(g['loss'])) < 1e-5 * max(1.0, abs(float(g['loss'])))
+    checked = 0
+    for name, grad in grads.items():
+        assert grad is not None, name
+        ref_norm = float(g[f'gradnorm_{name}'])
+        sample = grad.reshape(-1)[::util.GRAD_SAMPLE_STRIDE]
+        scale = max(ref_norm / max(1.0, grad.numel() ** 0.5), 1e-12)  # rms magnitude of this tensor's gradient
+        assert abs(float(grad.double().norm()) - ref_norm) <= 2e-3 * ref_norm + 1e-12, name
+        assert util.linf(sample, g[f'gradsample_{name}']) <= 2e-3 * max(scale, float(numpy.abs(g[f'gradsample_{name}']).max())), name
+        checked += 1
+    assert checked == len(util.model_param_shapes(cfg))

@@ -104,3 +104,19 @@ def outlier_fraction(a, b, tol):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else numpy.asarray(a)
     b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else numpy.asarray(b)
     return float(numpy.mean(numpy.abs(a.astype(numpy.float64) - b.astype(numpy.float64)) > tol))
+
+
+GRAD_SAMPLE_STRIDE = 61
+
+
+def grad_loss(out):
+    """The fixed scalar loss of tools/make_golden.py (G7): mean squares of every rgb_* / depth_* output the shipped
+    losses read, depths scaled by 0.01."""
+    loss = 0.
+    for k in sorted(out):
+        base = k.replace('points_augmentation_', '').replace('views_augmentation_', '')
+        if base in ('rgb_coarse', 'rgb_fine'):
+            loss = loss + (out[k] ** 2).mean()
+        elif base in ('depth_coarse', 'depth_fine'):
+            loss = loss + 0.01 * (out[k] ** 2).mean()
+    return loss

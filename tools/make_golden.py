@@ -17,6 +17,7 @@ Fixtures written (names follow SURVEY.md 8c):
     composite.npz           G4  volume_rendering (NDC, world, white background; S in 64/192/256)
     resample.npz            G5  sample_pdf + sort (deterministic and with injected u)
     e2e_<config>.npz        G6  SimpleNeRF.forward end-to-end (eval: config1/config2/headline; train: config3)
+    grads_<config>.npz      G7  parameter gradients of a fixed scalar loss through the training-mode forward
 """
 import json
 import os
@@ -400,6 +401,52 @@ def make_e2e(cams):
         save(f'e2e_config3_train_{variant}_{profile}.npz', **arrays)
 
 
+GRAD_SAMPLE_STRIDE = 61
+
+
+def grad_loss(out):
+    """Fixed scalar loss over exactly the outputs the shipped losses read: mean squares of every
+    rgb_* / depth_* output (augmentation-prefixed ones included), depths scaled to O(1)."""
+    loss = 0.
+    for k in sorted(out):
+        base = k.replace('points_augmentation_', '').replace('views_augmentation_', '')
+        if base in ('rgb_coarse', 'rgb_fine'):
+            loss = loss + (out[k] ** 2).mean()
+        elif base in ('depth_coarse', 'depth_fine'):
+            loss = loss + 0.01 * (out[k] ** 2).mean()
+    return loss
+
+
+def make_grads(cams):
+    for kind, n, profile in (('config3', 64, 'consistent'), ('config2', 64, 'consistent'), ('headline_world', 48, 'dense'),
+                             ('config1', 96, 'dense')):
+        cfg = synth.with_overrides(synth.make_configs(kind), perturb=False, raw_noise_std=0.0)
+        model = ref_model(cfg, 106, training=True)
+        if cfg['data_loader']['ndc']:
+            batch, pix = fern_batch(47, n, cams)
+        else:
+            batch = {k: torch.from_numpy(v) for k, v in synth.random_world_rays(n, seed=5).items()}
+        overrides = calibrate_density(model, batch, train_mode=True)
+        if profile == 'consistent':
+            overrides = {k: v for k, v in overrides.items() if not k.startswith('ovr_fine_model')}
+            overrides.update(tie_fine_to_coarse(model))
+        model.zero_grad()
+        out = model(batch)
+        loss = grad_loss(out)
+        loss.backward()
+        arrays = {'seed': 106, 'loss': loss.detach()}
+        arrays.update(overrides)
+        arrays.update({f'in_{k}': v for k, v in batch.items()})
+        for name, p in model.named_parameters():  # fixture stays small: norm + a strided sample of every gradient
+            flat = p.grad.reshape(-1)
+            arrays[f'gradnorm_{name}'] = flat.double().norm()
+            arrays[f'gradsample_{name}'] = flat[::GRAD_SAMPLE_STRIDE].clone()
+        for k in ('rgb_coarse', 'depth_coarse'):
+            arrays[f'out_{k}'] = out[k].detach()
+        save(f'grads_{kind}_{profile}.npz', **arrays)
+        print('   loss %.6f  max|grad| %.3e' % (float(loss), max(float(p.grad.abs().max()) for p in model.parameters())))
+
+
 if __name__ == '__main__':
     cams = make_cameras()
     make_raygen(cams)
@@ -408,3 +455,4 @@ if __name__ == '__main__':
     make_composite(cams)
     make_resample()
     make_e2e(cams)
+    make_grads(cams)
