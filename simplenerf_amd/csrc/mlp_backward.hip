@@ -18,6 +18,8 @@
 // Bound: MFMA fp32; algorithmic FLOPs = 2x the forward's (dgrad + wgrad).  HBM per sample: reads ~10 KB of saved
 // activations + ~10 KB of dY tiles twice (B1 writes, B2 reads) -- about 40 KB/sample, i.e. ~2.5 TB/s at the full MFMA
 // rate: under the HBM roofline, overlapped with the matrix work.
+#include <algorithm>
+
 #include "mlp_device.h"
 
 namespace {
@@ -161,108 +163,134 @@ struct WgradJob {
     int b_param;                        // bias destination or -1
 };
 
-constexpr int kLdsRow = 36;  // 32 samples + 4 floats of padding: conflict-free ds_read_b128 over 16 consecutive rows
+constexpr int kMaxJobs = 16;
+struct JobTable {
+    int count;
+    int wg_start[kMaxJobs + 1];  // workgroup range of job j in the single launch: [wg_start[j], wg_start[j+1])
+    WgradJob jobs[kMaxJobs];
+};
+struct GradPointers {
+    float* p[40];
+};
 
-template <int TPW>
-__global__ void __launch_bounds__(256, 1) wgrad_kernel(WgradJob job, const float* __restrict__ grads,
-                                                       const float* __restrict__ acts, float* __restrict__ partial) {
+// Per-wave register tile of the weight-gradient kernel: NO x NI accumulator tiles of 32x32.  The 4 waves of a workgroup
+// form a (WO x WI) grid over the job's (out_tiles x in_tiles) product, WO = out_tiles / NO, WI = in_tiles / NI.
+template <int NO, int NI>
+__global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const float* __restrict__ grads,
+                                                       const float* __restrict__ acts, float* __restrict__ partial,
+                                                       const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    const int chunk = blockIdx.x;
+    int ji = 0;
+    while (ji + 1 < table.count && (int)blockIdx.x >= table.wg_start[ji + 1]) ++ji;
+    const WgradJob& job = table.jobs[ji];
+    const int chunk = blockIdx.x - table.wg_start[ji];
     const int rows_dy = job.out_tiles * 32, rows_x = job.in_tiles * 32, rows = rows_dy + rows_x;
-    const int ntiles = job.out_tiles * job.in_tiles;
+    const int wgrid_i = job.in_tiles / NI;               // WI: 1, 2 or 4
+    const int wo = wave / wgrid_i, wi = wave - wo * wgrid_i;
+    const bool active = wo * NO < job.out_tiles;          // surplus waves only help with the staging
     const long long per = (job.blocks + job.chunks - 1) / job.chunks;
     const long long b0 = chunk * per, b1 = (b0 + per < job.blocks) ? b0 + per : job.blocks;
 
-    f32x16 acc[TPW];
-    float bsum[TPW];
+    f32x16 acc[NO][NI];
+    float bsum[NO];
 #pragma unroll
-    for (int n = 0; n < TPW; ++n) {
-        bsum[n] = 0.0f;
+    for (int oo = 0; oo < NO; ++oo) {
+        bsum[oo] = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+        for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[oo][ii][r] = 0.0f;
     }
-    float* lds_dy = lds;
-    float* lds_x = lds + rows_dy * kLdsRow;
 
-    constexpr int kMaxStage = 16;  // float4 per thread per block: (out_tiles + in_tiles) <= 16
-    f32x4 stage[kMaxStage];
-    auto fetch = [&](long long b) {
-#pragma unroll
-        for (int it = 0; it < kMaxStage; ++it) {
-            const int idx = it * 256 + tid;
-            const int row = idx >> 3, c4 = idx & 7;
-            f32x4 v = {0, 0, 0, 0};
-            if (row < rows) {
-                if (row < rows_dy) {
-                    if (row < job.out_rows) v = *reinterpret_cast<const f32x4*>(grads + (b * job.grad_rows + job.dy_row0 + row) * 32 + c4 * 4);
-                } else {
-                    const int xr = row - rows_dy;
-                    if (xr < job.in_rows) v = *reinterpret_cast<const f32x4*>(acts + (b * job.act_rows + job.x_row0 + xr) * 32 + c4 * 4);
-                }
+    // Staging by LDS-DMA, 1 KiB (= 8 tile rows of 32 samples) per wave instruction.  LDS keeps plain 128-byte rows; the
+    // 16-byte chunks of a row are XOR-swizzled by ((row >> 1) & 7) -- applied to the per-lane SOURCE address here and
+    // to the read address below -- so that the 16 lanes of a ds_read_b128 group (16 rows, same logical chunk) hit 16
+    // different bank quads.  Rows beyond the job's out_rows / in_rows are filled from a zero page.
+    const int buf_floats = rows * 32;
+    auto stage = [&](long long b, float* dst) {
+        const int pieces = rows >> 3;
+        for (int q = wave; q < pieces; q += 4) {
+            const int r = q * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            const float* src = zeros + c * 4;
+            if (r < rows_dy) {
+                if (r < job.out_rows) src = grads + (b * job.grad_rows + job.dy_row0 + r) * 32 + c * 4;
+            } else if (r - rows_dy < job.in_rows) {
+                src = acts + (b * job.act_rows + job.x_row0 + (r - rows_dy)) * 32 + c * 4;
             }
-            stage[it] = v;
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int it = 0; it < kMaxStage; ++it) {
-            const int idx = it * 256 + tid;
-            const int row = idx >> 3, c4 = idx & 7;
-            if (row < rows) *reinterpret_cast<f32x4*>(lds + row * kLdsRow + c4 * 4) = stage[it];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + q * 256), 16, 0, 0);
         }
     };
 
-    if (b0 < b1) fetch(b0);
+    const int swz = ((lane & 31) >> 1) & 7;
+    const int row_off = (lane & 31) * 32;
+    const int a_base = wo * NO * 1024;
+    const int b_base = rows_dy * 32 + wi * NI * 1024;
+
+    if (b0 < b1) stage(b0, lds);
     for (long long b = b0; b < b1; ++b) {
-        __syncthreads();  // everyone finished reading the previous block's tiles
-        commit();
-        __syncthreads();
-        if (b + 1 < b1) fetch(b + 1);  // in flight during the MFMAs below
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // block b has landed for every wave, and every wave is done reading the other buffer
+        const float* cur = lds + ((b - b0) & 1) * buf_floats;
+        if (b + 1 < b1) stage(b + 1, lds + ((b - b0 + 1) & 1) * buf_floats);
+        if (active) {
+            // one 8-sample group at a time (not unrolled): keeps the live fragment registers at 4*(NO+NI) so that nothing
+            // spills -- a scratch reload inside this loop would force vmcnt(0) and drain the prefetch DMA issued above
+#pragma unroll 1
+            for (int g = 0; g < 4; ++g) {
+                const int off = (((2 * g + half) ^ swz) << 2) + row_off;
+                f32x4 av[NO], bv[NI];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+                for (int oo = 0; oo < NO; ++oo) av[oo] = *reinterpret_cast<const f32x4*>(cur + a_base + oo * 1024 + off);
 #pragma unroll
-            for (int n = 0; n < TPW; ++n) {
-                const int t = wave + 4 * n;
-                if (t < ntiles) {
-                    const int o = t / job.in_tiles, i = t - o * job.in_tiles;
-                    const f32x4 av = *reinterpret_cast<const f32x4*>(lds_dy + (o * 32 + (lane & 31)) * kLdsRow + 8 * g + 4 * half);
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(lds_x + (i * 32 + (lane & 31)) * kLdsRow + 8 * g + 4 * half);
+                for (int ii = 0; ii < NI; ++ii) bv[ii] = *reinterpret_cast<const f32x4*>(cur + b_base + ii * 1024 + off);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc[n], 0, 0, 0);
-                    if (i == 0) bsum[n] += (av[0] + av[1]) + (av[2] + av[3]);
+                for (int oo = 0; oo < NO; ++oo) {
+#pragma unroll
+                    for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[oo][q], bv[ii][q], acc[oo][ii], 0, 0, 0);
+                    bsum[oo] += (av[oo][0] + av[oo][1]) + (av[oo][2] + av[oo][3]);
                 }
             }
         }
     }
-    // partial[chunk][o*32 + row][i*32 + col]
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!active) return;
+    // partial[chunk][o*32 + row][i*32 + col], bias partial[chunk][o*32 + row]
     const int in_cols = job.in_tiles * 32;
     float* out = partial + job.partial_off + (long long)chunk * rows_dy * in_cols;
     float* bout = partial + job.bias_off + (long long)chunk * rows_dy;
 #pragma unroll
-    for (int n = 0; n < TPW; ++n) {
-        const int t = wave + 4 * n;
-        if (t < ntiles) {
-            const int o = t / job.in_tiles, i = t - o * job.in_tiles;
+    for (int oo = 0; oo < NO; ++oo) {
+        const int o = wo * NO + oo;
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii) {
+            const int i = wi * NI + ii;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                out[(long long)(o * 32 + row) * in_cols + i * 32 + (lane & 31)] = acc[n][r];
+                out[(long long)(o * 32 + row) * in_cols + i * 32 + (lane & 31)] = acc[oo][ii][r];
             }
-            if (i == 0) {
-                const float s = bsum[n] + __shfl_xor(bsum[n], 32, 64);
-                if (half == 0) bout[o * 32 + lane] = s;
-            }
+        }
+        if (wi == 0) {
+            const float sum = bsum[oo] + __shfl_xor(bsum[oo], 32, 64);
+            if (half == 0) bout[o * 32 + lane] = sum;
         }
     }
 }
 
 // B3: fixed-order sum over chunks, scattered into the reference-layout gradient tensors
-__global__ void __launch_bounds__(256) reduce_kernel(WgradJob job, const float* __restrict__ partial,
-                                                     float* __restrict__ grad_w, float* __restrict__ grad_b) {
+__global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float* __restrict__ partial, GradPointers ptrs) {
+    const WgradJob& job = table.jobs[blockIdx.y];
+    float* __restrict__ grad_w = ptrs.p[job.w_param];
+    float* __restrict__ grad_b = job.b_param >= 0 ? ptrs.p[job.b_param] : nullptr;
     const int in_cols = job.in_tiles * 32, rows_dy = job.out_tiles * 32;
     const long long nw = (long long)job.out_rows * job.in_rows;
     const long long total = nw + (grad_b ? job.out_rows : 0);
@@ -293,14 +321,16 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples) {
     Workspace w;
     const long long blocks = (total_samples + 127) / 128 * 4;
     w.grads_floats = blocks * p.grad_rows() * 32;
-    long long chunks = blocks / 8;
-    if (chunks < 1) chunks = 1;
-    if (chunks > 128) chunks = 128;
-    long long off = 0;
+    long long off = 64;  // [0, 64): zero page for padded rows
     auto add = [&](int dy_row0, int out_rows, int x_row0, int in_rows, int w_param, int w_ld, int w_col, int b_param) {
         WgradJob j;
         j.dy_row0 = dy_row0; j.out_rows = out_rows; j.out_tiles = (out_rows + 31) / 32;
         j.x_row0 = x_row0; j.in_rows = in_rows; j.in_tiles = (in_rows + 31) / 32;
+        // workgroups per job ~ its share of the MFMA work: 256 for a full 8x8-tile product, at least 32
+        long long chunks = 4LL * j.out_tiles * j.in_tiles;
+        if (chunks < 32) chunks = 32;
+        if (chunks > blocks / 32) chunks = blocks / 32;  // >= 32 wave blocks per workgroup amortise its 256 KB epilogue
+        if (chunks < 1) chunks = 1;
         j.grad_rows = p.grad_rows(); j.act_rows = p.act_rows();
         j.chunks = (int)chunks; j.blocks = blocks;
         j.partial_off = off;
@@ -331,6 +361,10 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples) {
     } else {
         add(p.grad_head(), 4, p.act_h(d), wd, 2 * d, wd, 0, 2 * d + 1);                      // pts_output_linear (4 rows)
     }
+    // heaviest products first, so the tail of the single launch is made of the small head/encoding jobs
+    std::stable_sort(w.jobs.begin(), w.jobs.end(), [](const WgradJob& a, const WgradJob& b) {
+        return a.out_tiles * a.in_tiles > b.out_tiles * b.in_tiles;
+    });
     w.partial_floats = off;
     w.total_floats = w.grads_floats + w.partial_floats;
     return w;
@@ -352,19 +386,34 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
     return snerf::check_launch("mlp_backward(chain)");
 }
 
-template <int TPW>
-int launch_wgrad(const WgradJob& job, const float* grads, const float* acts, float* partial, hipStream_t stream) {
-    const size_t lds_bytes = sizeof(float) * (size_t)(job.out_tiles + job.in_tiles) * 32 * kLdsRow;
-    auto kernel = wgrad_kernel<TPW>;
+template <int NO, int NI>
+int launch_wgrad(const JobTable& table, const float* grads, const float* acts, float* partial, const float* zeros,
+                 hipStream_t stream) {
+    int max_rows = 0;
+    for (int j = 0; j < table.count; ++j) {
+        const int r = (table.jobs[j].out_tiles + table.jobs[j].in_tiles) * 32;
+        if (r > max_rows) max_rows = r;
+    }
+    const size_t lds_bytes = 2 * sizeof(float) * 32 * (size_t)max_rows;  // double-buffered [rows][32 samples]
+    auto kernel = wgrad_kernel<NO, NI>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(sizeof(float) * 16 * 32 * kLdsRow));
+                                           2 * 4 * 32 * 512);
         if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured = true;
     }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)job.chunks), dim3(256), lds_bytes, stream, job, grads, acts, partial);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)table.wg_start[table.count]), dim3(256), lds_bytes, stream, table, grads, acts,
+                       partial, zeros);
     return snerf::check_launch("mlp_backward(wgrad)");
+}
+
+// Register tile (NO, NI) per wave for a job of (out_tiles x in_tiles): the 4 waves must cover it as a WO x WI grid.
+inline void wave_tile(const WgradJob& j, int* no, int* ni) {
+    const int ot = j.out_tiles, it = j.in_tiles;
+    if (ot >= 4) { *no = ot / 4; *ni = it; return; }          // waves split the out tiles
+    if (ot == 2) { *no = 1; *ni = it >= 2 ? it / 2 : 1; return; }  // 2 x 2 wave grid (or 2 x 1)
+    *no = 1; *ni = it >= 4 ? it / 4 : 1;                        // one out tile: waves split the in tiles
 }
 
 }  // namespace
@@ -413,20 +462,55 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
                                     plan.views_width);
     }
     if (rc != SNERF_OK) return rc;
-    for (const WgradJob& job : ws.jobs) {
-        const int tiles = job.out_tiles * job.in_tiles;
-        const int tpw = (tiles + 3) / 4;
-        if (tpw <= 1) rc = launch_wgrad<1>(job, grads, saved_acts, partial, s);
-        else if (tpw <= 2) rc = launch_wgrad<2>(job, grads, saved_acts, partial, s);
-        else if (tpw <= 4) rc = launch_wgrad<4>(job, grads, saved_acts, partial, s);
-        else if (tpw <= 8) rc = launch_wgrad<8>(job, grads, saved_acts, partial, s);
-        else rc = launch_wgrad<16>(job, grads, saved_acts, partial, s);
-        if (rc != SNERF_OK) return rc;
-        const long long work = (long long)job.out_rows * job.in_rows + job.out_rows;
-        hipLaunchKernelGGL(reduce_kernel, dim3(snerf::stride_grid(work, 256)), dim3(256), 0, s, job, partial,
-                           param_grads[job.w_param], job.b_param >= 0 ? param_grads[job.b_param] : nullptr);
-        rc = snerf::check_launch("mlp_backward(reduce)");
+    if ((int)ws.jobs.size() > kMaxJobs) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many weight-gradient jobs");
+    hipError_t he = hipMemsetAsync(partial, 0, 64 * sizeof(float), s);  // the zero page (first 64 floats of `partial`)
+    if (he != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: memset: %s", hipGetErrorString(he));
+    JobTable table;  // all jobs, for the reduction
+    table.count = (int)ws.jobs.size();
+    table.wg_start[0] = 0;
+    long long max_work = 0;
+    for (int j = 0; j < table.count; ++j) {
+        table.jobs[j] = ws.jobs[j];
+        table.wg_start[j + 1] = table.wg_start[j] + ws.jobs[j].chunks;
+        const long long work = (long long)ws.jobs[j].out_rows * ws.jobs[j].in_rows + ws.jobs[j].out_rows;
+        if (work > max_work) max_work = work;
+    }
+    static const int classes[][2] = {{2, 8}, {2, 2}, {2, 1}, {1, 8}, {1, 4}, {1, 2}, {1, 1}};
+    for (const auto& cls : classes) {
+        JobTable sub;
+        sub.count = 0;
+        sub.wg_start[0] = 0;
+        for (const WgradJob& job : ws.jobs) {
+            int no, ni;
+            wave_tile(job, &no, &ni);
+            if (no != cls[0] || ni != cls[1]) continue;
+            sub.jobs[sub.count] = job;
+            sub.wg_start[sub.count + 1] = sub.wg_start[sub.count] + job.chunks;
+            ++sub.count;
+        }
+        if (sub.count == 0) continue;
+        if (cls[0] == 2 && cls[1] == 8) rc = launch_wgrad<2, 8>(sub, grads, saved_acts, partial, partial, s);
+        else if (cls[0] == 2 && cls[1] == 2) rc = launch_wgrad<2, 2>(sub, grads, saved_acts, partial, partial, s);
+        else if (cls[0] == 2 && cls[1] == 1) rc = launch_wgrad<2, 1>(sub, grads, saved_acts, partial, partial, s);
+        else if (cls[0] == 1 && cls[1] == 8) rc = launch_wgrad<1, 8>(sub, grads, saved_acts, partial, partial, s);
+        else if (cls[0] == 1 && cls[1] == 4) rc = launch_wgrad<1, 4>(sub, grads, saved_acts, partial, partial, s);
+        else if (cls[0] == 1 && cls[1] == 2) rc = launch_wgrad<1, 2>(sub, grads, saved_acts, partial, partial, s);
+        else rc = launch_wgrad<1, 1>(sub, grads, saved_acts, partial, partial, s);
         if (rc != SNERF_OK) return rc;
     }
+    for (const WgradJob& job : ws.jobs) {  // every job must have found its class
+        int no, ni;
+        wave_tile(job, &no, &ni);
+        bool ok = false;
+        for (const auto& cls : classes) ok = ok || (no == cls[0] && ni == cls[1]);
+        if (!ok) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: no weight-gradient kernel for a %dx%d-tile product",
+                                    job.out_tiles, job.in_tiles);
+    }
+    GradPointers ptrs;
+    for (int i = 0; i < num_params; ++i) ptrs.p[i] = param_grads[i];
+    hipLaunchKernelGGL(reduce_kernel, dim3(snerf::stride_grid(max_work, 256), table.count), dim3(256), 0, s, table, partial,
+                       ptrs);
+    rc = snerf::check_launch("mlp_backward(reduce)");
+    if (rc != SNERF_OK) return rc;
     return SNERF_OK;
 }
