@@ -327,9 +327,14 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples) {
         j.dy_row0 = dy_row0; j.out_rows = out_rows; j.out_tiles = (out_rows + 31) / 32;
         j.x_row0 = x_row0; j.in_rows = in_rows; j.in_tiles = (in_rows + 31) / 32;
         // workgroups per job ~ its share of the MFMA work: 256 for a full 8x8-tile product, at least 32
-        long long chunks = 4LL * j.out_tiles * j.in_tiles;
-        if (chunks < 32) chunks = 32;
-        if (chunks > blocks / 32) chunks = blocks / 32;  // >= 32 wave blocks per workgroup amortise its 256 KB epilogue
+        // Large products are MFMA-bound: ~256 workgroups, each with >= 32 wave blocks to amortise its 256 KB epilogue.
+        // Small products (heads, encodings) are DMA-latency-bound with tiny epilogues: as many workgroups as there are
+        // 8-block pieces, up to 512, so that every CU holds two of them.
+        const int tiles = j.out_tiles * j.in_tiles;
+        long long chunks, cap;
+        if (tiles >= 32) { chunks = 4LL * tiles; cap = blocks / 32; }
+        else { chunks = 512; cap = blocks / 8; }
+        if (chunks > cap) chunks = cap;
         if (chunks < 1) chunks = 1;
         j.grad_rows = p.grad_rows(); j.act_rows = p.act_rows();
         j.chunks = (int)chunks; j.blocks = blocks;
