@@ -102,13 +102,20 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP renderer has no CPU path')
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        # RCCL ('nccl') on a multi-GPU node; SNERF_DIST_BACKEND=gloo lets the same code path be rehearsed with several
+        # ranks sharing one GPU (RCCL refuses two ranks on one device)
+        backend = os.environ.get('SNERF_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     configs = synth.make_configs('headline')
     camera = synth.camera('fern', 0)

@@ -95,3 +95,22 @@ def to_display(rgb: Tensor, depth: Tensor):
     """clip -> round(255 x) -> uint8 colour; depth clipped at 0 (post_process_image / post_process_depth)."""
     img = torch.round(torch.clamp(rgb, 0, 1) * 255).to(torch.uint8)
     return img, torch.clamp(depth, min=0)
+
+
+def allreduce_gradients(parameters, world_size: int, group=None) -> None:
+    """Training with rays sharded over ranks: average every parameter gradient across ranks with ONE collective
+    (all gradients flattened into a single buffer: 2 265 488 floats = 9.06 MB for the 4-MLP model).
+    Equivalent to the reference's DataParallel, which gathers the per-device outputs and takes the loss mean over the
+    whole batch (src/Trainer01.py:93-96), when every rank holds the same number of rays."""
+    import torch.distributed as dist
+    params = [p for p in parameters if p.grad is not None]
+    if not params or world_size == 1:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(world_size)
+    offset = 0
+    for p in params:
+        n = p.grad.numel()
+        p.grad.copy_(flat[offset:offset + n].view_as(p.grad))
+        offset += n

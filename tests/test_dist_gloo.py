@@ -54,3 +54,30 @@ def test_two_rank_gather_reassembles_frame(tmp_path, n):
     marker = str(tmp_path / 'done')
     mp.spawn(_worker, args=(2, _free_port(), n, marker), nprocs=2, join=True)
     assert open(marker).read() == 'ok'
+
+
+def _grad_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+        x = torch.arange(40, dtype=torch.float32).reshape(8, 5) / 10
+        shard = x[rank * 4:(rank + 1) * 4]
+        (net(shard) ** 2).mean().backward()
+        harness.allreduce_gradients(net.parameters(), world)
+        got = [p.grad.clone() for p in net.parameters()]
+        net.zero_grad()
+        (net(x) ** 2).mean().backward()  # the same loss over the whole batch on one rank
+        for g, p in zip(got, net.parameters()):
+            assert torch.allclose(g, p.grad, rtol=1e-5, atol=1e-7)
+        if rank == 0:
+            open(tmp, 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_equals_full_batch(tmp_path):
+    marker = str(tmp_path / 'done')
+    mp.spawn(_grad_worker, args=(2, _free_port(), marker), nprocs=2, join=True)
+    assert open(marker).read() == 'ok'
