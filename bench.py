@@ -35,11 +35,13 @@ from simplenerf_amd.models.ModelFactory import get_model  # noqa: E402
 RAYS_PER_GPU = 1024
 FLOP_PER_SAMPLE = 2 * 593408          # main 8x256 MLP, Linear layers only
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_FP16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
 WORKLOAD = ('headline: 1024 rays/GPU x (128 coarse + 128 fine -> 256 merged) samples, 8x256 coarse+fine MLPs, '
             'LLFF fern NDC rays, eval')
 
 
-def synthetic_model(configs, seed, device):
+def synthetic_model(configs, seed, device, precision='fp32'):
+    configs = synth.with_overrides(configs, hip_precision=precision)
     model = get_model(configs, None)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed, sigma_gain=200.0, sigma_shift=8.0).items()})
@@ -78,9 +80,9 @@ def cpu_baseline(configs, camera, first_ray):
                       f'torch {torch.__version__} CPU fp32, chunk 4096 / netchunk 16384'}
 
 
-def pmc_traffic():
+def pmc_traffic(precision):
     """HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run (profiles/), or None."""
-    path = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
+    path = os.path.join(REPO, 'profiles', 'pmc_traffic.json' if precision == 'fp32' else f'pmc_traffic_{precision}.json')
     if os.path.exists(path):
         with open(path) as f:
             return json.load(f).get('mlp_forward_hbm_bytes_per_launch')
@@ -93,6 +95,9 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', choices=('fp32', 'f16x3'), default='fp32',
+                    help="arithmetic of the fused MLP kernel: fp32 MFMA, or fp16 hi/lo split with 3 MFMAs per product "
+                         "(fp32-grade results, same parity tests)")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -120,7 +125,7 @@ def main():
     configs = synth.make_configs('headline')
     camera = synth.camera('fern', 0)
     h, w = camera['resolution']
-    model = synthetic_model(configs, 7, device)
+    model = synthetic_model(configs, 7, device, args.precision)
     # rank r renders pixels [base + r*1024, base + (r+1)*1024) from the middle of the frame
     base = (h // 2) * w
     first = base + rank * RAYS_PER_GPU
@@ -159,6 +164,14 @@ def main():
         kernel_ms = sum(a.elapsed_time(b) for a, b, _ in log)
         kernel_flop = sum(n for _, _, n in log) * FLOP_PER_SAMPLE
         achieved = kernel_flop / (kernel_ms * 1e-3) / 1e12
+        if args.precision == 'fp32':
+            peak, dtype, kernel_name = PEAK_FP32_MFMA_TFLOPS, 'f32', 'mlp_forward_kernel<8,4,true,false,false>'
+            note = 'fp32 MFMA: one pass per algorithmic FLOP'
+        else:
+            peak, dtype, kernel_name = PEAK_FP16_MFMA_TFLOPS, 'f16x3 (fp16 hi/lo split, fp32 accumulate)', \
+                'mlp_forward_f16x3_kernel<8,4,true,false>'
+            note = ('achieved counts ALGORITHMIC FLOPs; the kernel issues 3 fp16 MFMA passes per product, so its ceiling is '
+                    'peak/3 = 833 TFLOP/s and MFMA-pipe utilisation = 3 x frac')
         result = {
             'metric': 'rays/sec (coarse+fine, 128+128 samples)',
             'value': world * RAYS_PER_GPU * args.steps / elapsed,
@@ -166,12 +179,12 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': WORKLOAD, 'rays_per_gpu': RAYS_PER_GPU, 'samples': '128+128',
                        'parallelism': f'ray-shard x{world}' + (' + 1 gather/step' if world > 1 else '')},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(),
-                         'kernel': 'mlp_forward_kernel<8,4,true,false>', 'launches': len(log),
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': pmc_traffic(args.precision),
+                         'kernel': kernel_name, 'note': note, 'launches': len(log),
                          'avg_launch_ms': kernel_ms / max(1, len(log)),
                          'kernel_share_of_step': kernel_ms / (elapsed * 1e3)},
         }

@@ -90,7 +90,10 @@ int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* params, int n
                    snerf_stream_t stream);
 
 enum snerf_precision {
-    SNERF_PRECISION_FP32 = 0 /* fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 FMA chains: the parity path */
+    SNERF_PRECISION_FP32 = 0, /* fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 FMA chains */
+    SNERF_PRECISION_F16X3 = 1 /* every operand split into two fp16 (hi + lo, ~22 significand bits), three fp16 MFMAs per
+                                 product (hi.hi + hi.lo + lo.hi), fp32 accumulate: fp32-grade results at 3/16 of the
+                                 fp32-MFMA time; forward only */
 };
 
 /*   origins, dirs   device (num_rays,3): the rays the depths are measured along (NDC rays when ndc)

@@ -29,6 +29,50 @@ __global__ void __launch_bounds__(256) pack_segment_kernel(const float* __restri
     }
 }
 
+// f16x3 stream: for every (stage, out tile u, k-step): a hi fragment [64 lanes][8 fp16] then a lo fragment, where
+// hi = fp16(w), lo = fp16(w - hi) (lo may be subnormal: the MFMA honours fp16 subnormals, measured).  Element j of lane
+// (i, h) multiplies input feature  16*ks + 8*(j>>2) + 4*h + (j&3)  of an accumulator-sourced segment (the order in which
+// a 32x32 accumulator tile turns into the next B operand), or encoding register n = 8*ks + j of the lane half.
+__global__ void __launch_bounds__(256) pack_half_stage_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                              const float* __restrict__ w2, snerf::MlpPlan::HalfStage st,
+                                                              float* __restrict__ packed) {
+    const int unit_ks = st.unit_floats / 512;
+    const long long total = (long long)st.tiles * unit_ks * 512;  // one thread per (u, ks, lane, j): 512 elements per k-step
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    _Float16* out = reinterpret_cast<_Float16*>(packed + st.dst);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int j = (int)(idx & 7);
+        const int lane = (int)((idx >> 3) & 63);
+        const long long uk = idx >> 9;
+        int ks = (int)(uk % unit_ks);
+        const int u = (int)(uk / unit_ks);
+        const int ks_unit = ks;
+        int si = 0;
+        while (si + 1 < st.nseg && ks >= st.seg[si].ksteps) { ks -= st.seg[si].ksteps; ++si; }
+        const snerf::MlpPlan::HalfSegment& sg = st.seg[si];
+        const float* w = si == 0 ? w0 : (si == 1 ? w1 : w2);
+        const int h = lane >> 5, row = 32 * u + (lane & 31);
+        int col = -1;
+        if (sg.kind == snerf::SEG_ACC) {
+            col = sg.col_offset + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+        } else if (sg.kind == snerf::SEG_POINTS_PE) {
+            const int e = snerf::pe_feature(8 * ks + j, h, snerf::kPointsPairs, sg.degree);
+            if (e >= sg.feat_lo && e < sg.feat_hi) col = sg.col_offset + (e - sg.feat_lo);
+        } else {
+            const int e = snerf::pe_feature(8 * ks + j, h, snerf::kViewsPairs, sg.degree);
+            if (e >= 0) col = sg.col_offset + e;
+        }
+        float v = 0.0f;
+        if (row < sg.out_dim && col >= 0 && col < sg.ld) v = w[(long long)row * sg.ld + col];
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        // unit layout: [ks][hi: 64 lanes x 8][lo: 64 lanes x 8]  (fp16)
+        const long long base = ((long long)u * unit_ks + ks_unit) * 1024;
+        out[base + lane * 8 + j] = hi;
+        out[base + 512 + lane * 8 + j] = lo;
+    }
+}
+
 }  // namespace
 
 extern "C" int snerf_mlp_num_params(const snerf_mlp_desc* desc) {
@@ -61,6 +105,12 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
             hipLaunchKernelGGL(pack_segment_kernel, dim3(snerf::stride_grid(total, 256)), dim3(256), 0, s,
                                params[seg.param], seg, packed);
         }
+    }
+    for (const snerf::MlpPlan::HalfStage& st : plan.half_stages) {
+        const long long total = (long long)st.tiles * (st.unit_floats / 512) * 512;
+        hipLaunchKernelGGL(pack_half_stage_kernel, dim3(snerf::stride_grid(total, 256)), dim3(256), 0, s,
+                           params[st.seg[0].param], params[st.seg[st.nseg > 1 ? 1 : 0].param],
+                           params[st.seg[st.nseg > 2 ? 2 : 0].param], st, packed);
     }
     auto copy = [&](long long dst, const float* src, long long n) {
         if (e == hipSuccess) e = hipMemcpyAsync(packed + dst, src, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, s);

@@ -24,6 +24,22 @@ struct MlpPlan {
     long long head_offset = 0;    // pts_output W [rows][width], b [4]; views_output W [3][views_width], b [4]
     long long dgrad_offset = 0;   // W^T stream consumed by the backward chain (views, feature, trunk depth-1 .. 1) + runway
     std::vector<Segment> dgrad_segments;
+    // ---- f16x3 stream (mlp_forward_f16.hip): out-tile-major "units", each = every k-step of one 32-row out tile ------
+    struct HalfSegment {
+        int param, ld, out_dim;      // source weight tensor (rows x ld)
+        int kind;                    // SEG_ACC / SEG_POINTS_PE / SEG_VIEWS_PE
+        int ksteps;                  // 16-feature k-steps: 16 (width 256), 8 (width 128), 4 (point encoding), 2 (view encoding)
+        int col_offset, feat_lo, feat_hi, degree;
+    };
+    struct HalfStage {
+        int tiles;                   // out tiles
+        int nseg;
+        HalfSegment seg[3];
+        long long dst;               // offset (floats) of the stage's first unit
+        int unit_floats;             // 512 floats (2 KiB: hi + lo fragment) per k-step
+    };
+    std::vector<HalfStage> half_stages;
+    long long half_offset = 0;       // start of the f16x3 stream inside the packed buffer
     long long total_floats = 0;
 
     // ---- saved-activation / gradient tiles of one 32-sample wave block (backward only) -----------------------
@@ -151,6 +167,46 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
         }
         doff += (long long)kSlabKSteps * plan.wt * 64;
         off = doff;
+    }
+    off = (off + 1023) / 1024 * 1024;
+    plan.half_offset = off;
+    {
+        long long hoff = off;
+        auto stage = [&](int tiles, std::initializer_list<MlpPlan::HalfSegment> segs) {
+            MlpPlan::HalfStage st;
+            st.tiles = tiles; st.nseg = 0; st.dst = hoff;
+            int ks = 0;
+            for (const auto& sg : segs) { st.seg[st.nseg++] = sg; ks += sg.ksteps; }
+            st.unit_floats = ks * 512;
+            hoff += (long long)tiles * st.unit_floats;
+            plan.half_stages.push_back(st);
+        };
+        const int hk = plan.width / 16;
+        const MlpPlan::HalfSegment pe_trunk0{0, plan.pts_in, plan.width, SEG_POINTS_PE, 4, 0, 0, plan.pts_in, plan.points_degree};
+        stage(plan.wt, {pe_trunk0});
+        for (int l = 1; l < plan.depth; ++l) {
+            const bool skip_in = (l == 5);
+            const int ld = plan.width + (skip_in ? plan.pts_in : 0);
+            const MlpPlan::HalfSegment hseg{2 * l, ld, plan.width, SEG_ACC, hk, skip_in ? plan.pts_in : 0, 0, 0, 0};
+            if (skip_in) {
+                const MlpPlan::HalfSegment pseg{2 * l, ld, plan.width, SEG_POINTS_PE, 4, 0, 0, plan.pts_in, plan.points_degree};
+                stage(plan.wt, {pseg, hseg});
+            } else {
+                stage(plan.wt, {hseg});
+            }
+        }
+        if (plan.view_dependent) {
+            const int pf = 2 * plan.depth + 2, pv = pf + 2;
+            const int ldv = plan.width + plan.extra + plan.views_pe;
+            stage(plan.wt, {MlpPlan::HalfSegment{pf, plan.width, plan.width, SEG_ACC, hk, 0, 0, 0, 0}});
+            const MlpPlan::HalfSegment vfeat{pv, ldv, plan.views_width, SEG_ACC, hk, 0, 0, 0, 0};
+            const MlpPlan::HalfSegment vpe{pv, ldv, plan.views_width, SEG_POINTS_PE, 4, plan.width, plan.pts_in, plan.full_pe, plan.points_degree};
+            const MlpPlan::HalfSegment vview{pv, ldv, plan.views_width, SEG_VIEWS_PE, 2, plan.width + plan.extra, 0, 0, plan.views_degree};
+            if (plan.sigma_pe) stage(plan.vt, {vfeat, vpe, vview});
+            else stage(plan.vt, {vfeat, vview});
+        }
+        hoff += 24 * 512;  // prefetch runway: one maximum-size unit of zeros
+        off = hoff;
     }
     plan.total_floats = (off + 63) / 64 * 64;
     *p = plan;

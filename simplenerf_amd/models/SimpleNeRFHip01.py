@@ -7,6 +7,10 @@ sites (src/Trainer01.py:93,194,328; src/Tester01.py:63) work unchanged.  All ari
 (simplenerf_amd/csrc) through the C ABI in include/simplenerf_hip.h; PyTorch only owns device memory, the stream and
 the parameters.  There is no eager/CPU fallback: CPU tensors or an unbuilt library raise.
 
+One extra, optional config key: ``configs['model']['hip_precision']`` = ``'fp32'`` (default; fp32 matrix cores) or
+``'f16x3'`` (fp16 hi/lo split, three MFMAs per product, fp32 accumulate: fp32-grade results ~3x faster; used for
+no-grad forwards -- gradient-carrying forwards always run the fp32 kernels, which keep the activations).
+
 Differences from the reference that a caller can observe:
   * ``model.chunk`` / ``model.netchunk`` are accepted and ignored -- the kernels tile the work themselves and the
     results do not depend on chunking;
@@ -135,6 +139,10 @@ class SimpleNeRFHip(torch.nn.Module):
                         name = f'{short}_{level}_model'
                         setattr(self, name, MlpParameters(configs, mcfg[key][f'{level}_mlp']))
                         self._train_only.append((f'{key}_', level, name))
+        precision = mcfg.get('hip_precision', 'fp32')
+        if precision not in ops.PRECISIONS:
+            raise KeyError(f"model.hip_precision must be one of {sorted(ops.PRECISIONS)}, got {precision!r}")
+        self.precision = ops.PRECISIONS[precision]
         self._packed: Dict[str, tuple] = {}
         self._draws: Optional[dict] = None
 
@@ -206,7 +214,7 @@ class SimpleNeRFHip(torch.nn.Module):
                 comp = dict(zip(keys, res[:len(keys)]))
                 sigma, rgb = res[len(keys)], res[len(keys) + 1]
             else:
-                sigma, rgb = packed.forward(march_o, march_d, view_dirs, depths, noise)
+                sigma, rgb = packed.forward(march_o, march_d, view_dirs, depths, noise, self.precision)
                 comp = ops.composite(sigma, rgb, depths, march_d, self.ndc, mcfg['white_bkgd'], rays_o, rays_d)
             # key order as volume_rendering's return_dict (:465-477)
             for k in ('rgb', 'acc', 'alpha', 'visibility', 'weights', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc'):

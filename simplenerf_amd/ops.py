@@ -12,6 +12,9 @@ from . import _lib
 from ._lib import MlpDesc
 
 Tensor = torch.Tensor
+PRECISION_FP32 = 0   # fp32 MFMA
+PRECISION_F16X3 = 1  # fp16 hi/lo split, 3 MFMAs per product, fp32 accumulate (forward only)
+PRECISIONS = {'fp32': PRECISION_FP32, 'f16x3': PRECISION_F16X3}
 
 
 def _stream() -> ctypes.c_void_p:
@@ -120,8 +123,8 @@ class PackedMlp:
         _lib.check(st, 'snerf_mlp_pack')
 
     def forward(self, origins: Tensor, dirs: Tensor, view_dirs: Optional[Tensor], depths: Tensor,
-                sigma_noise: Optional[Tensor] = None):
-        """-> sigma (n,S,1), rgb (n,S,3)"""
+                sigma_noise: Optional[Tensor] = None, precision: int = 0):
+        """-> sigma (n,S,1), rgb (n,S,3).  precision: PRECISION_FP32 (0) or PRECISION_F16X3 (1), see the C header."""
         lib = _lib.load()
         n, s = depths.shape
         origins = _dev(origins, 'origins', (n, 3))
@@ -140,8 +143,8 @@ class PackedMlp:
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0.record()
             st = lib.snerf_mlp_forward(ctypes.byref(self.desc), _ptr(self.buffer), _ptr(origins), _ptr(dirs),
-                                       _ptr(view_dirs), _ptr(depths), n, s, _ptr(sigma_noise), _ptr(sigma), _ptr(rgb), 0,
-                                       _stream())
+                                       _ptr(view_dirs), _ptr(depths), n, s, _ptr(sigma_noise), _ptr(sigma), _ptr(rgb),
+                                       int(precision), _stream())
             if log is not None:
                 t1.record()
                 log.append((t0, t1, n * s))

@@ -98,7 +98,8 @@ def abi_param_list(params: dict, prefix: str = ''):
 @pytest.mark.parametrize('layout', ['main', 'ptsaug', 'viewsaug'])
 @pytest.mark.parametrize('size', ['8x256', '4x128'])
 @pytest.mark.parametrize('mode', ['plain', 'dense'])
-def test_mlp_forward_matches_reference(layout, size, mode):
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+def test_mlp_forward_matches_reference(layout, size, mode, precision):
     g = util.load(f'mlp_{layout}_{size}_{mode}.npz')
     cfg = synth.mlp_config(64, depth=int(g['depth']), width=int(g['width']), views_width=int(g['views_width']),
                            **LAYOUTS[layout])
@@ -110,7 +111,8 @@ def test_mlp_forward_matches_reference(layout, size, mode):
     pts = g['pts']
     b = pts.shape[0]
     origins = torch.zeros((b, 3), device=DEV)
-    sigma, rgb = mlp.forward(origins, dev(pts), dev(g['view_dirs']), torch.ones((b, 1), device=DEV))
+    sigma, rgb = mlp.forward(origins, dev(pts), dev(g['view_dirs']), torch.ones((b, 1), device=DEV),
+                             precision=ops.PRECISIONS[precision])
     # 'dense' multiplies the density head by 400: the same few-ulp summation-order difference of the 256-term dot
     # product is amplified 400x, so its bound is scaled accordingly
     assert util.rel_linf(sigma[:, 0], g['out_sigma']) < (1e-5 if mode == 'plain' else 1e-4)
@@ -126,14 +128,14 @@ def test_mlp_forward_noise_tail_and_multi_sample():
     mlp = ops.PackedMlp(cfg, DEV)
     mlp.pack(abi_param_list({k: v.to(DEV) for k, v in params.items()}))
     rng = numpy.random.RandomState(0)
-    for n, s in ((1, 1), (3, 7), (5, 67), (2, 192)):
+    for n, s, prec in ((1, 1, 0), (3, 7, 0), (5, 67, 1), (2, 192, 0), (2, 192, 1), (1, 1, 1)):
         o = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(numpy.float32))
         d = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(numpy.float32))
         v = d / d.norm(dim=1, keepdim=True)
         z = torch.from_numpy(numpy.sort(rng.uniform(0, 1, (n, s)).astype(numpy.float32), axis=1))
         noise = torch.from_numpy(rng.standard_normal((n, s, 1)).astype(numpy.float32))
         ref = oracle.run_mlp(params, '', cfg, oracle.ray_points(o, d, z), v, None, noise)
-        sigma, rgb = mlp.forward(o.to(DEV), d.to(DEV), v.to(DEV), z.to(DEV), noise.to(DEV))
+        sigma, rgb = mlp.forward(o.to(DEV), d.to(DEV), v.to(DEV), z.to(DEV), noise.to(DEV), precision=prec)
         assert util.rel_linf(sigma, ref['sigma']) < 1e-5
         assert util.linf(rgb, ref['rgb']) < 1e-5
 

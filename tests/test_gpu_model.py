@@ -40,7 +40,8 @@ RGB_TOL, DEPTH_TOL = 1e-4, 1e-3
 MAX_OUTLIER_RAYS = 0.05
 
 
-def build(configs, golden):
+def build(configs, golden, precision='fp32'):
+    configs = synth.with_overrides(configs, hip_precision=precision)
     model = get_model(configs, None)
     res = model.load_state_dict(util.golden_params(configs, golden), strict=True)
     assert not res.missing_keys and not res.unexpected_keys
@@ -106,17 +107,18 @@ EVAL_CASES = [(k, p) for k in ('config1', 'config2', 'headline', 'headline_world
 
 
 @pytest.mark.parametrize('kind,profile', EVAL_CASES)
-def test_eval_forward_matches_reference(kind, profile):
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+def test_eval_forward_matches_reference(kind, profile, precision):
     g = util.load(f'e2e_{kind}_{profile}.npz')
     cfg = synth.make_configs(kind)
-    model = build(cfg, g).eval()
+    model = build(cfg, g, precision).eval()
     batch = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
     before = {k: v.clone() for k, v in batch.items()}
     with torch.no_grad():
         out = model(batch, retraw=True)
         plain = model(batch)
     ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
-    check_outputs(out, ref, strict_fine=(profile == 'consistent'), tag=f'{kind}/{profile}')
+    check_outputs(out, ref, strict_fine=(profile == 'consistent'), tag=f'{kind}/{profile}/{precision}')
     assert sorted(plain.keys()) == sorted(g['eval_keys'].tolist())
     assert all(torch.equal(plain[k], out[k]) for k in plain)
     assert list(batch.keys()) == list(before.keys()) and all(torch.equal(batch[k], before[k]) for k in batch)
