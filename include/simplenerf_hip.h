@@ -29,7 +29,7 @@ enum snerf_status {
 };
 
 /* ABI version of this header; bumped on any signature change. */
-#define SNERF_ABI_VERSION 2
+#define SNERF_ABI_VERSION 3
 int snerf_abi_version(void);
 const char* snerf_last_error(void);
 
@@ -161,6 +161,14 @@ int snerf_composite_backward(const float* sigma, const float* rgb, const float* 
  */
 int snerf_resample_depths(const float* depths_coarse, const float* weights_coarse, long long num_rays,
                           int num_coarse, int num_fine, const float* u, float* depths_fine, snerf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Output post-processing (next-row f3).  Replaces post_process_image / post_process_depth
+ * (src/data_preprocessors/DataPreprocessor01.py:1106-1114) on the device, so a rendered frame crosses PCIe as uint8.
+ *   rgb (n,3) device; depth (n) device or NULL;  image (n,3) uint8 device;  depth_out (n) device or NULL
+ */
+int snerf_to_display(const float* rgb, const float* depth, long long num_rays, unsigned char* image, float* depth_out,
+                     snerf_stream_t stream);
 
 #ifdef __cplusplus
 }

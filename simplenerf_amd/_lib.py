@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_longlong, c_size_t, c_vo
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsimplenerf_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MlpDesc(ctypes.Structure):
@@ -44,6 +44,7 @@ SIGNATURES = {
                                          _FP, _FP, c_void_p]),
     'snerf_composite': (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_longlong, c_int, c_int, c_int, _FP, _FP, _FP, _FP, _FP,
                                 _FP, _FP, _FP, _FP, c_void_p]),
+    'snerf_to_display': (c_int, [_FP, _FP, c_longlong, _FP, _FP, c_void_p]),
     'snerf_resample_depths': (c_int, [_FP, _FP, c_longlong, c_int, c_int, _FP, _FP, c_void_p]),
 }
 

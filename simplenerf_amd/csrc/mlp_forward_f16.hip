@@ -45,6 +45,10 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform; the c
         case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
         case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
         case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -56,6 +60,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform; the c
 // younger unit in flight (a plain __syncthreads() would drain it: its fence waits vmcnt(0) while LDS-DMA is pending).
 struct UnitStream {
     const float* fetch_ptr;  // global address of the next unit to request
+    const float* stream_base;
     float* lds;
     int slot;                // ring slot of the unit about to be consumed
     int lane, wave;
@@ -63,24 +68,40 @@ struct UnitStream {
     const float* pend_src;   // unit being requested piecewise (one DMA instruction per call of fetch_piece)
     float* pend_dst;
     int pend_left;           // DMA instructions this wave still has to issue for it
+    int issued;              // DMA instructions issued for the youngest requested unit (>= its piece count)
 
+    // Branch-free on purpose: a conditional here would cut the unrolled MFMA loop into basic blocks and the fragment reads
+    // could no longer be scheduled a k-step ahead.  Once the unit's pieces are all requested the same (last) piece is simply
+    // requested again -- idempotent, and it only happens where a unit has more k-step pairs than its second successor has
+    // pieces (a few times per pass).  `issued` feeds the counted vmcnt of the next acquire().
     __device__ __forceinline__ void fetch_piece() {
 #ifdef SNERF_ABL_NODMA
-        if (pend_left > 0) { --pend_left; return; }
+        pend_left -= pend_left > 0 ? 1 : 0;
+        return;
 #endif
-        if (pend_left > 0) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pend_src + lane * 4),
-                                             (__attribute__((address_space(3))) void*)pend_dst, 16, 0, 0);
-            pend_src += 1024; pend_dst += 1024; --pend_left;  // this wave's next piece is 4 KiB-pieces further
-        }
+        const int adv = pend_left > 0 ? 1024 : 0;
+        pend_src += adv; pend_dst += adv;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pend_src + lane * 4),
+                                         (__attribute__((address_space(3))) void*)pend_dst, 16, 0, 0);
+        pend_left -= pend_left > 0 ? 1 : 0;
+        ++issued;
     }
     __device__ __forceinline__ void finish_fetch() {
         while (pend_left > 0) fetch_piece();
     }
+    // No further unit to request: the (branch-free) fetch_piece calls of the remaining k-steps re-read one valid KiB of
+    // the stream into a per-wave dump area instead of touching a live buffer.
+    __device__ __forceinline__ void issued_next_none() {
+        pend_src = stream_base;
+        pend_dst = lds + kUnitBuffers * kUnitBufFloats + wave * 256;  // dump: 4 KiB right after the ring
+        pend_left = 0;
+        issued = 0;
+    }
     __device__ __forceinline__ void begin_fetch(int ksteps, int into_slot) {
-        pend_src = fetch_ptr + wave * 256;
-        pend_dst = lds + into_slot * kUnitBufFloats + wave * 256;
+        pend_src = fetch_ptr + wave * 256 - 1024;   // fetch_piece pre-increments
+        pend_dst = lds + into_slot * kUnitBufFloats + wave * 256 - 1024;
         pend_left = ksteps >> 1;
+        issued = 0;
         fetch_ptr += ksteps * 512;
     }
     __device__ __forceinline__ void fetch(int ksteps, int into_slot) {
@@ -88,9 +109,10 @@ struct UnitStream {
         finish_fetch();
     }
     __device__ __forceinline__ void start(const float* first, float* lds_base, int ks0, int ks1, int lane_, int wave_) {
-        fetch_ptr = first; lds = lds_base; slot = 0; lane = lane_; wave = wave_; pend_left = 0;
+        fetch_ptr = first; stream_base = first; lds = lds_base; slot = 0; lane = lane_; wave = wave_; pend_left = 0; issued = 0;
         fetch(ks0, 0);
         if (ks1 > 0) fetch(ks1, 1);
+        if (ks1 <= 0) issued_next_none();
     }
     // Unit i becomes readable.  `next` = k-steps of unit i+1 (still in flight afterwards), `next2` = k-steps of unit i+2,
     // which is requested now into the slot unit i-1 just vacated (0 = no such unit).
@@ -98,14 +120,14 @@ struct UnitStream {
     // MFMA loop (fetch_piece) so that their issue cost (~60-100 cycles each) does not sit in front of the tile's MFMAs.
     __device__ __forceinline__ const float* acquire(int next, int next2) {
         finish_fetch();                                         // (units shorter than their successor's piece count)
-        wait_vmcnt(next >> 1);                                  // everything older than unit i+1's pieces has landed
+        wait_vmcnt(next > 0 ? issued : 0);                      // everything older than unit i+1's requests has landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my LDS reads of unit i-1 are complete
 #ifndef SNERF_ABL_NOBARRIER
         __builtin_amdgcn_s_barrier();
 #endif
         const float* ready = lds + slot * kUnitBufFloats;
         const int vacated = slot == 0 ? kUnitBuffers - 1 : slot - 1;
-        if (next2 > 0) begin_fetch(next2, vacated);
+        if (next2 > 0) begin_fetch(next2, vacated); else issued_next_none();
         slot = slot == kUnitBuffers - 1 ? 0 : slot + 1;
         return ready;
     }
@@ -147,10 +169,12 @@ __device__ __forceinline__ void seg_mfma(f32x16& acc, const float*& p, const f16
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         f16x8 nah = ah, nal = al;
+#ifndef SNERF_ABL_NOLDSREAD
         if (ks + 1 < NKS) {
             nah = *reinterpret_cast<const f16x8*>(p + (ks + 1) * 512);
             nal = *reinterpret_cast<const f16x8*>(p + (ks + 1) * 512 + 256);
         }
+#endif
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
@@ -184,6 +208,10 @@ __device__ __forceinline__ void tile_bias(f32x16& acc, const float* __restrict__
 // (ReLU and) split one finished accumulator tile into the two k-steps it feeds in the next layer.
 template <bool RELU>
 __device__ __forceinline__ void split_tile(const f32x16& acc, f16x8& h0, f16x8& l0, f16x8& h1, f16x8& l1) {
+#ifdef SNERF_ABL_NOCONVERT
+    h0[0] = (_Float16)acc[0]; l0[0] = (_Float16)acc[1]; h1[0] = (_Float16)acc[8]; l1[0] = (_Float16)acc[9];
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float a = acc[j], b = acc[8 + j];
@@ -251,7 +279,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
     };
     // Biases and head weights live in LDS for the whole kernel: an ordinary global load inside the tile loop would make
     // the compiler wait vmcnt(0), i.e. drain the weight prefetch (LDS-DMA) that is deliberately left in flight.
-    float* consts = lds + kUnitBuffers * kUnitBufFloats;
+    float* consts = lds + kUnitBuffers * kUnitBufFloats + 1024;  // after the ring and the 4-KiB DMA dump area
     for (int i = threadIdx.x * 4; i < args.const_floats; i += 256 * 4)
         *reinterpret_cast<f32x4*>(consts + i) = *reinterpret_cast<const f32x4*>(a.packed + a.bias_offset + i);
     __syncthreads();
@@ -282,26 +310,22 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
     const float* bias = consts;
     const float* wout = consts + (a.pts_out_w - a.bias_offset);
     const float* bout = consts + (a.pts_out_b - a.bias_offset);
-    f16x8 xh[HK], xl[HK], nh[HK], nl[HK];
+    f16x8 xh[HK], xl[HK];
     float head[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // density (and view-independent colour) pre-activations
     const bool single = a.depth == 1;
 
-    // Two accumulator tiles alternate: while tile u accumulates on the matrix pipe, tile u-1 is ReLU'd and split into the
-    // next layer's fp16 operands on the VALU, one slice behind each k-step (TileSplitter, passed to seg_mfma as `side`).
-    f32x16 accs[2];
-    auto splitter_relu = [&](int u, bool on) {
-        const int t = u > 0 ? u - 1 : 0;
-        return TileSplitter<true>{&accs[(u & 1) ^ 1], &nh[2 * t], &nl[2 * t], &nh[2 * t + 1], &nl[2 * t + 1], on};
-    };
-    auto splitter_plain = [&](int u, bool on) {
-        const int t = u > 0 ? u - 1 : 0;
-        return TileSplitter<false>{&accs[(u & 1) ^ 1], &nh[2 * t], &nl[2 * t], &nh[2 * t + 1], &nl[2 * t + 1], on};
-    };
-    auto heads_from = [&](const f32x16& acc, int u) {
-        head[0] += tile_dot_relu(acc, wout + 32 * u, half);
+    // One accumulator tile per out tile of the layer (WT x 16 registers -- the matrix pipe's own AGPR file), and the
+    // activations xh/xl in arch VGPRs where the MFMA reads them directly.  After the layer's last tile the accumulators
+    // are ReLU'd and split into the next layer's operands in one VALU pass.  (An earlier variant overlapped that pass
+    // with the next tile's MFMAs through a second operand buffer; the extra 128 registers pushed the B operands into
+    // AGPRs and every MFMA then paid v_accvgpr_read moves -- slower overall.)
+    f32x16 acc[WT];
+    const NoSide none;
+    auto heads_from = [&](const f32x16& t, int u) {
+        head[0] += tile_dot_relu(t, wout + 32 * u, half);
         if (!VIEWDEP) {
 #pragma unroll
-            for (int c = 1; c < 4; ++c) head[c] += tile_dot_relu(acc, wout + c * WT * 32 + 32 * u, half);
+            for (int c = 1; c < 4; ++c) head[c] += tile_dot_relu(t, wout + c * WT * 32 + 32 * u, half);
         }
     };
 
@@ -309,21 +333,12 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
 #pragma unroll
     for (int u = 0; u < WT; ++u) {
         const float* unit = next_unit();
-        f32x16& acc = accs[u & 1];
-        const auto side = splitter_relu(u, u > 0);
-        tile_bias(acc, bias + 32 * u, half);
-        seg_mfma<4>(acc, unit, pe_h, pe_l, side, 0, st);
-#pragma unroll
-        for (int i = 4; i < 8; ++i) side.step(i);
-        if (single) heads_from(acc, u);
-    }
-    {
-        const auto tail = splitter_relu(WT, true);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) tail.step(i);
+        tile_bias(acc[u], bias + 32 * u, half);
+        seg_mfma<4>(acc[u], unit, pe_h, pe_l, none, 8, st);
+        if (single) heads_from(acc[u], u);
     }
 #pragma unroll
-    for (int k = 0; k < HK; ++k) { xh[k] = nh[k]; xl[k] = nl[k]; }
+    for (int u = 0; u < WT; ++u) split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
 
     // ---- trunk layers 1 .. depth-1 --------------------------------------------------------------------------------
 #pragma unroll 1
@@ -333,24 +348,13 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
 #pragma unroll
         for (int u = 0; u < WT; ++u) {
             const float* unit = next_unit();
-            f32x16& acc = accs[u & 1];
-            const auto side = splitter_relu(u, u > 0);
-            tile_bias(acc, bl + 32 * u, half);
-            if (l == 5) {  // skip connection [encoding | h]
-                seg_mfma<4>(acc, unit, pe_h, pe_l, side, 0, st);
-                seg_mfma<HK>(acc, unit, xh, xl, side, 4, st);
-            } else {
-                seg_mfma<HK>(acc, unit, xh, xl, side, 0, st);
-            }
-            if (last) heads_from(acc, u);
-        }
-        {
-            const auto tail = splitter_relu(WT, true);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) tail.step(i);
+            tile_bias(acc[u], bl + 32 * u, half);
+            if (l == 5) seg_mfma<4>(acc[u], unit, pe_h, pe_l, none, 8, st);  // skip connection [encoding | h]
+            seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
+            if (last) heads_from(acc[u], u);
         }
 #pragma unroll
-        for (int k = 0; k < HK; ++k) { xh[k] = nh[k]; xl[k] = nl[k]; }
+        for (int u = 0; u < WT; ++u) split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
     }
 
     float sigma = (head[0] + __shfl_xor(head[0], 32, 64)) + bout[0];
@@ -366,32 +370,25 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
 #pragma unroll
         for (int u = 0; u < WT; ++u) {
             const float* unit = next_unit();
-            f32x16& acc = accs[u & 1];
-            const auto side = splitter_plain(u, u > 0);
-            tile_bias(acc, bf + 32 * u, half);
-            seg_mfma<HK>(acc, unit, xh, xl, side, 0, st);
+            tile_bias(acc[u], bf + 32 * u, half);
+            seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
         }
-        {
-            const auto tail = splitter_plain(WT, true);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) tail.step(i);
-        }
+        for (int u = 0; u < WT; ++u) split_tile<false>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
         // views layer over [feature | rest of the point encoding (points-aug) | view encoding], then the colour head
         const float* bv = consts + (a.views_bias - a.bias_offset);
         const float* wv = consts + (a.views_out_w - a.bias_offset);
         const float* bo = consts + (a.views_out_b - a.bias_offset);
         float col[3] = {0.0f, 0.0f, 0.0f};
-        const NoSide none;
 #pragma unroll
         for (int u = 0; u < VT; ++u) {
             const float* unit = next_unit();
-            f32x16& acc = accs[u & 1];
-            tile_bias(acc, bv + 32 * u, half);
-            seg_mfma<HK>(acc, unit, nh, nl, none, 8, st);
-            if (SIGMA_PE) seg_mfma<4>(acc, unit, pe_h, pe_l, none, 8, st);
-            seg_mfma<2>(acc, unit, pev_h, pev_l, none, 8, st);
+            tile_bias(acc[u], bv + 32 * u, half);
+            seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
+            if (SIGMA_PE) seg_mfma<4>(acc[u], unit, pe_h, pe_l, none, 8, st);
+            seg_mfma<2>(acc[u], unit, pev_h, pev_l, none, 8, st);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) col[c] += tile_dot_relu(acc, wv + c * VT * 32 + 32 * u, half);
+            for (int c = 0; c < 3; ++c) col[c] += tile_dot_relu(acc[u], wv + c * VT * 32 + 32 * u, half);
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoidf((col[c] + __shfl_xor(col[c], 32, 64)) + bo[c]);
@@ -409,12 +406,12 @@ template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE>
 int launch_half(const HalfArgs& args, hipStream_t stream) {
     const long long blocks = (args.m.total + 127) / 128;
     if (blocks > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: too many samples in one call");
-    const size_t lds_bytes = sizeof(float) * (kUnitBuffers * kUnitBufFloats + (size_t)args.const_floats);
+    const size_t lds_bytes = sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024 + (size_t)args.const_floats);
     auto kernel = mlp_forward_f16x3_kernel<WT, VT, VIEWDEP, SIGMA_PE>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 6144)));
+                                           (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024 + 5120)));
         if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured = true;
     }
@@ -432,7 +429,7 @@ int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, hipStream_t stream)
     args.m = m;
     args.half_offset = plan.half_offset;
     args.const_floats = (int)((plan.dgrad_offset - plan.bias_offset + 3) / 4 * 4);  // biases + heads (+ alignment padding)
-    if (args.const_floats > 6144) return fail(SNERF_E_UNSUPPORTED, "mlp_forward(f16x3): bias/head block of %d floats exceeds its LDS area", args.const_floats);
+    if (args.const_floats > 5120) return fail(SNERF_E_UNSUPPORTED, "mlp_forward(f16x3): bias/head block of %d floats exceeds its LDS area", args.const_floats);
     for (const MlpPlan::HalfStage& st : plan.half_stages)
         if (st.unit_floats > kUnitBufFloats)
             return fail(SNERF_E_UNSUPPORTED, "mlp_forward(f16x3): staging unit of %d KiB exceeds the LDS buffer", st.unit_floats / 256);

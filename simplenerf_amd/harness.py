@@ -92,9 +92,9 @@ def render_frame(model, camera: dict, ndc: bool, device, keys: Iterable[str] = D
 
 
 def to_display(rgb: Tensor, depth: Tensor):
-    """clip -> round(255 x) -> uint8 colour; depth clipped at 0 (post_process_image / post_process_depth)."""
-    img = torch.round(torch.clamp(rgb, 0, 1) * 255).to(torch.uint8)
-    return img, torch.clamp(depth, min=0)
+    """clip -> round(255 x) -> uint8 colour; depth clipped at 0 (post_process_image / post_process_depth), fused on
+    the device so that a frame is copied to the host as 3 B/pixel."""
+    return ops.to_display(rgb, depth)
 
 
 def allreduce_gradients(parameters, world_size: int, group=None) -> None:

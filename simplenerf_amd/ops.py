@@ -52,6 +52,8 @@ def generate_rays(resolution, intrinsic, pose, near: float, ndc: bool, device, f
     p = numpy.ascontiguousarray(numpy.asarray(pose, dtype=numpy.float32).reshape(4, 4))
     out = {name: torch.empty((num_rays, 3), dtype=torch.float32, device=device)
            for name in (('rays_o', 'rays_d', 'view_dirs') + (('rays_o_ndc', 'rays_d_ndc') if ndc else ()))}
+    if num_rays == 0:
+        return out
     with torch.cuda.device(out['rays_o'].device):
         st = lib.snerf_generate_rays(h, w, k.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                                      p.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), float(pixel_offset), int(ndc),
@@ -71,6 +73,8 @@ def coarse_depths(near: Tensor, far: Tensor, num_samples: int, lindisp: bool = F
     far = _dev(far.reshape(-1), 'far', (n,))
     t_rand = _dev(t_rand, 't_rand', (n, num_samples))
     out = torch.empty((n, num_samples), dtype=torch.float32, device=near.device)
+    if n == 0:
+        return out
     with torch.cuda.device(near.device):
         st = lib.snerf_coarse_depths(_ptr(near), _ptr(far), n, int(num_samples), int(bool(lindisp)), _ptr(t_rand),
                                      _ptr(out), _stream())
@@ -137,6 +141,8 @@ class PackedMlp:
             sigma_noise = _dev(sigma_noise.reshape(n, s), 'sigma_noise', (n, s))
         sigma = torch.empty((n, s, 1), dtype=torch.float32, device=depths.device)
         rgb = torch.empty((n, s, 3), dtype=torch.float32, device=depths.device)
+        if n == 0:
+            return sigma, rgb
         log = PackedMlp.event_log
         with torch.cuda.device(depths.device):
             if log is not None:
@@ -170,6 +176,8 @@ class PackedMlp:
         sigma = torch.empty((n, s, 1), dtype=torch.float32, device=dev)
         rgb = torch.empty((n, s, 3), dtype=torch.float32, device=dev)
         saved = torch.empty(lib.snerf_mlp_saved_floats(ctypes.byref(self.desc), n, s), dtype=torch.float32, device=dev)
+        if n == 0:
+            return sigma, rgb, saved
         log = PackedMlp.event_log
         with torch.cuda.device(dev):
             if log is not None:
@@ -196,6 +204,8 @@ class PackedMlp:
         d_rgb = _dev(d_rgb, 'd_rgb', (n, s, 3))
         if len(param_shapes) != self.num_params:
             raise RuntimeError(f'expected {self.num_params} parameter shapes, got {len(param_shapes)}')
+        if n == 0:
+            return [torch.zeros(tuple(shape), dtype=torch.float32, device=dev) for shape in param_shapes]
         grads = [torch.empty(tuple(shape), dtype=torch.float32, device=dev) for shape in param_shapes]
         work = torch.empty(lib.snerf_mlp_backward_workspace_floats(ctypes.byref(self.desc), n, s), dtype=torch.float32,
                            device=dev)
@@ -229,6 +239,8 @@ def composite(sigma: Tensor, rgb: Tensor, depths: Tensor, march_dirs: Tensor, nd
     if ndc:
         rays_o = _dev(rays_o, 'rays_o', (n, 3))
         rays_d = _dev(rays_d, 'rays_d', (n, 3))
+    if n == 0:
+        return out
     with torch.cuda.device(dev):
         st = lib.snerf_composite(_ptr(sigma), _ptr(rgb), _ptr(depths), _ptr(march_dirs), _ptr(rays_o if ndc else None),
                                  _ptr(rays_d if ndc else None), n, s, int(bool(ndc)), int(bool(white_bkgd)),
@@ -260,6 +272,8 @@ def composite_backward(sigma: Tensor, rgb: Tensor, depths: Tensor, march_dirs: T
     dev = depths.device
     d_sigma = torch.empty((n, s), dtype=torch.float32, device=dev)
     d_rgb = torch.empty((n, s, 3), dtype=torch.float32, device=dev)
+    if n == 0:
+        return d_sigma, d_rgb
     with torch.cuda.device(dev):
         st = lib.snerf_composite_backward(_ptr(sigma), _ptr(rgb), _ptr(depths), _ptr(march_dirs),
                                           _ptr(rays_o if ndc else None), _ptr(rays_d if ndc else None), n, s,
@@ -277,8 +291,27 @@ def resample_depths(depths_coarse: Tensor, weights_coarse: Tensor, num_fine: int
     weights_coarse = _dev(weights_coarse, 'weights_coarse', (n, s_c))
     u = _dev(u, 'u', (n, num_fine))
     out = torch.empty((n, s_c + num_fine), dtype=torch.float32, device=depths_coarse.device)
+    if n == 0:
+        return out
     with torch.cuda.device(depths_coarse.device):
         st = lib.snerf_resample_depths(_ptr(depths_coarse), _ptr(weights_coarse), n, s_c, int(num_fine), _ptr(u),
                                        _ptr(out), _stream())
     _lib.check(st, 'snerf_resample_depths')
     return out
+
+
+# ---------------------------------------------------------------------------------------------- f3
+def to_display(rgb: Tensor, depth: Optional[Tensor] = None):
+    """-> uint8 image (n,3) [clip to [0,1], round(255 x) half-to-even] and depth clipped at 0 (or None)."""
+    lib = _lib.load()
+    n = rgb.shape[0]
+    rgb = _dev(rgb, 'rgb', (n, 3))
+    depth = _dev(depth, 'depth', (n,))
+    image = torch.empty((n, 3), dtype=torch.uint8, device=rgb.device)
+    depth_out = None if depth is None else torch.empty((n,), dtype=torch.float32, device=rgb.device)
+    if n == 0:
+        return image, depth_out
+    with torch.cuda.device(rgb.device):
+        st = lib.snerf_to_display(_ptr(rgb), _ptr(depth), n, ctypes.c_void_p(image.data_ptr()), _ptr(depth_out), _stream())
+    _lib.check(st, 'snerf_to_display')
+    return image, depth_out

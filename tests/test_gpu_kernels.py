@@ -215,3 +215,17 @@ def test_resample_ragged_sizes(s_c, s_f):
         got = ops.resample_depths(z.to(DEV), w.to(DEV), s_f, None if uu is None else uu.to(DEV))
         assert got.shape == (n, s_c + s_f)
         check_resample(got, ref, z)
+
+
+# ---------------------------------------------------------------- f3 output post-processing
+def test_to_display_bit_exact():
+    from oracle import raygen_oracle
+    rng = numpy.random.RandomState(4)
+    n = 100003
+    rgb = rng.uniform(-0.2, 1.2, (n, 3)).astype(numpy.float32)
+    rgb[:512] = (numpy.arange(512 * 3).reshape(512, 3) % 511 + 0.5).astype(numpy.float32) / 255  # exact .5 ties
+    depth = rng.uniform(-1, 6, n).astype(numpy.float32)
+    img_ref, dep_ref = raygen_oracle.to_display(rgb, depth)
+    img, dep = ops.to_display(dev(rgb), dev(depth))
+    assert img.dtype == torch.uint8 and numpy.array_equal(img.cpu().numpy(), img_ref)
+    assert numpy.array_equal(dep.cpu().numpy(), dep_ref)
