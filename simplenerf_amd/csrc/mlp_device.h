@@ -81,23 +81,61 @@ struct SlabStream {
         cur = first; lds = lds_base; parity = 0; lane = lane_; wave = wave_;
         fetch(cur, lds);
     }
-    // Make the current slab (U tiles wide) readable and start fetching the one after it.
+    // Make the current slab (U tiles wide) readable and OPEN the request for the one after it.  The WT DMA instructions
+    // of that request are issued one at a time from inside the MFMA loop (fetch_piece<i>), because a 1-KiB LDS-DMA costs
+    // ~60-100 issue cycles and a burst of WT of them in front of the slab's first MFMA idles the matrix pipe.
     template <int U>
     __device__ __forceinline__ const float* acquire() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of the current slab has landed
         __syncthreads();                                  // everyone's has, and everyone left the other buffer
         const float* ready = lds + parity * kBufFloats;
-        fetch(cur + U * 1024, lds + (parity ^ 1) * kBufFloats);
         cur += U * 1024;
         parity ^= 1;
         return ready;
     }
+    // piece I (0 .. WT-1) of the slab that follows the one being consumed; `cur`/`parity` already point at it
+    template <int I>
+    __device__ __forceinline__ void fetch_piece() const {
+        const int chunk = I * 4 + wave;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cur + chunk * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(lds + parity * kBufFloats + chunk * 256),
+                                         16, 0, 0);
+    }
 };
+
+template <int I, int WT>
+__device__ __forceinline__ void fetch_piece_if(const SlabStream<WT>& st) {
+    if constexpr (I >= 0 && I < WT) st.template fetch_piece<I>();
+}
+// slot = g*U+u of the unrolled loop (a constant after unrolling): issue piece slot/kEvery when slot % kEvery == 0
+template <int U, int WT, int EVERY>
+__device__ __forceinline__ void constexpr_fetch(const SlabStream<WT>& st, int slot) {
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+        if (slot == i * EVERY) {
+            const int chunk = i * 4 + st.wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st.cur + chunk * 256 + st.lane * 4),
+                                             (__attribute__((address_space(3))) void*)(st.lds + st.parity * SlabStream<WT>::kBufFloats + chunk * 256),
+                                             16, 0, 0);
+        }
+}
+template <int WT, int DONE>
+__device__ __forceinline__ void tail_fetch(const SlabStream<WT>& st) {
+#pragma unroll
+    for (int i = DONE; i < WT; ++i) {
+        const int chunk = i * 4 + st.wave;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st.cur + chunk * 256 + st.lane * 4),
+                                         (__attribute__((address_space(3))) void*)(st.lds + st.parity * SlabStream<WT>::kBufFloats + chunk * 256),
+                                         16, 0, 0);
+    }
+}
 
 // acc[u] += W_segment[u-th 32 rows] . B, B = `b` (one register per k-step), NSLAB slabs of 16 k-steps.
 template <int U, int NSLAB, int WT, int NB>
 __device__ __forceinline__ void gemm_segment(f32x16 (&acc)[U], const float (&b)[NB], SlabStream<WT>& st) {
     static_assert(NB >= NSLAB * 16, "B operand array too short");
+    constexpr int kSlots = 4 * U;                      // (k-group, tile) iterations per slab
+    constexpr int kEvery = kSlots >= WT ? kSlots / WT : 1;
 #pragma unroll
     for (int sl = 0; sl < NSLAB; ++sl) {
         const float* slab = st.template acquire<U>() + st.lane * 4;
@@ -109,8 +147,11 @@ __device__ __forceinline__ void gemm_segment(f32x16 (&acc)[U], const float (&b)[
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[sl * 16 + g * 4 + q], acc[u], 0, 0, 0);
+                // spread the next slab's WT DMA pieces over this slab's iterations (all indices are compile-time)
+                constexpr_fetch<U, WT, kEvery>(st, g * U + u);
             }
         }
+        if (kSlots < WT) tail_fetch<WT, kSlots>(st);
     }
 }
 
