@@ -44,8 +44,8 @@ __global__ void __launch_bounds__(256) coarse_depths_kernel(const float* __restr
 
 // One wavefront per ray; 4 rays per 256-thread block.  Per-wave LDS: merged[S_c+S_f] | cdf[S_c-1] | bins[S_c-1].
 // Scan: lane-blocked sequential prefix + 64-lane shuffle scan of the lane totals.  Search: binary search of the
-// LDS-resident CDF.  Merge: rank of every element of [coarse | samples] by counting (stable), scattered to its
-// sorted position -- valid for unsorted random `u` as well as the deterministic case.
+// LDS-resident CDF.  Merge: every element of [coarse | samples] is scattered to its rank (binary searches; a counting
+// pass over the samples only when `u` is random and they are unsorted).
 // HBM: reads 8 B per coarse sample (+4 B per fine sample with `u`), writes 4 B per merged sample.
 __global__ void __launch_bounds__(256) resample_kernel(const float* __restrict__ z_coarse, const float* __restrict__ weights,
                                                        long long num_rays, int s_c, int s_f, const float* __restrict__ u_in,
@@ -113,16 +113,36 @@ __global__ void __launch_bounds__(256) resample_kernel(const float* __restrict__
     }
     snerf::wave_lds_sync();
 
-    // sort(cat(coarse, samples)) by stable rank counting (:314)
+    // sort(cat(coarse, samples)) (:314) as a merge by rank: the coarse depths are ascending (linspace, or jittered
+    // inside disjoint strata), so the rank of a sample among them is a binary search; the samples are ascending too
+    // when u is the deterministic linspace (inverse CDF is monotone), otherwise their mutual order is counted.
+    // Ties: coarse before samples, equal samples by index -- a valid total order, and equal values are interchangeable.
     float* out = z_fine + ray * total;
-    for (int i = lane; i < total; i += 64) {
-        const float v = merged[i];
-        int rank = 0;
-        for (int q = 0; q < total; ++q) {
-            const float x = merged[q];
-            rank += (x < v) || (x == v && q < i);
+    const float* smp = merged + s_c;
+    const bool sorted_samples = (u_in == nullptr);
+    for (int j = lane; j < s_c; j += 64) {          // coarse j: j + #{samples < z_j}
+        const float v = merged[j];
+        int below;
+        if (sorted_samples) {
+            int lo = 0, hi = s_f;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (smp[mid] < v) lo = mid + 1; else hi = mid; }
+            below = lo;
+        } else {
+            below = 0;
+            for (int q = 0; q < s_f; ++q) below += smp[q] < v;
         }
-        out[rank] = v;
+        out[j + below] = v;
+    }
+    for (int k = lane; k < s_f; k += 64) {          // sample k: #{coarse <= s_k} + rank among the samples
+        const float v = smp[k];
+        int lo = 0, hi = s_c;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (merged[mid] <= v) lo = mid + 1; else hi = mid; }
+        int among = k;
+        if (!sorted_samples) {
+            among = 0;
+            for (int q = 0; q < s_f; ++q) { const float x = smp[q]; among += (x < v) || (x == v && q < k); }
+        }
+        out[lo + among] = v;
     }
 }
 
