@@ -29,7 +29,7 @@ enum snerf_status {
 };
 
 /* ABI version of this header; bumped on any signature change. */
-#define SNERF_ABI_VERSION 3
+#define SNERF_ABI_VERSION 4
 int snerf_abi_version(void);
 const char* snerf_last_error(void);
 
@@ -93,7 +93,7 @@ enum snerf_precision {
     SNERF_PRECISION_FP32 = 0, /* fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 FMA chains */
     SNERF_PRECISION_F16X3 = 1 /* every operand split into two fp16 (hi + lo, ~22 significand bits), three fp16 MFMAs per
                                  product (hi.hi + hi.lo + lo.hi), fp32 accumulate: fp32-grade results at 3/16 of the
-                                 fp32-MFMA time; forward only */
+                                 fp32-MFMA time */
 };
 
 /*   origins, dirs   device (num_rays,3): the rays the depths are measured along (NDC rays when ndc)
@@ -116,6 +116,8 @@ int snerf_mlp_forward(const snerf_mlp_desc* desc, const float* packed, const flo
  *   workspace    device, snerf_mlp_backward_workspace_floats(...) floats of scratch
  *   param_grads  num_params device pointers, same order and shapes as snerf_mlp_pack's `params`; each tensor is
  *                OVERWRITTEN with dL/dparam (sums over samples are taken in a fixed order: bit-reproducible)
+ *   precision    SNERF_PRECISION_FP32, or SNERF_PRECISION_F16X3 for the fp16-split forward_train / dgrad chain (the
+ *                weight-gradient products stay on the fp32 matrix cores)
  * Inputs (rays, depths, view directions) receive no gradient -- the reference detaches the sample depths (:312).
  */
 size_t snerf_mlp_saved_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples);
@@ -126,7 +128,8 @@ int snerf_mlp_forward_train(const snerf_mlp_desc* desc, const float* packed, con
 size_t snerf_mlp_backward_workspace_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples);
 int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packed, const float* saved_acts, const float* sigma,
                        const float* rgb, const float* d_sigma, const float* d_rgb, long long num_rays, int num_samples,
-                       float* workspace, float* const* param_grads, int num_params, snerf_stream_t stream);
+                       float* workspace, float* const* param_grads, int num_params, int precision,
+                       snerf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * K4  alpha compositing.  Replaces SimpleNeRF.volume_rendering (src/models/SimpleNeRF01.py:430-483) and

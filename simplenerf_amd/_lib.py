@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_longlong, c_size_t, c_vo
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsimplenerf_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MlpDesc(ctypes.Structure):
@@ -39,7 +39,7 @@ SIGNATURES = {
                                         c_int, c_void_p]),
     'snerf_mlp_backward_workspace_floats': (c_size_t, [POINTER(MlpDesc), c_longlong, c_int]),
     'snerf_mlp_backward': (c_int, [POINTER(MlpDesc), _FP, _FP, _FP, _FP, _FP, _FP, c_longlong, c_int, _FP,
-                                   POINTER(c_void_p), c_int, c_void_p]),
+                                   POINTER(c_void_p), c_int, c_int, c_void_p]),
     'snerf_composite_backward': (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_longlong, c_int, c_int, c_int, _FP, _FP, _FP, _FP,
                                          _FP, _FP, c_void_p]),
     'snerf_composite': (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_longlong, c_int, c_int, c_int, _FP, _FP, _FP, _FP, _FP,

@@ -22,22 +22,11 @@
 
 #include "mlp_device.h"
 
-namespace {
+namespace snerf {
+int mlp_backward_chain_f16x3(const MlpPlan& plan, const ChainArgs& a, hipStream_t stream);  // mlp_backward_f16.hip
+}
 
-struct ChainArgs {
-    const float* packed;
-    const float* acts;      // saved activation tiles
-    const float* sigma;     // (M)   post-ReLU density from the forward (mask of the density ReLU)
-    const float* rgb;       // (M,3) post-sigmoid colour from the forward
-    const float* d_sigma;   // (M)
-    const float* d_rgb;     // (M,3)
-    float* grads;           // dY tiles
-    long long total;
-    int depth, width;
-    long long dgrad_offset, pts_out_w, views_out_w;
-    int act_rows, act_h1, act_hv;
-    int grad_rows, grad_feature, grad_yv, grad_head;
-};
+namespace {
 
 template <int U>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[U]) {
@@ -432,7 +421,7 @@ extern "C" size_t snerf_mlp_backward_workspace_floats(const snerf_mlp_desc* desc
 extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packed, const float* saved_acts,
                                   const float* sigma, const float* rgb, const float* d_sigma, const float* d_rgb,
                                   long long num_rays, int num_samples, float* workspace, float* const* param_grads,
-                                  int num_params, snerf_stream_t stream) {
+                                  int num_params, int precision, snerf_stream_t stream) {
     snerf::MlpPlan plan;
     const int st = snerf::build_plan(desc, &plan);
     if (st != SNERF_OK) return st;
@@ -442,6 +431,8 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
                   num_params);
     for (int i = 0; i < num_params; ++i) SNERF_REQUIRE(param_grads[i], "mlp_backward: gradient tensor %d is NULL", i);
     SNERF_REQUIRE(num_rays >= 1 && num_samples >= 1, "mlp_backward: bad sizes n=%lld S=%d", num_rays, num_samples);
+    if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3)
+        return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: precision %d not built", precision);
     const long long total = num_rays * num_samples;
     if ((total + 127) / 128 > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many samples");
     hipStream_t s = (hipStream_t)stream;
@@ -456,9 +447,17 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     a.act_rows = plan.act_rows(); a.act_h1 = plan.act_h(1); a.act_hv = plan.act_hv();
     a.grad_rows = plan.grad_rows(); a.grad_feature = plan.grad_feature(); a.grad_yv = plan.grad_yv();
     a.grad_head = plan.grad_head();
+    // partial[0..64): zero page for padded staging rows
+    hipError_t he = hipMemsetAsync(partial, 0, 64 * sizeof(float), s);
+    if (he != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: memset: %s", hipGetErrorString(he));
     int rc;
-    const int key = plan.wt * 10 + plan.vt;
+    const int key = precision == SNERF_PRECISION_F16X3 ? -1 : plan.wt * 10 + plan.vt;
+    if (precision == SNERF_PRECISION_F16X3) {
+        rc = snerf::mlp_backward_chain_f16x3(plan, a, s);
+        if (rc != SNERF_OK) return rc;
+    }
     switch (key) {
+        case -1: rc = SNERF_OK; break;
         case 84: rc = launch_chain<8, 4, true>(a, s); break;
         case 80: rc = launch_chain<8, 4, false>(a, s); break;
         case 42: rc = launch_chain<4, 2, true>(a, s); break;
@@ -468,8 +467,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     }
     if (rc != SNERF_OK) return rc;
     if ((int)ws.jobs.size() > kMaxJobs) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many weight-gradient jobs");
-    hipError_t he = hipMemsetAsync(partial, 0, 64 * sizeof(float), s);  // the zero page (first 64 floats of `partial`)
-    if (he != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: memset: %s", hipGetErrorString(he));
+    // (the zero page and the gradient-max word were cleared before the chain kernel)
     JobTable table;  // all jobs, for the reduction
     table.count = (int)ws.jobs.size();
     table.wg_start[0] = 0;

@@ -1,0 +1,246 @@
+// K7b (split-precision variant) -- the backward "dgrad" chain of the fused MLP on the fp16 matrix cores.
+//
+// Same computation as mlp_backward_chain_kernel (mlp_backward.hip): dX^T = W^T . dY^T layer by layer in reverse, ReLU
+// masks from the saved activations, every dY written as a [feature][32-sample] fp32 tile for the weight-gradient kernel.
+// Same arithmetic as mlp_forward_f16.hip: each operand is an fp16 hi/lo pair and each product is three MFMAs
+// (hi.hi + hi.lo + lo.hi) into an fp32 accumulator; W^T is pre-split at pack time (MlpPlan::half_dgrad_stages) and
+// streamed through the 3-slot LDS ring, one 32-row IN-feature tile (all of its k-steps over the OUT features) per unit.
+#include "mlp_device_f16.h"
+
+namespace {
+
+struct HalfChainArgs {
+    ChainArgs c;
+    long long half_dgrad_offset;
+};
+
+template <int U>
+__device__ __forceinline__ void zero_tiles(f32x16 (&acc)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+}
+
+__device__ __forceinline__ void store_tile_rows_scaled(const f32x16& acc, float* __restrict__ rows, int lane, float k) {
+    const int j = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rows[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + j] = acc[r] * k;
+}
+
+// Rescale this sample's gradient vector (U tiles of this lane + the partner lane half) to a maximum in [8, 16).
+template <int U>
+__device__ __forceinline__ void renormalise(f32x16 (&acc)[U], float& gscale, float& gback) {
+    float m = 0.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[u][r]));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float f = renorm_factor(m);
+    // keep the cumulative factor (and its reciprocal) finite: a sample whose gradient underflows to ~1e-38 simply
+    // stops being rescaled -- its contribution is nil anyway
+    if (!(gscale * f < 1.0e30f) || !(gscale * f > 1.0e-30f)) f = 1.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] *= f;
+    gscale *= f;
+    gback = 1.0f / gscale;
+}
+
+// acc <- acc . [saved activation > 0]   (rows 32u..32u+31 of the activation tile)
+__device__ __forceinline__ void mask_tile(f32x16& acc, const float* __restrict__ rows, int lane) {
+    const int j = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+        acc[r] = rows[f * 32 + j] > 0.0f ? acc[r] : 0.0f;
+    }
+}
+
+template <int WT, int VT, bool VIEWDEP>
+__global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfChainArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ChainArgs& a = args.c;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5;
+    constexpr int HK = WT * 2;   // k-steps over a full-width dY
+    constexpr int VK = VT * 2;   // k-steps over the views layer's dY
+
+    // unit idx -> k-steps: [views^T: WT units of VK][feature^T: WT of HK] (view-dependent MLPs), then (depth-1) x WT of HK
+    const int head_units = VIEWDEP ? 2 * WT : 0;
+    const int total_units = head_units + (a.depth - 1) * WT;
+    auto ks_of = [&](int idx) {
+        if (idx >= total_units) return 0;
+        if (VIEWDEP && idx < WT) return VK;
+        return HK;
+    };
+    UnitStream st;
+    st.start(a.packed + args.half_dgrad_offset, lds, ks_of(0), ks_of(1), lane, wave);
+    int unit_idx = 0;
+    auto next_unit = [&]() {
+        const float* p = st.acquire(ks_of(unit_idx + 1), ks_of(unit_idx + 2));
+        ++unit_idx;
+        return p + lane * 4;
+    };
+    const NoSide none;
+
+    const long long block = (long long)blockIdx.x * 4 + wave;
+    const long long first = block * 32 + (lane & 31);
+    const bool live = first < a.total;
+    const float* acts = a.acts + block * a.act_rows * 32;
+    float* grads = a.grads + block * a.grad_rows * 32;
+
+    // ---- head gradients (pre-activation) -------------------------------------------------------------------------
+    float dhead[4];
+    dhead[0] = live && a.sigma[first] > 0.0f ? a.d_sigma[first] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float col = live ? a.rgb[first * 3 + c] : 0.0f;
+        dhead[c + 1] = live ? a.d_rgb[first * 3 + c] * (col * (1.0f - col)) : 0.0f;
+    }
+    if (half == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) grads[(a.grad_head + c) * 32 + (lane & 31)] = dhead[c];
+    }
+    // Per-sample power-of-two scaling (see renorm_factor): `gscale` is the factor currently applied to this sample's
+    // gradients inside the chain, `gback` = 1/gscale is applied whenever one of its dY tiles is stored.
+    float gscale = renorm_factor(fmaxf(fmaxf(fabsf(dhead[0]), fabsf(dhead[1])), fmaxf(fabsf(dhead[2]), fabsf(dhead[3]))));
+    if (!(gscale < 1.0e30f)) gscale = 1.0e30f;
+    float gback = 1.0f / gscale;
+    const float dsig_raw = dhead[0];  // re-enters below, after the views/feature products have been renormalised
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dhead[c] *= gscale;
+
+    f32x16 acc[WT];
+    f16x8 xh[HK], xl[HK];
+    if (VIEWDEP) {
+        // d hv = W_rgb^T dpre masked by the views-layer ReLU -> stored, split into the operand of the first product
+        const float* wv = a.packed + a.views_out_w;
+        const float* hv_tile = acts + a.act_hv * 32;
+        f16x8 vh[VK], vl[VK];
+        f32x16 dyvs[VT];
+#pragma unroll
+        for (int u = 0; u < VT; ++u) {
+            f32x16& dyv = dyvs[u];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wv + 0 * VT * 32 + 32 * u + 8 * g + 4 * half);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wv + 1 * VT * 32 + 32 * u + 8 * g + 4 * half);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(wv + 2 * VT * 32 + 32 * u + 8 * g + 4 * half);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    dyv[4 * g + q] = fmaf(w2[q], dhead[3], fmaf(w1[q], dhead[2], w0[q] * dhead[1]));
+            }
+            mask_tile(dyv, hv_tile + 32 * u * 32, lane);
+            store_tile_rows_scaled(dyv, grads + (a.grad_yv + 32 * u) * 32, lane, gback);
+        }
+        renormalise<VT>(dyvs, gscale, gback);
+#pragma unroll
+        for (int u = 0; u < VT; ++u) split_tile<false>(dyvs[u], vh[2 * u], vl[2 * u], vh[2 * u + 1], vl[2 * u + 1]);
+        // d feature = Wv[:, :width]^T dYv
+#pragma unroll
+        for (int u = 0; u < WT; ++u) {
+            const float* unit = next_unit();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+            seg_mfma<VK>(acc[u], unit, vh, vl, none, 8, st);
+            store_tile_rows_scaled(acc[u], grads + (a.grad_feature + 32 * u) * 32, lane, gback);
+        }
+        renormalise<WT>(acc, gscale, gback);
+#pragma unroll
+        for (int u = 0; u < WT; ++u) split_tile<false>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
+        // d h_depth = W_feature^T dfeature
+#pragma unroll
+        for (int u = 0; u < WT; ++u) {
+            const float* unit = next_unit();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+            seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
+        }
+    } else {
+        zero_tiles<WT>(acc);
+    }
+    // + density head (and, without a views layer, the colour rows of pts_output_linear): d h += W_out^T dhead
+    {
+        const float* wo = a.packed + a.pts_out_w;
+#pragma unroll
+        for (int g = 0; g < WT * 4; ++g) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wo + 8 * g + 4 * half);
+            f32x4 w1 = {0, 0, 0, 0}, w2 = {0, 0, 0, 0}, w3 = {0, 0, 0, 0};
+            if (!VIEWDEP) {
+                w1 = *reinterpret_cast<const f32x4*>(wo + 1 * WT * 32 + 8 * g + 4 * half);
+                w2 = *reinterpret_cast<const f32x4*>(wo + 2 * WT * 32 + 8 * g + 4 * half);
+                w3 = *reinterpret_cast<const f32x4*>(wo + 3 * WT * 32 + 8 * g + 4 * half);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = w0[q] * (VIEWDEP ? dsig_raw * gscale : dhead[0]);  // at the scale `acc` currently carries
+                if (!VIEWDEP) v = fmaf(w3[q], dhead[3], fmaf(w2[q], dhead[2], fmaf(w1[q], dhead[1], v)));
+                acc[g >> 2][4 * (g & 3) + q] += v;
+            }
+        }
+    }
+    // ---- trunk, last layer first: dY_l = dh_{l+1} . [h_{l+1} > 0];  dh_l = W_l[:, h-columns]^T dY_l -------------
+#pragma unroll 1
+    for (int l = a.depth - 1; l >= 0; --l) {
+        const float* h_tile = acts + (a.act_h1 + l * a.width) * 32;
+        float* dy_tile = grads + (l * a.width) * 32;
+#pragma unroll
+        for (int u = 0; u < WT; ++u) {
+            mask_tile(acc[u], h_tile + 32 * u * 32, lane);
+            store_tile_rows_scaled(acc[u], dy_tile + 32 * u * 32, lane, gback);
+        }
+        if (l == 0) break;
+        renormalise<WT>(acc, gscale, gback);
+#pragma unroll
+        for (int u = 0; u < WT; ++u) split_tile<false>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
+#pragma unroll
+        for (int u = 0; u < WT; ++u) {
+            const float* unit = next_unit();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+            seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int WT, int VT, bool VIEWDEP>
+int launch_chain_half(const HalfChainArgs& args, hipStream_t stream) {
+    const long long blocks = (args.c.total + 127) / 128;
+    const size_t lds_bytes = sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024);  // ring + DMA dump area
+    auto kernel = mlp_backward_chain_f16x3_kernel<WT, VT, VIEWDEP>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, args);
+    return snerf::check_launch("mlp_backward(chain, f16x3)");
+}
+
+}  // namespace
+
+namespace snerf {
+
+int mlp_backward_chain_f16x3(const MlpPlan& plan, const ChainArgs& a, hipStream_t stream) {
+    HalfChainArgs args;
+    args.c = a;
+    args.half_dgrad_offset = plan.half_dgrad_offset;
+    const int key = plan.wt * 10 + plan.vt;
+    switch (key) {
+        case 84: return launch_chain_half<8, 4, true>(args, stream);
+        case 80: return launch_chain_half<8, 4, false>(args, stream);
+        case 42: return launch_chain_half<4, 2, true>(args, stream);
+        case 40: return launch_chain_half<4, 2, false>(args, stream);
+        default: return fail(SNERF_E_UNSUPPORTED, "mlp_backward(f16x3): width %d / views width %d not built", plan.width,
+                             plan.views_width);
+    }
+}
+
+}  // namespace snerf

@@ -26,6 +26,37 @@ struct MlpArgs {
     int act_rows, act_pev, act_h1, act_feature, act_hv;
 };
 
+// Arguments of the backward chain kernels (fp32: mlp_backward.hip, f16x3: mlp_backward_f16.hip)
+struct ChainArgs {
+    const float* packed;
+    const float* acts;      // saved activation tiles
+    const float* sigma;     // (M)   post-ReLU density from the forward (mask of the density ReLU)
+    const float* rgb;       // (M,3) post-sigmoid colour from the forward
+    const float* d_sigma;   // (M)
+    const float* d_rgb;     // (M,3)
+    float* grads;           // dY tiles
+    long long total;
+    int depth, width;
+    long long dgrad_offset, pts_out_w, views_out_w;
+    int act_rows, act_h1, act_hv;
+    int grad_rows, grad_feature, grad_yv, grad_head;
+};
+
+// Power-of-two factor that brings a positive magnitude into [8, 16) (1 for zero / non-finite input).  The f16x3
+// backward chain renormalises every sample's gradient vector with it before each hi/lo split: an fp16 pair only keeps
+// ~22 bits for values above 2^-2 (the lo part bottoms out at the 2^-24 subnormal step), loss gradients are 1e-5 .. 1e-10
+// and shrink or grow from layer to layer, and the chain is linear per sample -- so the factor is exact to apply and
+// exact to undo when the sample's dY values are stored.
+__host__ __device__ inline float renorm_factor(float max_abs) {
+    if (!(max_abs > 0.0f) || !(max_abs < 3.0e38f)) return 1.0f;
+    int e;
+    frexpf(max_abs, &e);             // max_abs = m * 2^e, m in [0.5, 1)
+    int shift = 4 - e;
+    if (shift > 120) shift = 120;
+    if (shift < -120) shift = -120;
+    return ldexpf(1.0f, shift);
+}
+
 // ---- [feature][32-sample] tile stores/loads of one wave block (rows in natural feature order) -------------------
 // accumulator-ordered registers: register 16u+r of lane (j, half) is feature 32u + (r&3) + 8(r>>2) + 4*half
 template <int N>

@@ -1,0 +1,239 @@
+// Device-side building blocks of the split-precision (f16x3) kernels: the LDS unit ring, the 3-MFMA segment product,
+// accumulator -> fp16 hi/lo operand conversion.  Shared by mlp_forward_f16.hip and mlp_backward_f16.hip.
+#pragma once
+#include "mlp_device.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kUnitBufFloats = 22 * 512;  // largest unit: 22 k-steps x 2 KiB (views layer of the points-aug MLP)
+constexpr int kUnitBuffers = 3;
+
+__device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform; the count must be an immediate
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// Weight stream L2 -> LDS by LDS-DMA through a ring of three unit buffers, TWO units ahead of the one being consumed:
+// at fp16 rates one tile's MFMAs (~0.65 us) are shorter than the DMA's issue-to-landing time, so a single unit of
+// run-ahead leaves the matrix pipe waiting.  A unit of k k-steps is 2k KiB-pieces (hi + lo fragment per k-step), k even,
+// so each of the 4 waves issues exactly k/2 DMA instructions per unit and can wait with a COUNTED vmcnt that leaves the
+// younger unit in flight (a plain __syncthreads() would drain it: its fence waits vmcnt(0) while LDS-DMA is pending).
+struct UnitStream {
+    const float* fetch_ptr;  // global address of the next unit to request
+    const float* stream_base;
+    float* lds;
+    int slot;                // ring slot of the unit about to be consumed
+    int lane, wave;
+
+    const float* pend_src;   // unit being requested piecewise (one DMA instruction per call of fetch_piece)
+    float* pend_dst;
+    int pend_left;           // DMA instructions this wave still has to issue for it
+    int issued;              // DMA instructions issued for the youngest requested unit (>= its piece count)
+
+    // Branch-free on purpose: a conditional here would cut the unrolled MFMA loop into basic blocks and the fragment reads
+    // could no longer be scheduled a k-step ahead.  Once the unit's pieces are all requested the same (last) piece is simply
+    // requested again -- idempotent, and it only happens where a unit has more k-step pairs than its second successor has
+    // pieces (a few times per pass).  `issued` feeds the counted vmcnt of the next acquire().
+    __device__ __forceinline__ void fetch_piece() {
+#ifdef SNERF_ABL_NODMA
+        pend_left -= pend_left > 0 ? 1 : 0;
+        return;
+#endif
+        const int adv = pend_left > 0 ? 1024 : 0;
+        pend_src += adv; pend_dst += adv;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pend_src + lane * 4),
+                                         (__attribute__((address_space(3))) void*)pend_dst, 16, 0, 0);
+        pend_left -= pend_left > 0 ? 1 : 0;
+        ++issued;
+    }
+    __device__ __forceinline__ void finish_fetch() {
+        while (pend_left > 0) fetch_piece();
+    }
+    // No further unit to request: the (branch-free) fetch_piece calls of the remaining k-steps re-read one valid KiB of
+    // the stream into a per-wave dump area instead of touching a live buffer.
+    __device__ __forceinline__ void issued_next_none() {
+        pend_src = stream_base;
+        pend_dst = lds + kUnitBuffers * kUnitBufFloats + wave * 256;  // dump: 4 KiB right after the ring
+        pend_left = 0;
+        issued = 0;
+    }
+    __device__ __forceinline__ void begin_fetch(int ksteps, int into_slot) {
+        pend_src = fetch_ptr + wave * 256 - 1024;   // fetch_piece pre-increments
+        pend_dst = lds + into_slot * kUnitBufFloats + wave * 256 - 1024;
+        pend_left = ksteps >> 1;
+        issued = 0;
+        fetch_ptr += ksteps * 512;
+    }
+    __device__ __forceinline__ void fetch(int ksteps, int into_slot) {
+        begin_fetch(ksteps, into_slot);
+        finish_fetch();
+    }
+    __device__ __forceinline__ void start(const float* first, float* lds_base, int ks0, int ks1, int lane_, int wave_) {
+        fetch_ptr = first; stream_base = first; lds = lds_base; slot = 0; lane = lane_; wave = wave_; pend_left = 0; issued = 0;
+        fetch(ks0, 0);
+        if (ks1 > 0) fetch(ks1, 1);
+        if (ks1 <= 0) issued_next_none();
+    }
+    // Unit i becomes readable.  `next` = k-steps of unit i+1 (still in flight afterwards), `next2` = k-steps of unit i+2,
+    // which is requested now into the slot unit i-1 just vacated (0 = no such unit).
+    // The request for unit i+2 is only OPENED here; its DMA instructions are issued one per two k-steps from inside the
+    // MFMA loop (fetch_piece) so that their issue cost (~60-100 cycles each) does not sit in front of the tile's MFMAs.
+    __device__ __forceinline__ const float* acquire(int next, int next2) {
+        finish_fetch();                                         // (units shorter than their successor's piece count)
+        wait_vmcnt(next > 0 ? issued : 0);                      // everything older than unit i+1's requests has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my LDS reads of unit i-1 are complete
+#ifndef SNERF_ABL_NOBARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+        const float* ready = lds + slot * kUnitBufFloats;
+        const int vacated = slot == 0 ? kUnitBuffers - 1 : slot - 1;
+        if (next2 > 0) begin_fetch(next2, vacated); else issued_next_none();
+        slot = slot == kUnitBuffers - 1 ? 0 : slot + 1;
+        return ready;
+    }
+};
+
+// Converts accumulator registers (2i, 2i+1) of a finished tile -- ReLU optional -- into the fp16 hi/lo pair they form
+// in the next layer's operand: registers 8s..8s+7 are the 8 elements of k-step s.
+template <bool RELU>
+struct TileSplitter {
+    const f32x16* src;
+    f16x8 *h0, *l0, *h1, *l1;
+    bool on;
+    __device__ __forceinline__ void step(int i) const {  // i = 0..7 (compile-time after unrolling)
+        if (!on) return;
+#ifdef SNERF_ABL_NOSPLIT
+        if (i > 0) return;
+#endif
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = 2 * i + e;
+            float v = (*src)[r];
+            if (RELU) v = fmaxf(v, 0.0f);
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            if (r < 8) { (*h0)[r] = hi; (*l0)[r] = lo; } else { (*h1)[r - 8] = hi; (*l1)[r - 8] = lo; }
+        }
+    }
+};
+
+// acc += W[tile rows, segment columns] . X over NKS k-steps; `p` walks the unit (lane offset already applied).
+// Fragments for k-step ks+1 are requested before the MFMAs of k-step ks are issued (LDS latency hides under 96 MFMA
+// cycles), and `side.step()` slots one slice of the previous tile's ReLU + hi/lo split (VALU) behind each k-step's MFMAs.
+template <int NKS, int NB, typename Side>
+__device__ __forceinline__ void seg_mfma(f32x16& acc, const float*& p, const f16x8 (&bh)[NB], const f16x8 (&bl)[NB],
+                                         const Side& side, int side_first, UnitStream& st) {
+    static_assert(NB >= NKS, "operand array too short");
+    f16x8 ah = *reinterpret_cast<const f16x8*>(p);
+    f16x8 al = *reinterpret_cast<const f16x8*>(p + 256);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        f16x8 nah = ah, nal = al;
+#ifndef SNERF_ABL_NOLDSREAD
+        if (ks + 1 < NKS) {
+            nah = *reinterpret_cast<const f16x8*>(p + (ks + 1) * 512);
+            nal = *reinterpret_cast<const f16x8*>(p + (ks + 1) * 512 + 256);
+        }
+#endif
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
+        if (side_first + ks < 8) side.step(side_first + ks);
+        if ((ks & 1) == 0) st.fetch_piece();
+        ah = nah; al = nal;
+        // Pin the issue order per k-step: the two fragment reads of the NEXT k-step, then this k-step's three MFMAs, then
+        // the VALU slice.  Left to itself the scheduler (at the 256-VGPR ceiling) serialises read -> wait -> MFMA through
+        // one register quad and exposes the LDS latency on every k-step.
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // MFMA
+        if ((ks & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (the LDS-DMA piece)
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0); // VALU
+    }
+    p += NKS * 512;
+}
+
+struct NoSide {
+    __device__ __forceinline__ void step(int) const {}
+};
+
+__device__ __forceinline__ void tile_bias(f32x16& acc, const float* __restrict__ bias, int half) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(bias + 8 * g + 4 * half);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[4 * g + q] = v[q];
+    }
+}
+
+// (ReLU and) split one finished accumulator tile into the two k-steps it feeds in the next layer.
+template <bool RELU>
+__device__ __forceinline__ void split_tile(const f32x16& acc, f16x8& h0, f16x8& l0, f16x8& h1, f16x8& l1) {
+#ifdef SNERF_ABL_NOCONVERT
+    h0[0] = (_Float16)acc[0]; l0[0] = (_Float16)acc[1]; h1[0] = (_Float16)acc[8]; l1[0] = (_Float16)acc[9];
+    return;
+#endif
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float a = acc[j], b = acc[8 + j];
+        if (RELU) { a = fmaxf(a, 0.0f); b = fmaxf(b, 0.0f); }
+        const _Float16 ah = (_Float16)a, bh = (_Float16)b;
+        h0[j] = ah; l0[j] = (_Float16)(a - (float)ah);
+        h1[j] = bh; l1[j] = (_Float16)(b - (float)bh);
+    }
+}
+
+// sum over the tile's 32 features (this lane half's 16) of w[f] * relu(acc)
+__device__ __forceinline__ float tile_dot_relu(const f32x16& acc, const float* __restrict__ w, int half) {
+    float s = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + 8 * g + 4 * half);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s = fmaf(v[q], fmaxf(acc[4 * g + q], 0.0f), s);
+    }
+    return s;
+}
+
+template <int NREG, int NKS>
+__device__ __forceinline__ void split_encoding(const float (&pe)[NREG], f16x8 (&h)[NKS], f16x8 (&l)[NKS]) {
+    static_assert(NREG == NKS * 8, "8 encoding registers per k-step");
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = pe[8 * ks + j];
+            const _Float16 hi = (_Float16)v;
+            h[ks][j] = hi;
+            l[ks][j] = (_Float16)(v - (float)hi);
+        }
+}
+
+
+// One finished accumulator tile -> rows 32u .. 32u+31 of a [feature][32-sample] fp32 tile (training: saved activations).
+template <bool RELU>
+__device__ __forceinline__ void store_tile_rows(const f32x16& acc, float* __restrict__ rows, int lane) {
+    const int j = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+        rows[f * 32 + j] = RELU ? fmaxf(acc[r], 0.0f) : acc[r];
+    }
+}
+

@@ -25,7 +25,7 @@
 #include "mlp_device.h"
 
 namespace snerf {
-int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, hipStream_t stream);  // mlp_forward_f16.hip
+int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, hipStream_t stream);  // mlp_forward_f16.hip
 }
 
 namespace {
@@ -160,8 +160,6 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     SNERF_REQUIRE(!train || saved_acts, "mlp_forward_train: saved_acts is NULL");
     if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3)
         return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: precision %d not built", precision);
-    if (train && precision != SNERF_PRECISION_FP32)
-        return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward_train: only SNERF_PRECISION_FP32 keeps activations for the backward");
     if (num_rays == 0) return SNERF_OK;
     MlpArgs a;
     a.packed = packed; a.origins = origins; a.dirs = dirs; a.view_dirs = view_dirs; a.depths = depths;
@@ -173,7 +171,7 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     a.acts = saved_acts; a.act_rows = plan.act_rows(); a.act_pev = plan.act_pev(); a.act_h1 = plan.act_h(1);
     a.act_feature = plan.act_feature(); a.act_hv = plan.act_hv();
     hipStream_t s = (hipStream_t)stream;
-    if (precision == SNERF_PRECISION_F16X3) return snerf::mlp_forward_f16x3(plan, a, s);
+    if (precision == SNERF_PRECISION_F16X3) return snerf::mlp_forward_f16x3(plan, a, train, s);
     const int key = plan.wt * 100 + plan.vt * 10 + (plan.sigma_pe ? 1 : 0);
 #define SNERF_DISPATCH(WT_, VT_, VD_, SP_) return train ? launch<WT_, VT_, VD_, SP_, true>(a, s) : launch<WT_, VT_, VD_, SP_, false>(a, s)
     switch (key) {

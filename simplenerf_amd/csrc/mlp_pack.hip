@@ -33,6 +33,14 @@ __global__ void __launch_bounds__(256) pack_segment_kernel(const float* __restri
 // hi = fp16(w), lo = fp16(w - hi) (lo may be subnormal: the MFMA honours fp16 subnormals, measured).  Element j of lane
 // (i, h) multiplies input feature  16*ks + 8*(j>>2) + 4*h + (j&3)  of an accumulator-sourced segment (the order in which
 // a 32x32 accumulator tile turns into the next B operand), or encoding register n = 8*ks + j of the lane half.
+__device__ __forceinline__ _Float16* out_ptr(float* packed, const snerf::MlpPlan::HalfStage& st) {
+    return reinterpret_cast<_Float16*>(packed + st.dst);
+}
+__device__ __forceinline__ void out_store(_Float16* out, long long base, int lane, int j, _Float16 hi, _Float16 lo) {
+    out[base + lane * 8 + j] = hi;
+    out[base + 512 + lane * 8 + j] = lo;
+}
+
 __global__ void __launch_bounds__(256) pack_half_stage_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
                                                               const float* __restrict__ w2, snerf::MlpPlan::HalfStage st,
                                                               float* __restrict__ packed) {
@@ -53,6 +61,16 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(const float* __res
         const float* w = si == 0 ? w0 : (si == 1 ? w1 : w2);
         const int h = lane >> 5, row = 32 * u + (lane & 31);
         int col = -1;
+        if (sg.transposed) {
+            // dgrad operand: tile row = IN feature, k = OUT feature in accumulator order
+            const int out = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+            float tv = 0.0f;
+            if (out < sg.out_dim && row < sg.feat_hi) tv = w[(long long)out * sg.ld + sg.col_offset + row];
+            const _Float16 thi = (_Float16)tv;
+            const long long tbase = ((long long)u * unit_ks + ks_unit) * 1024;
+            out_store(out_ptr(packed, st), tbase, lane, j, thi, (_Float16)(tv - (float)thi));
+            continue;
+        }
         if (sg.kind == snerf::SEG_ACC) {
             col = sg.col_offset + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
         } else if (sg.kind == snerf::SEG_POINTS_PE) {
@@ -68,8 +86,7 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(const float* __res
         const _Float16 lo = (_Float16)(v - (float)hi);
         // unit layout: [ks][hi: 64 lanes x 8][lo: 64 lanes x 8]  (fp16)
         const long long base = ((long long)u * unit_ks + ks_unit) * 1024;
-        out[base + lane * 8 + j] = hi;
-        out[base + 512 + lane * 8 + j] = lo;
+        out_store(out, base, lane, j, hi, lo);
     }
 }
 
@@ -106,11 +123,13 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
                                params[seg.param], seg, packed);
         }
     }
-    for (const snerf::MlpPlan::HalfStage& st : plan.half_stages) {
-        const long long total = (long long)st.tiles * (st.unit_floats / 512) * 512;
-        hipLaunchKernelGGL(pack_half_stage_kernel, dim3(snerf::stride_grid(total, 256)), dim3(256), 0, s,
-                           params[st.seg[0].param], params[st.seg[st.nseg > 1 ? 1 : 0].param],
-                           params[st.seg[st.nseg > 2 ? 2 : 0].param], st, packed);
+    for (const std::vector<snerf::MlpPlan::HalfStage>* list : {&plan.half_stages, &plan.half_dgrad_stages}) {
+        for (const snerf::MlpPlan::HalfStage& st : *list) {
+            const long long total = (long long)st.tiles * (st.unit_floats / 512) * 512;
+            hipLaunchKernelGGL(pack_half_stage_kernel, dim3(snerf::stride_grid(total, 256)), dim3(256), 0, s,
+                               params[st.seg[0].param], params[st.seg[st.nseg > 1 ? 1 : 0].param],
+                               params[st.seg[st.nseg > 2 ? 2 : 0].param], st, packed);
+        }
     }
     auto copy = [&](long long dst, const float* src, long long n) {
         if (e == hipSuccess) e = hipMemcpyAsync(packed + dst, src, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, s);

@@ -30,6 +30,8 @@ struct MlpPlan {
         int kind;                    // SEG_ACC / SEG_POINTS_PE / SEG_VIEWS_PE
         int ksteps;                  // 16-feature k-steps: 16 (width 256), 8 (width 128), 4 (point encoding), 2 (view encoding)
         int col_offset, feat_lo, feat_hi, degree;
+        int transposed;              // 1: dgrad operand W^T -- tile rows are IN features col_offset + 32u + i (< feat_hi of
+                                     //    them), k-steps run over OUT features in accumulator order
     };
     struct HalfStage {
         int tiles;                   // out tiles
@@ -40,6 +42,8 @@ struct MlpPlan {
     };
     std::vector<HalfStage> half_stages;
     long long half_offset = 0;       // start of the f16x3 stream inside the packed buffer
+    std::vector<HalfStage> half_dgrad_stages;  // W^T stream of the f16x3 backward chain (views, feature, trunk depth-1 .. 1)
+    long long half_dgrad_offset = 0;
     long long total_floats = 0;
 
     // ---- saved-activation / gradient tiles of one 32-sample wave block (backward only) -----------------------
@@ -182,14 +186,14 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
             plan.half_stages.push_back(st);
         };
         const int hk = plan.width / 16;
-        const MlpPlan::HalfSegment pe_trunk0{0, plan.pts_in, plan.width, SEG_POINTS_PE, 4, 0, 0, plan.pts_in, plan.points_degree};
+        const MlpPlan::HalfSegment pe_trunk0{0, plan.pts_in, plan.width, SEG_POINTS_PE, 4, 0, 0, plan.pts_in, plan.points_degree, 0};
         stage(plan.wt, {pe_trunk0});
         for (int l = 1; l < plan.depth; ++l) {
             const bool skip_in = (l == 5);
             const int ld = plan.width + (skip_in ? plan.pts_in : 0);
-            const MlpPlan::HalfSegment hseg{2 * l, ld, plan.width, SEG_ACC, hk, skip_in ? plan.pts_in : 0, 0, 0, 0};
+            const MlpPlan::HalfSegment hseg{2 * l, ld, plan.width, SEG_ACC, hk, skip_in ? plan.pts_in : 0, 0, 0, 0, 0};
             if (skip_in) {
-                const MlpPlan::HalfSegment pseg{2 * l, ld, plan.width, SEG_POINTS_PE, 4, 0, 0, plan.pts_in, plan.points_degree};
+                const MlpPlan::HalfSegment pseg{2 * l, ld, plan.width, SEG_POINTS_PE, 4, 0, 0, plan.pts_in, plan.points_degree, 0};
                 stage(plan.wt, {pseg, hseg});
             } else {
                 stage(plan.wt, {hseg});
@@ -198,14 +202,33 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
         if (plan.view_dependent) {
             const int pf = 2 * plan.depth + 2, pv = pf + 2;
             const int ldv = plan.width + plan.extra + plan.views_pe;
-            stage(plan.wt, {MlpPlan::HalfSegment{pf, plan.width, plan.width, SEG_ACC, hk, 0, 0, 0, 0}});
-            const MlpPlan::HalfSegment vfeat{pv, ldv, plan.views_width, SEG_ACC, hk, 0, 0, 0, 0};
-            const MlpPlan::HalfSegment vpe{pv, ldv, plan.views_width, SEG_POINTS_PE, 4, plan.width, plan.pts_in, plan.full_pe, plan.points_degree};
-            const MlpPlan::HalfSegment vview{pv, ldv, plan.views_width, SEG_VIEWS_PE, 2, plan.width + plan.extra, 0, 0, plan.views_degree};
+            stage(plan.wt, {MlpPlan::HalfSegment{pf, plan.width, plan.width, SEG_ACC, hk, 0, 0, 0, 0, 0}});
+            const MlpPlan::HalfSegment vfeat{pv, ldv, plan.views_width, SEG_ACC, hk, 0, 0, 0, 0, 0};
+            const MlpPlan::HalfSegment vpe{pv, ldv, plan.views_width, SEG_POINTS_PE, 4, plan.width, plan.pts_in, plan.full_pe, plan.points_degree, 0};
+            const MlpPlan::HalfSegment vview{pv, ldv, plan.views_width, SEG_VIEWS_PE, 2, plan.width + plan.extra, 0, 0, plan.views_degree, 0};
             if (plan.sigma_pe) stage(plan.vt, {vfeat, vpe, vview});
             else stage(plan.vt, {vfeat, vview});
         }
         hoff += 24 * 512;  // prefetch runway: one maximum-size unit of zeros
+        plan.half_dgrad_offset = hoff;
+        auto tstage = [&](int param, int ld, int out_dim, int ksteps, int col_offset) {
+            MlpPlan::HalfStage st;
+            st.tiles = plan.wt; st.nseg = 1; st.dst = hoff;
+            st.seg[0] = MlpPlan::HalfSegment{param, ld, out_dim, SEG_ACC, ksteps, col_offset, 0, plan.width, 0, 1};
+            st.unit_floats = ksteps * 512;
+            hoff += (long long)st.tiles * st.unit_floats;
+            plan.half_dgrad_stages.push_back(st);
+        };
+        if (plan.view_dependent) {
+            const int pf = 2 * plan.depth + 2, pv = pf + 2;
+            tstage(pv, plan.width + plan.extra + plan.views_pe, plan.views_width, plan.views_width / 16, 0);
+            tstage(pf, plan.width, plan.width, hk, 0);
+        }
+        for (int l = plan.depth - 1; l >= 1; --l) {
+            const bool skip_in = (l == 5);
+            tstage(2 * l, plan.width + (skip_in ? plan.pts_in : 0), plan.width, hk, skip_in ? plan.pts_in : 0);
+        }
+        hoff += 24 * 512;
         off = hoff;
     }
     plan.total_floats = (off + 63) / 64 * 64;

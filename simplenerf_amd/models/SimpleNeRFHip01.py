@@ -8,8 +8,8 @@ sites (src/Trainer01.py:93,194,328; src/Tester01.py:63) work unchanged.  All ari
 the parameters.  There is no eager/CPU fallback: CPU tensors or an unbuilt library raise.
 
 One extra, optional config key: ``configs['model']['hip_precision']`` = ``'fp32'`` (default; fp32 matrix cores) or
-``'f16x3'`` (fp16 hi/lo split, three MFMAs per product, fp32 accumulate: fp32-grade results ~3x faster; used for
-no-grad forwards -- gradient-carrying forwards always run the fp32 kernels, which keep the activations).
+``'f16x3'`` (fp16 hi/lo split, three MFMAs per product, fp32 accumulate: fp32-grade results ~2.5x faster; covers the
+forward, the activation-keeping training forward and the backward dgrad chain -- weight-gradient products stay fp32).
 
 Differences from the reference that a caller can observe:
   * ``model.chunk`` / ``model.netchunk`` are accepted and ignored -- the kernels tile the work themselves and the
@@ -90,10 +90,10 @@ class _ShadeFunction(torch.autograd.Function):
     COMPOSITE_KEYS = ('rgb', 'acc', 'alpha', 'visibility', 'weights', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc')
 
     @staticmethod
-    def forward(ctx, packed, ndc, white, march_o, march_d, view_dirs, depths, noise, rays_o, rays_d, *params):
-        sigma, rgb, saved = packed.forward_train(march_o, march_d, view_dirs, depths, noise)
+    def forward(ctx, packed, precision, ndc, white, march_o, march_d, view_dirs, depths, noise, rays_o, rays_d, *params):
+        sigma, rgb, saved = packed.forward_train(march_o, march_d, view_dirs, depths, noise, precision)
         comp = ops.composite(sigma, rgb, depths, march_d, ndc, white, rays_o, rays_d)
-        ctx.packed, ctx.ndc, ctx.white = packed, ndc, white
+        ctx.packed, ctx.ndc, ctx.white, ctx.precision = packed, ndc, white, precision
         ctx.param_shapes = [tuple(p.shape) for p in params]
         ctx.save_for_backward(sigma, rgb, saved, depths, march_d, rays_o, rays_d)
         outs = [comp.get(k) for k in _ShadeFunction.COMPOSITE_KEYS if k in comp]
@@ -113,8 +113,8 @@ class _ShadeFunction(torch.autograd.Function):
             d_sigma = d_sigma + g['sigma'].reshape(d_sigma.shape)
         if g.get('rgb_raw') is not None:
             d_rgb = d_rgb + g['rgb_raw']
-        grads = ctx.packed.backward(saved, sigma, rgb, d_sigma, d_rgb, ctx.param_shapes)
-        return (None,) * 10 + tuple(grads)
+        grads = ctx.packed.backward(saved, sigma, rgb, d_sigma, d_rgb, ctx.param_shapes, ctx.precision)
+        return (None,) * 11 + tuple(grads)
 
 
 class SimpleNeRFHip(torch.nn.Module):
@@ -208,7 +208,7 @@ class SimpleNeRFHip(torch.nn.Module):
             packed = self._packed_mlp(name)
             noise = draw(noise_key, (n, s, 1), True)
             if with_grad:
-                res = _ShadeFunction.apply(packed, self.ndc, bool(mcfg['white_bkgd']), march_o, march_d, view_dirs, depths,
+                res = _ShadeFunction.apply(packed, self.precision, self.ndc, bool(mcfg['white_bkgd']), march_o, march_d, view_dirs, depths,
                                            noise, rays_o, rays_d, *getattr(self, name).abi_params())
                 keys = [k for k in _ShadeFunction.COMPOSITE_KEYS if self.ndc or not k.endswith('_ndc')]
                 comp = dict(zip(keys, res[:len(keys)]))

@@ -160,7 +160,7 @@ class PackedMlp:
 
     # ---- training ------------------------------------------------------------------------------------------
     def forward_train(self, origins: Tensor, dirs: Tensor, view_dirs: Optional[Tensor], depths: Tensor,
-                      sigma_noise: Optional[Tensor] = None):
+                      sigma_noise: Optional[Tensor] = None, precision: int = 0):
         """Forward that also keeps every layer's input for backward().  -> sigma (n,S,1), rgb (n,S,3), saved"""
         lib = _lib.load()
         n, s = depths.shape
@@ -185,7 +185,7 @@ class PackedMlp:
                 t0.record()
             st = lib.snerf_mlp_forward_train(ctypes.byref(self.desc), _ptr(self.buffer), _ptr(origins), _ptr(dirs),
                                              _ptr(view_dirs), _ptr(depths), n, s, _ptr(sigma_noise), _ptr(sigma), _ptr(rgb),
-                                             _ptr(saved), 0, _stream())
+                                             _ptr(saved), int(precision), _stream())
             if log is not None:
                 t1.record()
                 log.append((t0, t1, n * s))
@@ -193,7 +193,7 @@ class PackedMlp:
         return sigma, rgb, saved
 
     def backward(self, saved: Tensor, sigma: Tensor, rgb: Tensor, d_sigma: Tensor, d_rgb: Tensor,
-                 param_shapes: List[tuple]) -> List[Tensor]:
+                 param_shapes: List[tuple], precision: int = 0) -> List[Tensor]:
         """dL/dparam for every parameter (C-ABI order), given dL/dsigma (n,S[,1]) and dL/drgb (n,S,3)."""
         lib = _lib.load()
         n, s = sigma.shape[0], sigma.shape[1]
@@ -212,7 +212,8 @@ class PackedMlp:
         arr = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
         with torch.cuda.device(dev):
             st = lib.snerf_mlp_backward(ctypes.byref(self.desc), _ptr(self.buffer), _ptr(saved), _ptr(sigma), _ptr(rgb),
-                                        _ptr(d_sigma), _ptr(d_rgb), n, s, _ptr(work), arr, len(grads), _stream())
+                                        _ptr(d_sigma), _ptr(d_rgb), n, s, _ptr(work), arr, len(grads), int(precision),
+                                        _stream())
         _lib.check(st, 'snerf_mlp_backward')
         return grads
 

@@ -18,6 +18,21 @@ DEV = 'cuda:0'
 GRAD_TOL = 1e-3
 
 
+def rel_l2(got, ref):
+    ref = ref.detach().cpu().double()
+    got = got.detach().cpu().double()
+    return float((got - ref).norm() / max(float(ref.norm()), 1e-30))
+
+
+# The f16x3 kernels reproduce every activation to ~1e-6 relative instead of ~1e-7.  d relu/dx is discontinuous, so the few
+# (sample, unit) pairs whose pre-activation lies within that distance of 0 get a different mask than the CPU evaluation.
+# With the spiky gradients of a dense field (a handful of surface samples per ray carry the loss) one flipped pair on
+# such a sample moves entries of the early layers' gradients by several percent of the tensor's largest entry.  The
+# arithmetic itself is gated separately and tightly: test_f16x3_chain_arithmetic_with_identical_masks (<= 1e-4) and the
+# forward's activations (<= 1e-5 of the fp32 kernel's).  Hence the loose end-to-end bounds for f16x3:
+F16_TOL_MAX, F16_TOL_L2 = 1e-1, 6e-2
+
+
 def rel_to_max(got, ref):
     ref = ref.detach().cpu().double()
     got = got.detach().cpu().double()
@@ -63,7 +78,8 @@ def test_composite_backward_matches_autograd(ndc, white, s):
 # ---------------------------------------------------------------- K7
 @pytest.mark.parametrize('layout', ['main', 'ptsaug', 'viewsaug'])
 @pytest.mark.parametrize('size', [(8, 256, 128), (4, 128, 64)])
-def test_mlp_backward_matches_autograd(layout, size):
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+def test_mlp_backward_matches_autograd(layout, size, precision):
     depth, width, vwidth = size
     cfg = synth.mlp_config(64, depth=depth, width=width, views_width=vwidth, **LAYOUTS[layout])
     sd = synth.synth_state_dict(util.mlp_param_shapes(cfg), 31, 50.0, 1.0)
@@ -84,22 +100,60 @@ def test_mlp_backward_matches_autograd(layout, size):
     plist = abi_param_list(dev_params)
     mlp = ops.PackedMlp(cfg, DEV)
     mlp.pack(plist)
-    sigma, rgb, saved = mlp.forward_train(o.to(DEV), dd.to(DEV), v.to(DEV), z.to(DEV), noise.to(DEV))
+    prec = ops.PRECISIONS[precision]
+    sigma, rgb, saved = mlp.forward_train(o.to(DEV), dd.to(DEV), v.to(DEV), z.to(DEV), noise.to(DEV), prec)
     assert util.rel_linf(sigma, ref['sigma']) < 1e-5 and util.linf(rgb, ref['rgb']) < 1e-5
-    grads = mlp.backward(saved, sigma, rgb, g_sigma.to(DEV), g_rgb.to(DEV), [tuple(p.shape) for p in plist])
+    grads = mlp.backward(saved, sigma, rgb, g_sigma.to(DEV), g_rgb.to(DEV), [tuple(p.shape) for p in plist], prec)
     names = [k for k in abi_param_list({k: k for k in sd})]
-    worst = {}
+    bad = {}
     for name, got in zip(names, grads):
-        worst[name] = rel_to_max(got, params[name].grad)
-    bad = {k: e for k, e in worst.items() if not e < GRAD_TOL}
+        e_max, e_l2 = rel_to_max(got, params[name].grad), rel_l2(got, params[name].grad)
+        ok = e_max < GRAD_TOL if precision == 'fp32' else (e_max < F16_TOL_MAX and e_l2 < F16_TOL_L2)
+        if not ok:
+            bad[name] = (e_max, e_l2)
     assert not bad, bad
+
+
+def test_f16x3_chain_arithmetic_with_identical_masks():
+    """The f16x3 backward chain against the fp32 chain on the SAME saved activations (identical ReLU masks), with
+    gradients spanning many orders of magnitude between samples and scaled down to 1e-9: what remains is pure
+    arithmetic (fp16 hi/lo split with per-sample power-of-two scaling) and must be fp32-grade.  Also: the f16x3
+    training forward saves the same activations as the fp32 one."""
+    cfg = synth.mlp_config(64)
+    sd = synth.synth_state_dict(util.mlp_param_shapes(cfg), 31, 50.0, 1.0)
+    plist = abi_param_list({k: torch.from_numpy(v).to(DEV) for k, v in sd.items()})
+    shapes = [tuple(p.shape) for p in plist]
+    mlp = ops.PackedMlp(cfg, DEV)
+    mlp.pack(plist)
+    rng = numpy.random.RandomState(0)
+    n, s = 64, 192
+    o = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(numpy.float32)).to(DEV)
+    d = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(numpy.float32)).to(DEV)
+    v = d / d.norm(dim=1, keepdim=True)
+    z = torch.sort(torch.from_numpy(rng.uniform(0, 1, (n, s)).astype(numpy.float32)).to(DEV), 1)[0]
+    sigma, rgb, saved = mlp.forward_train(o, d, v, z, None, ops.PRECISION_FP32)
+    sigma16, rgb16, saved16 = mlp.forward_train(o, d, v, z, None, ops.PRECISION_F16X3)
+    rows = saved.numel() // (((n * s + 127) // 128) * 4 * 32)
+    a, b = saved.reshape(-1, rows, 32), saved16.reshape(-1, rows, 32)
+    for r0, r1 in ((0, 63), (64, 91), (96, rows)):  # encodings, view encodings, every layer's activations (pads excluded)
+        assert float((a[:, r0:r1] - b[:, r0:r1]).abs().max()) <= 1e-5 * max(1.0, float(a[:, r0:r1].abs().max()))
+    assert util.rel_linf(sigma16, sigma) < 1e-5 and util.linf(rgb16, rgb) < 1e-5
+    for scale in (1.0, 1e-6, 1e-9):
+        spread = numpy.exp(4 * rng.standard_normal((n, s, 1)))
+        gs = torch.from_numpy((rng.standard_normal((n, s, 1)) * spread * scale).astype(numpy.float32)).to(DEV)
+        gr = torch.from_numpy((rng.standard_normal((n, s, 3)) * spread * scale).astype(numpy.float32)).to(DEV)
+        ref = mlp.backward(saved, sigma, rgb, gs, gr, shapes, ops.PRECISION_FP32)
+        got = mlp.backward(saved, sigma, rgb, gs, gr, shapes, ops.PRECISION_F16X3)
+        for g_, r_ in zip(got, ref):
+            assert rel_to_max(g_, r_) < 1e-4 and rel_l2(g_, r_) < 1e-4, scale
 
 
 # ---------------------------------------------------------------- whole model
 @pytest.mark.parametrize('kind,profile', [('config3', 'consistent'), ('config2', 'consistent'), ('headline_world', 'dense'),
                                           ('config1', 'dense')])
 @pytest.mark.parametrize('fine_depths', ['own', 'oracle'])
-def test_model_gradients_match_reference(kind, profile, fine_depths):
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+def test_model_gradients_match_reference(kind, profile, fine_depths, precision):
     """loss.backward() through the drop-in model vs (a) autograd through the oracle, every element, and (b) the
     reference's own gradients (strided sample in fixture G7).
 
@@ -113,7 +167,7 @@ def test_model_gradients_match_reference(kind, profile, fine_depths):
     ref_out = oracle.render(params, cfg, util.golden_batch(g), training=True)
     util.grad_loss(ref_out).backward()
 
-    model = get_model(cfg, None)
+    model = get_model(synth.with_overrides(cfg, hip_precision=precision), None)
     model.load_state_dict(util.golden_params(cfg, g))
     model = model.to(DEV).train()
     batch = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
@@ -129,16 +183,17 @@ def test_model_gradients_match_reference(kind, profile, fine_depths):
     for name, p in model.named_parameters():
         assert p.grad is not None, name
         fine = name.startswith('fine_model.')
-        tol = 5e-2 if (fine_depths == 'own' and fine) else 2 * GRAD_TOL
+        tol = 5e-2 if (fine_depths == 'own' and fine) else (2 * GRAD_TOL if precision == 'fp32' else F16_TOL_MAX)
         # the fixture was produced on the build container's CPU; the reference's fine depths are not reproducible
         # across CPUs/BLAS builds either (same discontinuity), so its FINE-model gradients are only loosely comparable
-        tol_ref = 5e-2 if fine else 2 * GRAD_TOL
+        tol_ref = 5e-2 if fine else (2 * GRAD_TOL if precision == 'fp32' else F16_TOL_MAX)
         err = rel_to_max(p.grad, params[name].grad)
         sample = p.grad.reshape(-1)[::util.GRAD_SAMPLE_STRIDE].cpu().double().numpy()
         ref = g[f'gradsample_{name}'].astype(numpy.float64)
         err_ref = float(numpy.abs(sample - ref).max() / max(float(params[name].grad.abs().max()), 1e-30))
-        if not (err < tol and err_ref < tol_ref):
-            bad[name] = (err, err_ref, tol, tol_ref)
+        l2_ok = precision == 'fp32' or (fine and fine_depths == 'own') or rel_l2(p.grad, params[name].grad) < F16_TOL_L2
+        if not (err < tol and err_ref < tol_ref and l2_ok):
+            bad[name] = (err, err_ref, tol, tol_ref, rel_l2(p.grad, params[name].grad))
     assert not bad, bad
 
 

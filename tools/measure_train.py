@@ -30,7 +30,7 @@ def loss_fn(out):
 
 def main():
     cfg = synth.make_configs('config3')
-    model = get_model(cfg, None)
+    model = get_model(synth.with_overrides(cfg, hip_precision=os.environ.get("SNERF_PREC", "fp32")), None)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
     model = model.to(DEV).train()
