@@ -150,7 +150,38 @@ struct WgradJob {
     long long bias_off;                 //                                  [chunk][out_tiles*32]
     int w_param, w_ld, w_col;           // destination: grad of params[w_param] (out_rows x w_ld), columns from w_col
     int b_param;                        // bias destination or -1
+    int half;                           // 1: computed by the f16x3 kernel with dY scaled by wgrad_scale(max of its region)
 };
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// One power-of-two scale per dY region for the f16x3 weight-gradient product (the contraction runs over the samples, so a
+// per-sample factor cannot be pulled out): max |dY| -> [2^9, 2^10).  Samples whose gradients are < 6e-11 of the largest
+// one underflow the fp16 pair; their contribution is below fp32 rounding of the sum anyway.
+__host__ __device__ inline float wgrad_scale(float max_abs) {
+    if (!(max_abs > 0.0f) || !(max_abs < 3.0e38f)) return 1.0f;
+    int e;
+    frexpf(max_abs, &e);
+    int shift = 10 - e;
+    if (shift > 120) shift = 120;
+    if (shift < -120) shift = -120;
+    return ldexpf(1.0f, shift);
+}
+
+// 8 consecutive samples of one tile row (two swizzled 16-byte chunks) -> fp16 hi/lo fragments; `k` scales (dY) or is 1 (X)
+__device__ __forceinline__ void split_fragment(const float* __restrict__ row, int c0, int swz, float k, f16x8& hi, f16x8& lo,
+                                               float& sum) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(row + ((c0 ^ swz) << 2));
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + (((c0 + 1) ^ swz) << 2));
+    sum += (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = v0[j] * k, b = v1[j] * k;
+        const _Float16 ah = (_Float16)a, bh = (_Float16)b;
+        hi[j] = ah; lo[j] = (_Float16)(a - (float)ah);
+        hi[4 + j] = bh; lo[4 + j] = (_Float16)(b - (float)bh);
+    }
+}
 
 constexpr int kMaxJobs = 16;
 struct JobTable {
@@ -164,7 +195,7 @@ struct GradPointers {
 
 // Per-wave register tile of the weight-gradient kernel: NO x NI accumulator tiles of 32x32.  The 4 waves of a workgroup
 // form a (WO x WI) grid over the job's (out_tiles x in_tiles) product, WO = out_tiles / NO, WI = in_tiles / NI.
-template <int NO, int NI>
+template <int NO, int NI, bool F16>
 __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const float* __restrict__ grads,
                                                        const float* __restrict__ acts, float* __restrict__ partial,
                                                        const float* __restrict__ zeros) {
@@ -227,7 +258,29 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
         __syncthreads();  // block b has landed for every wave, and every wave is done reading the other buffer
         const float* cur = lds + ((b - b0) & 1) * buf_floats;
         if (b + 1 < b1) stage(b + 1, lds + ((b - b0 + 1) & 1) * buf_floats);
-        if (active) {
+        if (active && F16) {
+            // fp16-split product: two k-steps of 16 samples; dY scaled by one power of two per region (wgrad_scale)
+            const float gk = wgrad_scale(__uint_as_float(reinterpret_cast<const unsigned*>(zeros)[64 + job.dy_row0 / 32]));
+#pragma unroll 1
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c0 = 4 * kk + 2 * half;
+                f16x8 ah[NO], al[NO], bh[NI], bl[NI];
+                float unused = 0.0f;
+#pragma unroll
+                for (int oo = 0; oo < NO; ++oo) split_fragment(cur + a_base + oo * 1024 + row_off, c0, swz, gk, ah[oo], al[oo], bsum[oo]);
+#pragma unroll
+                for (int ii = 0; ii < NI; ++ii) split_fragment(cur + b_base + ii * 1024 + row_off, c0, swz, 1.0f, bh[ii], bl[ii], unused);
+#pragma unroll
+                for (int oo = 0; oo < NO; ++oo)
+#pragma unroll
+                    for (int ii = 0; ii < NI; ++ii) {
+                        acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[oo], bh[ii], acc[oo][ii], 0, 0, 0);
+                        acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[oo], bl[ii], acc[oo][ii], 0, 0, 0);
+                        acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[oo], bh[ii], acc[oo][ii], 0, 0, 0);
+                    }
+            }
+        }
+        if (active && !F16) {
             // one 8-sample group at a time (not unrolled): keeps the live fragment registers at 4*(NO+NI) so that nothing
             // spills -- a scratch reload inside this loop would force vmcnt(0) and drain the prefetch DMA issued above
 #pragma unroll 1
@@ -278,6 +331,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
 // B3: fixed-order sum over chunks, scattered into the reference-layout gradient tensors
 __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float* __restrict__ partial, GradPointers ptrs) {
     const WgradJob& job = table.jobs[blockIdx.y];
+    const float unscale =
+        job.half ? 1.0f / wgrad_scale(__uint_as_float(reinterpret_cast<const unsigned*>(partial)[64 + job.dy_row0 / 32])) : 1.0f;
     float* __restrict__ grad_w = ptrs.p[job.w_param];
     float* __restrict__ grad_b = job.b_param >= 0 ? ptrs.p[job.b_param] : nullptr;
     const int in_cols = job.in_tiles * 32, rows_dy = job.out_tiles * 32;
@@ -290,7 +345,7 @@ __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float
             const float* p = partial + job.partial_off + (long long)o * in_cols + i;
             float s = 0.0f;
             for (int c = 0; c < job.chunks; ++c) s += p[(long long)c * rows_dy * in_cols];
-            grad_w[(long long)o * job.w_ld + job.w_col + i] = s;
+            grad_w[(long long)o * job.w_ld + job.w_col + i] = s * unscale;
         } else {
             const int o = (int)(idx - nw);
             const float* p = partial + job.bias_off + o;
@@ -310,7 +365,7 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples) {
     Workspace w;
     const long long blocks = (total_samples + 127) / 128 * 4;
     w.grads_floats = blocks * p.grad_rows() * 32;
-    long long off = 64;  // [0, 64): zero page for padded rows
+    long long off = 192;  // [0, 64): zero page for padded rows; [64, 192): per-region max |dY| words (f16x3)
     auto add = [&](int dy_row0, int out_rows, int x_row0, int in_rows, int w_param, int w_ld, int w_col, int b_param) {
         WgradJob j;
         j.dy_row0 = dy_row0; j.out_rows = out_rows; j.out_tiles = (out_rows + 31) / 32;
@@ -331,7 +386,7 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples) {
         off += chunks * j.out_tiles * 32 * j.in_tiles * 32;
         j.bias_off = off;
         off += chunks * j.out_tiles * 32;
-        j.w_param = w_param; j.w_ld = w_ld; j.w_col = w_col; j.b_param = b_param;
+        j.w_param = w_param; j.w_ld = w_ld; j.w_col = w_col; j.b_param = b_param; j.half = 0;
         w.jobs.push_back(j);
     };
     const int d = p.depth, wd = p.width;
@@ -380,7 +435,7 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
     return snerf::check_launch("mlp_backward(chain)");
 }
 
-template <int NO, int NI>
+template <int NO, int NI, bool F16 = false>
 int launch_wgrad(const JobTable& table, const float* grads, const float* acts, float* partial, const float* zeros,
                  hipStream_t stream) {
     int max_rows = 0;
@@ -389,7 +444,7 @@ int launch_wgrad(const JobTable& table, const float* grads, const float* acts, f
         if (r > max_rows) max_rows = r;
     }
     const size_t lds_bytes = 2 * sizeof(float) * 32 * (size_t)max_rows;  // double-buffered [rows][32 samples]
-    auto kernel = wgrad_kernel<NO, NI>;
+    auto kernel = wgrad_kernel<NO, NI, F16>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -447,12 +502,14 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     a.act_rows = plan.act_rows(); a.act_h1 = plan.act_h(1); a.act_hv = plan.act_hv();
     a.grad_rows = plan.grad_rows(); a.grad_feature = plan.grad_feature(); a.grad_yv = plan.grad_yv();
     a.grad_head = plan.grad_head();
-    // partial[0..64): zero page for padded staging rows
-    hipError_t he = hipMemsetAsync(partial, 0, 64 * sizeof(float), s);
+    // partial[0..64): zero page for padded staging rows; partial[64..192): per-region max |dY| (f16x3)
+    hipError_t he = hipMemsetAsync(partial, 0, 192 * sizeof(float), s);
     if (he != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: memset: %s", hipGetErrorString(he));
     int rc;
     const int key = precision == SNERF_PRECISION_F16X3 ? -1 : plan.wt * 10 + plan.vt;
+    a.dy_max = nullptr;
     if (precision == SNERF_PRECISION_F16X3) {
+        a.dy_max = reinterpret_cast<unsigned*>(partial) + 64;
         rc = snerf::mlp_backward_chain_f16x3(plan, a, s);
         if (rc != SNERF_OK) return rc;
     }
@@ -467,15 +524,23 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     }
     if (rc != SNERF_OK) return rc;
     if ((int)ws.jobs.size() > kMaxJobs) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many weight-gradient jobs");
+    // f16x3: the large products (8 in-tiles wide) run on the fp16 pipe with one power-of-two scale per dY region; the
+    // small head/encoding products are DMA-bound and stay on the fp32 kernel
+    std::vector<WgradJob> jobs = ws.jobs;
+    for (WgradJob& job : jobs) {
+        int no, ni;
+        wave_tile(job, &no, &ni);
+        job.half = (precision == SNERF_PRECISION_F16X3 && ni == 8) ? 1 : 0;
+    }
     // (the zero page and the gradient-max word were cleared before the chain kernel)
     JobTable table;  // all jobs, for the reduction
-    table.count = (int)ws.jobs.size();
+    table.count = (int)jobs.size();
     table.wg_start[0] = 0;
     long long max_work = 0;
     for (int j = 0; j < table.count; ++j) {
-        table.jobs[j] = ws.jobs[j];
-        table.wg_start[j + 1] = table.wg_start[j] + ws.jobs[j].chunks;
-        const long long work = (long long)ws.jobs[j].out_rows * ws.jobs[j].in_rows + ws.jobs[j].out_rows;
+        table.jobs[j] = jobs[j];
+        table.wg_start[j + 1] = table.wg_start[j] + jobs[j].chunks;
+        const long long work = (long long)jobs[j].out_rows * jobs[j].in_rows + jobs[j].out_rows;
         if (work > max_work) max_work = work;
     }
     static const int classes[][2] = {{2, 8}, {2, 2}, {2, 1}, {1, 8}, {1, 4}, {1, 2}, {1, 1}};
@@ -483,7 +548,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
         JobTable sub;
         sub.count = 0;
         sub.wg_start[0] = 0;
-        for (const WgradJob& job : ws.jobs) {
+        for (const WgradJob& job : jobs) {
             int no, ni;
             wave_tile(job, &no, &ni);
             if (no != cls[0] || ni != cls[1]) continue;
@@ -492,7 +557,10 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
             ++sub.count;
         }
         if (sub.count == 0) continue;
-        if (cls[0] == 2 && cls[1] == 8) rc = launch_wgrad<2, 8>(sub, grads, saved_acts, partial, partial, s);
+        const bool f16 = precision == SNERF_PRECISION_F16X3;
+        if (cls[0] == 2 && cls[1] == 8 && f16) rc = launch_wgrad<2, 8, true>(sub, grads, saved_acts, partial, partial, s);
+        else if (cls[0] == 1 && cls[1] == 8 && f16) rc = launch_wgrad<1, 8, true>(sub, grads, saved_acts, partial, partial, s);
+        else if (cls[0] == 2 && cls[1] == 8) rc = launch_wgrad<2, 8>(sub, grads, saved_acts, partial, partial, s);
         else if (cls[0] == 2 && cls[1] == 2) rc = launch_wgrad<2, 2>(sub, grads, saved_acts, partial, partial, s);
         else if (cls[0] == 2 && cls[1] == 1) rc = launch_wgrad<2, 1>(sub, grads, saved_acts, partial, partial, s);
         else if (cls[0] == 1 && cls[1] == 8) rc = launch_wgrad<1, 8>(sub, grads, saved_acts, partial, partial, s);

@@ -29,14 +29,29 @@ __device__ __forceinline__ void store_tile_rows_scaled(const f32x16& acc, float*
 }
 
 // Rescale this sample's gradient vector (U tiles of this lane + the partner lane half) to a maximum in [8, 16).
+// max over the wave of a non-negative value -> atomicMax into the region's word (non-negative floats order like their bits)
+__device__ __forceinline__ void publish_max(unsigned* word, float v, int lane) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    if (lane == 0 && v > 0.0f) atomicMax(word, __float_as_uint(v));
+}
+
 template <int U>
-__device__ __forceinline__ void renormalise(f32x16 (&acc)[U], float& gscale, float& gback) {
+__device__ __forceinline__ float tiles_max(const f32x16 (&acc)[U]) {
     float m = 0.0f;
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[u][r]));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    return fmaxf(m, __shfl_xor(m, 32, 64));
+}
+
+// `region_max` (may be null): receives max |dY| of the region just stored, in UNSCALED units, for the f16x3 weight-gradient
+// kernel, which has to pick one power-of-two scale per dY region (its contraction runs over the samples).
+template <int U>
+__device__ __forceinline__ void renormalise(f32x16 (&acc)[U], float& gscale, float& gback, unsigned* region_max, int lane) {
+    const float m = tiles_max<U>(acc);
+    if (region_max) publish_max(region_max, m * gback, lane);
     float f = renorm_factor(m);
     // keep the cumulative factor (and its reciprocal) finite: a sample whose gradient underflows to ~1e-38 simply
     // stops being rescaled -- its contribution is nil anyway
@@ -137,7 +152,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
             mask_tile(dyv, hv_tile + 32 * u * 32, lane);
             store_tile_rows_scaled(dyv, grads + (a.grad_yv + 32 * u) * 32, lane, gback);
         }
-        renormalise<VT>(dyvs, gscale, gback);
+        renormalise<VT>(dyvs, gscale, gback, a.dy_max ? a.dy_max + a.grad_yv / 32 : nullptr, lane);
 #pragma unroll
         for (int u = 0; u < VT; ++u) split_tile<false>(dyvs[u], vh[2 * u], vl[2 * u], vh[2 * u + 1], vl[2 * u + 1]);
         // d feature = Wv[:, :width]^T dYv
@@ -149,7 +164,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
             seg_mfma<VK>(acc[u], unit, vh, vl, none, 8, st);
             store_tile_rows_scaled(acc[u], grads + (a.grad_feature + 32 * u) * 32, lane, gback);
         }
-        renormalise<WT>(acc, gscale, gback);
+        renormalise<WT>(acc, gscale, gback, a.dy_max ? a.dy_max + a.grad_feature / 32 : nullptr, lane);
 #pragma unroll
         for (int u = 0; u < WT; ++u) split_tile<false>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
         // d h_depth = W_feature^T dfeature
@@ -193,8 +208,12 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
             mask_tile(acc[u], h_tile + 32 * u * 32, lane);
             store_tile_rows_scaled(acc[u], dy_tile + 32 * u * 32, lane, gback);
         }
-        if (l == 0) break;
-        renormalise<WT>(acc, gscale, gback);
+        unsigned* region = a.dy_max ? a.dy_max + (l * a.width) / 32 : nullptr;
+        if (l == 0) {
+            if (region) publish_max(region, tiles_max<WT>(acc) * gback, lane);
+            break;
+        }
+        renormalise<WT>(acc, gscale, gback, region, lane);
 #pragma unroll
         for (int u = 0; u < WT; ++u) split_tile<false>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
 #pragma unroll

@@ -40,6 +40,7 @@ struct ChainArgs {
     long long dgrad_offset, pts_out_w, views_out_w;
     int act_rows, act_h1, act_hv;
     int grad_rows, grad_feature, grad_yv, grad_head;
+    unsigned* dy_max;  // f16x3: per dY region (index = first tile row / 32) the max |dY| over the call, as float bits
 };
 
 // Power-of-two factor that brings a positive magnitude into [8, 16) (1 for zero / non-finite input).  The f16x3
