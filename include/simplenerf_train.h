@@ -1,0 +1,87 @@
+/*
+ * simplenerf_train.h -- C ABI of the training-step pieces either side of the ray-marching path (SURVEY 8f "next"
+ * rows): loss evaluation (f1), batch assembly and random draws (f2), the optimiser update (f4).  Same conventions as
+ * simplenerf_hip.h: device pointers to contiguous arrays in the reference's layouts, calls only enqueue on `stream`,
+ * 0 / negative snerf_status return, no CPU fallback.
+ */
+#ifndef SIMPLENERF_TRAIN_H
+#define SIMPLENERF_TRAIN_H
+
+#include "simplenerf_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * L1  fused loss evaluation.  One launch evaluates every masked mean-squared-error term of a training step and one
+ * launch writes every gradient.  Replaces, per term:
+ *   MSE.compute_mse                       (src/loss_functions/MSE01.py:57-67; MSE02/MSE03 identical)
+ *   SparseDepthMSE.compute_depth_loss     (src/loss_functions/SparseDepthMSE01.py:58-71; 02/03 identical)
+ *   ...DepthLoss.compute_depth_mse        (src/loss_functions/PointsAugmentationDepthLoss02.py:196-212)
+ *   CoarseFineConsistencyLoss.compute_loss_sd (src/loss_functions/CoarseFineConsistencyLoss02.py:174-189)
+ * and the weighted sum of LossComputer.compute_losses (src/loss_functions/LossComputer01.py:40-52).
+ *
+ *   term value  = sum over rays with numerator_mask of sum_c (pred - target)^2  /  (channels * #rays with
+ *                 denominator_mask);  0 when the denominator count is 0 (the reference's `if numel() > 0 else 0`)
+ *   numerator_mask == denominator_mask for the plain masked MSE; the patch-consistency depth terms average over all
+ *   pixel rays but only count the rays the decision mask keeps (the reference zeroes the others, then takes the mean).
+ *   `target` never receives a gradient (the reference detaches it or it is data).
+ */
+#define SNERF_LOSS_MAX_TERMS 16
+#define SNERF_LOSS_MAX_GROUPS 16
+
+typedef struct snerf_loss_term {
+    const float* pred;                     /* device (num_rays, channels) */
+    const float* target;                   /* device (num_rays, channels) */
+    const unsigned char* numerator_mask;   /* device (num_rays) 0/1 bytes, or NULL = every ray */
+    const unsigned char* denominator_mask; /* device (num_rays) 0/1 bytes, or NULL = every ray */
+    float* d_pred;                         /* backward only: device (num_rays, channels) gradient buffer */
+    int channels;                          /* 1 (depth) or 3 (colour) */
+    int group;                             /* which loss (LossComputer entry) the term belongs to, 0 <= group < num_groups */
+    int accumulate;                        /* backward only: 1 = add to d_pred (an earlier term of the table wrote it) */
+    float weight;                          /* the loss weight of LossComputer.get_loss_weight for this iteration */
+} snerf_loss_term;
+
+/* Bytes of device scratch snerf_loss_forward needs (partial sums + a completion counter that must be zero on first
+ * use; the kernel leaves it zero again). */
+long long snerf_loss_workspace_bytes(void);
+
+/* values  device (num_terms + num_groups + 1): [0,T) term values, [T,T+G) per-loss sums of their terms (what the
+ *         reference reports as loss_value per loss name), [T+G] = sum_t weight_t * value_t (TotalLoss)
+ * scales  device (num_terms): 2 / (channels * count), 0 for an empty term -- consumed by snerf_loss_backward */
+int snerf_loss_forward(const snerf_loss_term* terms, int num_terms, int num_groups, long long num_rays, float* values,
+                       float* scales, void* workspace, snerf_stream_t stream);
+
+/* upstream  device (num_terms + num_groups + 1): gradient of the caller's scalar with respect to `values` (all zero
+ *           except a 1 at [T+G] when the caller back-propagates TotalLoss).
+ * Writes d_pred of every term:  (upstream[t] + upstream[T+group] + upstream[T+G]*weight) * scale * (pred - target)
+ * on the numerator-masked rays, 0 elsewhere; terms with accumulate=1 add to what an earlier term wrote. */
+int snerf_loss_backward(const snerf_loss_term* terms, int num_terms, int num_groups, long long num_rays,
+                        const float* scales, const float* upstream, snerf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * L2  patch-reprojection decision masks.  Replaces the decision part of compute_loss_nerf
+ * (src/loss_functions/PointsAugmentationDepthLoss02.py:119-169; ViewsAugmentationDepthLoss02 and
+ * CoarseFineConsistencyLoss02 share it) together with CommonUtils.reproject (src/utils/CommonUtils01.py:45-71):
+ * the 3-D points of two depth estimates are projected into the nearest other training view, patch_x x patch_y
+ * patches of the ground-truth images are compared with the patch around the source pixel, and
+ *   mask1 = estimate 1 matches better (or estimate 2 lands outside), its patch RMSE < threshold, all patches inside
+ *   mask2 = likewise for estimate 2
+ *   rays_o, rays_d  device (n,3)     depth1, depth2  device (n)      ray_mask  device (n) bytes or NULL: rays outside
+ *   pixel_id  device (n,3) int32 (view, x, y)                         it get mask1 = mask2 = 0
+ *   poses  device (num_views,4,4) camera-to-world    intrinsic  device (3,3): the FIRST view's, used for every ray
+ *   images device (num_views, height, width, 3) in [0,1]              (CommonUtils01.py:66)
+ *   mask1, mask2  device (n) bytes;  rmse1, rmse2  device (n) or NULL (diagnostics)
+ */
+int snerf_patch_consistency_masks(const float* rays_o, const float* rays_d, const float* depth1, const float* depth2,
+                                  const unsigned char* ray_mask, const int* pixel_id, long long num_rays,
+                                  const float* poses, const float* intrinsic, const float* images, int num_views,
+                                  int height, int width, int patch_x, int patch_y, float rmse_threshold,
+                                  unsigned char* mask1, unsigned char* mask2, float* rmse1, float* rmse2,
+                                  snerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMPLENERF_TRAIN_H */

@@ -1,4 +1,4 @@
-"""ctypes binding of the C-ABI shared library (include/simplenerf_hip.h).
+"""ctypes binding of the C-ABI shared library (include/simplenerf_hip.h, include/simplenerf_train.h).
 
 The HIP library is the only implementation of the path: if it is missing or a call fails, a RuntimeError is raised --
 there is no PyTorch or CPU fallback.
@@ -20,6 +20,15 @@ class MlpDesc(ctypes.Structure):
         'points_net_depth', 'points_net_width', 'views_net_depth', 'views_net_width', 'points_pe_degree',
         'views_pe_degree', 'sigma_pe_degree', 'use_view_dirs', 'view_dependent_rgb')]
 
+
+class LossTerm(ctypes.Structure):
+    """struct snerf_loss_term"""
+    _fields_ = [('pred', c_void_p), ('target', c_void_p), ('numerator_mask', c_void_p), ('denominator_mask', c_void_p),
+                ('d_pred', c_void_p), ('channels', c_int), ('group', c_int), ('accumulate', c_int), ('weight', c_float)]
+
+
+LOSS_MAX_TERMS = 16
+LOSS_MAX_GROUPS = 16
 
 _FP = c_void_p  # device (or host, where the header says so) float*
 
@@ -46,6 +55,13 @@ SIGNATURES = {
                                 _FP, _FP, _FP, _FP, c_void_p]),
     'snerf_to_display': (c_int, [_FP, _FP, c_longlong, _FP, _FP, c_void_p]),
     'snerf_resample_depths': (c_int, [_FP, _FP, c_longlong, c_int, c_int, _FP, _FP, c_void_p]),
+    # include/simplenerf_train.h
+    'snerf_loss_workspace_bytes': (c_longlong, []),
+    'snerf_loss_forward': (c_int, [POINTER(LossTerm), c_int, c_int, c_longlong, _FP, _FP, c_void_p, c_void_p]),
+    'snerf_loss_backward': (c_int, [POINTER(LossTerm), c_int, c_int, c_longlong, _FP, _FP, c_void_p]),
+    'snerf_patch_consistency_masks': (c_int, [_FP, _FP, _FP, _FP, c_void_p, c_void_p, c_longlong, _FP, _FP, _FP, c_int,
+                                              c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, _FP, _FP,
+                                              c_void_p]),
 }
 
 _lib = None

@@ -316,3 +316,127 @@ def to_display(rgb: Tensor, depth: Optional[Tensor] = None):
         st = lib.snerf_to_display(_ptr(rgb), _ptr(depth), n, ctypes.c_void_p(image.data_ptr()), _ptr(depth_out), _stream())
     _lib.check(st, 'snerf_to_display')
     return image, depth_out
+
+
+# ---------------------------------------------------------------------------------------------- f1 losses
+class LossTermSpec:
+    """One masked mean-squared-error term of the fused loss evaluation (struct snerf_loss_term)."""
+    __slots__ = ('pred', 'target', 'numerator_mask', 'denominator_mask', 'group', 'weight')
+
+    def __init__(self, pred: Tensor, target: Tensor, numerator_mask: Optional[Tensor], denominator_mask: Optional[Tensor],
+                 group: int, weight: float):
+        n = pred.shape[0]
+        self.pred = _dev(pred, 'loss pred')
+        self.target = _dev(target, 'loss target', tuple(pred.shape))
+        self.numerator_mask = _mask(numerator_mask, 'numerator_mask', n)
+        self.denominator_mask = _mask(denominator_mask, 'denominator_mask', n)
+        self.group, self.weight = int(group), float(weight)
+        if self.pred.dim() not in (1, 2) or (self.pred.dim() == 2 and self.pred.shape[1] > 4):
+            raise RuntimeError(f'loss pred: expected (n,) or (n,c<=4), got {tuple(pred.shape)}')
+
+
+def _mask(t: Optional[Tensor], name: str, n: int) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype not in (torch.bool, torch.uint8) or tuple(t.shape) != (n,):
+        raise RuntimeError(f'{name}: expected a bool/uint8 GPU tensor of shape ({n},), got {t.dtype} {tuple(t.shape)} on {t.device}')
+    return t.contiguous()
+
+
+_loss_workspaces: Dict[torch.device, Tensor] = {}
+
+
+def _loss_table(terms: List[LossTermSpec], grads: Optional[List[Optional[Tensor]]]):
+    if not 1 <= len(terms) <= _lib.LOSS_MAX_TERMS:
+        raise RuntimeError(f'fused loss: {len(terms)} terms, the kernel table holds 1..{_lib.LOSS_MAX_TERMS}')
+    table = (_lib.LossTerm * len(terms))()
+    seen = set()
+    for i, t in enumerate(terms):
+        e = table[i]
+        e.pred, e.target = t.pred.data_ptr(), t.target.data_ptr()
+        e.numerator_mask = 0 if t.numerator_mask is None else t.numerator_mask.data_ptr()
+        e.denominator_mask = 0 if t.denominator_mask is None else t.denominator_mask.data_ptr()
+        e.channels = 1 if t.pred.dim() == 1 else t.pred.shape[1]
+        e.group, e.weight = t.group, t.weight
+        e.d_pred, e.accumulate = 0, 0
+        if grads is not None and grads[i] is not None:
+            e.d_pred = grads[i].data_ptr()
+            e.accumulate = int(e.d_pred in seen)
+            seen.add(e.d_pred)
+    return table
+
+
+def loss_forward(terms: List[LossTermSpec], num_groups: int):
+    """-> values (T+G+1: term values, per-loss sums, weighted total), scales (T) for loss_backward.  One launch."""
+    lib = _lib.load()
+    dev = terms[0].pred.device
+    n, count = terms[0].pred.shape[0], len(terms)
+    if any(t.pred.shape[0] != n for t in terms):
+        raise RuntimeError('fused loss: every term must cover the same rays')
+    values = torch.empty((count + num_groups + 1,), dtype=torch.float32, device=dev)
+    scales = torch.empty((count,), dtype=torch.float32, device=dev)
+    ws = _loss_workspaces.get(dev)
+    if ws is None:
+        ws = _loss_workspaces[dev] = torch.zeros((int(lib.snerf_loss_workspace_bytes()),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        st = lib.snerf_loss_forward(_loss_table(terms, None), count, int(num_groups), n, _ptr(values), _ptr(scales),
+                                    ctypes.c_void_p(ws.data_ptr()), _stream())
+    _lib.check(st, 'snerf_loss_forward')
+    return values, scales
+
+
+def loss_backward(terms: List[LossTermSpec], num_groups: int, scales: Tensor, upstream: Tensor,
+                  wanted: List[bool]) -> List[Optional[Tensor]]:
+    """Gradient of every term's pred (None where ``wanted[i]`` is false).  Terms that share a pred tensor share one
+    buffer holding the sum.  One launch."""
+    lib = _lib.load()
+    n = terms[0].pred.shape[0]
+    buffers: Dict[int, Tensor] = {}
+    grads: List[Optional[Tensor]] = []
+    for t, want in zip(terms, wanted):
+        if not want:
+            grads.append(None)
+            continue
+        key = t.pred.data_ptr()
+        if key not in buffers:
+            buffers[key] = torch.empty_like(t.pred)
+        grads.append(buffers[key])
+    upstream = _dev(upstream, 'upstream', (len(terms) + num_groups + 1,))
+    if n > 0 and buffers:
+        with torch.cuda.device(scales.device):
+            st = lib.snerf_loss_backward(_loss_table(terms, grads), len(terms), int(num_groups), n, _ptr(scales),
+                                         _ptr(upstream), _stream())
+        _lib.check(st, 'snerf_loss_backward')
+    return grads
+
+
+def patch_consistency_masks(rays_o: Tensor, rays_d: Tensor, depth1: Tensor, depth2: Tensor, ray_mask: Optional[Tensor],
+                            pixel_id: Tensor, poses: Tensor, intrinsic: Tensor, images: Tensor, patch_size,
+                            rmse_threshold: float, with_rmse: bool = False):
+    """Decision masks of the patch-reprojection consistency losses: (mask1, mask2[, rmse1, rmse2]) per ray."""
+    lib = _lib.load()
+    n = rays_o.shape[0]
+    v, h, w, c = images.shape
+    if c != 3:
+        raise RuntimeError(f'images: expected (views,h,w,3), got {tuple(images.shape)}')
+    rays_o, rays_d = _dev(rays_o, 'rays_o', (n, 3)), _dev(rays_d, 'rays_d', (n, 3))
+    depth1, depth2 = _dev(depth1, 'depth1', (n,)), _dev(depth2, 'depth2', (n,))
+    ray_mask = _mask(ray_mask, 'ray_mask', n)
+    if not pixel_id.is_cuda or pixel_id.dtype != torch.int32 or tuple(pixel_id.shape) != (n, 3):
+        raise RuntimeError(f'pixel_id: expected int32 GPU tensor ({n},3), got {pixel_id.dtype} {tuple(pixel_id.shape)}')
+    pixel_id = pixel_id.contiguous()
+    poses, images = _dev(poses, 'poses', (v, 4, 4)), _dev(images, 'images')
+    intrinsic = _dev(intrinsic, 'intrinsic', (3, 3))
+    dev = rays_o.device
+    mask1 = torch.empty((n,), dtype=torch.bool, device=dev)
+    mask2 = torch.empty((n,), dtype=torch.bool, device=dev)
+    rmse1 = torch.empty((n,), dtype=torch.float32, device=dev) if with_rmse else None
+    rmse2 = torch.empty((n,), dtype=torch.float32, device=dev) if with_rmse else None
+    if n > 0:
+        with torch.cuda.device(dev):
+            st = lib.snerf_patch_consistency_masks(
+                _ptr(rays_o), _ptr(rays_d), _ptr(depth1), _ptr(depth2), _ptr(ray_mask), _ptr(pixel_id), n, _ptr(poses),
+                _ptr(intrinsic), _ptr(images), v, h, w, int(patch_size[0]), int(patch_size[1]), float(rmse_threshold),
+                _ptr(mask1), _ptr(mask2), _ptr(rmse1), _ptr(rmse2), _stream())
+        _lib.check(st, 'snerf_patch_consistency_masks')
+    return (mask1, mask2, rmse1, rmse2) if with_rmse else (mask1, mask2)

@@ -174,3 +174,113 @@ def camera(scene: str = 'fern', pose_index: int = 0, downscale: int = 1) -> dict
         'near': float(cams['near']), 'far': float(cams['far']),
         'near_ndc': float(cams['near_ndc']), 'far_ndc': float(cams['far_ndc']),
     }
+
+
+# --------------------------------------------------------------------------------------
+# a small multi-view scene for the loss / batch-assembly rows
+# --------------------------------------------------------------------------------------
+def _rotation(rx: float, ry: float, rz: float) -> numpy.ndarray:
+    cx, sx, cy, sy, cz, sz = numpy.cos(rx), numpy.sin(rx), numpy.cos(ry), numpy.sin(ry), numpy.cos(rz), numpy.sin(rz)
+    mx = numpy.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    my = numpy.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    mz = numpy.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return mz @ my @ mx
+
+
+def synth_scene(seed: int = 0, num_views: int = 3, height: int = 48, width: int = 64, plane_depth: float = 4.0) -> dict:
+    """A textured plane z = -plane_depth seen by ``num_views`` pinhole cameras (camera-to-world poses in the
+    reference's processed convention: x right, y up, looking down -z; src/data_preprocessors/DataPreprocessor01.py
+    :351-368).  Images are rendered exactly (ray/plane intersection), so a ray's true depth reprojects onto a matching
+    patch in the neighbouring view and a wrong depth does not -- what the patch-consistency losses measure.
+
+    Returns float32 arrays: images (V,h,w,3) in [0,1], poses (V,4,4), intrinsics (V,3,3), resolution (h,w),
+    true_depth (V,h,w) = ray parameter t with o + t*d on the plane (d as produced by get_rays, d_z = -1 in camera space).
+    """
+    rng = numpy.random.RandomState(seed)
+    focal = 0.9 * width
+    k = numpy.array([[focal, 0, width / 2], [0, focal, height / 2], [0, 0, 1]], dtype=numpy.float64)
+    poses = numpy.zeros((num_views, 4, 4))
+    for v in range(num_views):
+        angles = 0.04 * rng.standard_normal(3) if v else numpy.zeros(3)
+        shift = numpy.array([0.35, 0.25, 0.05]) * rng.standard_normal(3) if v else numpy.zeros(3)
+        poses[v, :3, :3] = _rotation(*angles)
+        poses[v, :3, 3] = shift
+        poses[v, 3, 3] = 1
+    phase = rng.uniform(0, 2 * numpy.pi, size=(3, 4))
+    xs, ys = numpy.meshgrid(numpy.arange(width, dtype=numpy.float64), numpy.arange(height, dtype=numpy.float64))
+    dirs_cam = numpy.stack([(xs - k[0, 2]) / focal, -(ys - k[1, 2]) / focal, -numpy.ones_like(xs)], -1)
+    images = numpy.zeros((num_views, height, width, 3))
+    depth = numpy.zeros((num_views, height, width))
+    for v in range(num_views):
+        d = dirs_cam @ poses[v, :3, :3].T
+        o = poses[v, :3, 3]
+        t = (-plane_depth - o[2]) / d[..., 2]
+        px, py = o[0] + t * d[..., 0], o[1] + t * d[..., 1]
+        depth[v] = t
+        for c in range(3):
+            images[v, ..., c] = 0.5 + 0.2 * numpy.sin(2.3 * px + phase[c, 0]) * numpy.cos(1.9 * py + phase[c, 1]) \
+                + 0.15 * numpy.sin(5.1 * px + 3.7 * py + phase[c, 2]) + 0.1 * numpy.cos(9.0 * py - 4.0 * px + phase[c, 3])
+    images = numpy.clip(images, 0, 1)
+    return {
+        'images': images.astype(numpy.float32), 'poses': poses.astype(numpy.float32),
+        'intrinsics': numpy.repeat(k[None], num_views, 0).astype(numpy.float32), 'resolution': (height, width),
+        'true_depth': depth.astype(numpy.float32),
+    }
+
+
+def loss_configs(iter_weighted: bool = True) -> list:
+    """The nine losses every shipped experiment enables (src/NerfLlffTrainerTester01.py:351-430)."""
+    late = {'iter_weights': {'0': 0, '10000': 0.1}} if iter_weighted else {'weight': 0.1}
+    patch = {'rmse_threshold': 0.1, 'patch_size': [5, 5]}
+    return [
+        {'name': 'MSE01', 'weight': 1}, {'name': 'SparseDepthMSE01', 'weight': 0.1},
+        {'name': 'MSE02', 'weight': 1}, {'name': 'SparseDepthMSE02', 'weight': 0.1},
+        {'name': 'MSE03', 'weight': 1}, {'name': 'SparseDepthMSE03', 'weight': 0.1},
+        {'name': 'PointsAugmentationDepthLoss02', **late, **patch},
+        {'name': 'ViewsAugmentationDepthLoss02', **late, **patch},
+        {'name': 'CoarseFineConsistencyLoss02', **late, **patch},
+    ]
+
+
+def loss_batch(scene: dict, num_rays: int, num_sparse: int, seed: int = 0) -> Dict[str, numpy.ndarray]:
+    """Seeded stand-ins for one training batch and the model outputs the losses read: ``num_rays`` pixel rays followed
+    by ``num_sparse`` sparse-depth rays (the layout of load_cached_next_batch, DataPreprocessor01.py:514-584), depth
+    estimates scattered around the true plane depth (some exact ties, some wildly off, some border pixels)."""
+    rng = numpy.random.RandomState(seed)
+    v, (h, w) = scene['images'].shape[0], scene['resolution']
+    n = num_rays + num_sparse
+    image_id = rng.randint(0, v, size=n)
+    x = rng.randint(0, w, size=n)
+    y = rng.randint(0, h, size=n)
+    x[:8] = [0, 1, 2, w - 1, w - 2, w - 3, 5, 6][:min(8, n)] if n >= 8 else x[:8]
+    y[:8] = [5, 6, 7, 8, 0, 1, h - 1, h - 2][:min(8, n)] if n >= 8 else y[:8]
+    k = scene['intrinsics'][0].astype(numpy.float64)
+    dirs = numpy.stack([(x - k[0, 2]) / k[0, 0], -(y - k[1, 2]) / k[1, 1], -numpy.ones(n)], -1)
+    rays_d = numpy.einsum('nj,nij->ni', dirs, scene['poses'][image_id, :3, :3].astype(numpy.float64))
+    rays_o = scene['poses'][image_id, :3, 3]
+    true = scene['true_depth'][image_id, y, x]
+
+    def estimate(sigma_small, sigma_large):
+        pick = rng.uniform(size=n) < 0.6
+        return (true + numpy.where(pick, sigma_small, sigma_large) * rng.standard_normal(n)).astype(numpy.float32)
+
+    depths = {name: estimate(0.03, 0.6) for name in ('depth_coarse', 'depth_fine', 'points_augmentation_depth_coarse',
+                                                      'views_augmentation_depth_coarse')}
+    ties = rng.uniform(size=n) < 0.1
+    depths['points_augmentation_depth_coarse'][ties] = depths['depth_coarse'][ties]
+    if n >= 16:
+        depths['depth_fine'][8:12] = [0.0, -1.5, 1e6, 3e-3]
+        depths['views_augmentation_depth_coarse'][12:16] = [1e-4, -40.0, 2.5e4, 0.0]
+    target = scene['images'][image_id, y, x]
+    colours = {name: numpy.clip(target + 0.1 * rng.standard_normal((n, 3)), 0, 1).astype(numpy.float32)
+               for name in ('rgb_coarse', 'rgb_fine', 'points_augmentation_rgb_coarse', 'views_augmentation_rgb_coarse')}
+    sparse = numpy.full((n, 1), -1.0, dtype=numpy.float32)
+    sparse[num_rays:, 0] = true[num_rays:] + 0.05 * rng.standard_normal(num_sparse)
+    target_rgb = target.astype(numpy.float32).copy()
+    target_rgb[num_rays:] = -1.0          # sparse-depth rows keep the loader's -1 fill (:598)
+    return {
+        'rays_o': rays_o.astype(numpy.float32), 'rays_d': rays_d.astype(numpy.float32),
+        'pixel_id': numpy.stack([image_id, x, y], 1).astype(numpy.int32), 'target_rgb': target_rgb,
+        'indices_mask_nerf': numpy.arange(n) < num_rays, 'indices_mask_sparse_depth': numpy.arange(n) >= num_rays,
+        'sparse_depth_values': sparse, **depths, **colours,
+    }

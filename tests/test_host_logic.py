@@ -15,7 +15,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
-    header = open(os.path.join(REPO, 'include', 'simplenerf_hip.h')).read()
+    headers = sorted(f for f in os.listdir(os.path.join(REPO, 'include')) if f.endswith('.h'))
+    assert headers == ['simplenerf_hip.h', 'simplenerf_train.h']
+    header = ''.join(open(os.path.join(REPO, 'include', f)).read() for f in headers)
     declared = set(re.findall(r'\b(snerf_[a-z_0-9]+)\s*\(', header))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()
@@ -76,3 +78,24 @@ def test_default_init_consumes_rng_like_reference_constructor_order():
     lin = torch.nn.Linear
     first = lin(63, 256)
     assert torch.equal(a['coarse_model.pts_linears.0.weight'], first.weight)
+
+
+def test_loss_computer_host_logic():
+    from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
+    configs = synth.make_configs('config3')
+    configs['losses'] = synth.loss_configs()
+    lc = LossComputer(configs)
+    assert list(lc.losses) == [c['name'] for c in configs['losses']]
+    assert lc.get_loss_weight(configs['losses'][6], 0) == 0 and lc.get_loss_weight(configs['losses'][6], 9999) == 0
+    assert lc.get_loss_weight(configs['losses'][6], 10000) == 0.1 and lc.get_loss_weight(configs['losses'][0], 5) == 1
+    with pytest.raises(RuntimeError, match='loss_weight is None'):
+        lc.get_loss_weight({'name': 'MSE01'}, 0)
+    with pytest.raises(RuntimeError, match='Unknown Loss Function'):
+        LossComputer({**configs, 'losses': [{'name': 'VisibilityLoss01', 'weight': 1}]})
+    # no CPU path: host tensors are refused, not silently evaluated by torch
+    import torch
+    inp = {'iter_num': 0, 'rays_o': torch.zeros(4, 3), 'indices_mask_nerf': torch.ones(4, dtype=torch.bool),
+           'target_rgb': torch.zeros(4, 3)}
+    out = {'rgb_coarse': torch.zeros(4, 3), 'rgb_fine': torch.zeros(4, 3)}
+    with pytest.raises(RuntimeError, match='expected a tensor on the GPU'):
+        LossComputer({**configs, 'losses': [{'name': 'MSE01', 'weight': 1}]}).compute_losses(inp, out)

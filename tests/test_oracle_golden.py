@@ -164,3 +164,50 @@ def test_gradients_match_reference(kind, profile):
         assert util.linf(sample, g[f'gradsample_{name}']) <= 2e-3 * max(scale, float(numpy.abs(g[f'gradsample_{name}']).max())), name
         checked += 1
     assert checked == len(util.model_param_shapes(cfg))
+
+
+# ---------------------------------------------------------------- G8 losses
+from oracle import loss_oracle  # noqa: E402
+
+LOSS_CASES = ['full', 'early', 'nosd', 'empty']
+
+
+@pytest.mark.parametrize('case', LOSS_CASES)
+def test_loss_oracle_matches_reference(case):
+    g = util.load(f'losses_{case}.npz')
+    configs, input_dict, output_dict = util.loss_case(g)
+    values = loss_oracle.compute_losses(configs, input_dict, output_dict)
+    assert float(values['TotalLoss']) == pytest.approx(float(g['TotalLoss']), rel=2e-6, abs=1e-9)
+    for cfg in configs['losses']:
+        assert float(values[cfg['name']]) == pytest.approx(float(g[f"value_{cfg['name']}"]), rel=2e-6, abs=1e-9), cfg['name']
+    if isinstance(values['TotalLoss'], torch.Tensor) and values['TotalLoss'].requires_grad:
+        values['TotalLoss'].backward()
+    for k in util.LOSS_OUTPUT_KEYS:
+        grad = output_dict[k].grad
+        grad = numpy.zeros_like(g[f'grad_{k}']) if grad is None else grad.numpy()
+        scale = max(float(numpy.abs(g[f'grad_{k}']).max()), 1e-12)
+        assert util.linf(grad, g[f'grad_{k}']) <= 2e-6 * scale, k
+
+
+def test_reprojection_and_masks_match_reference():
+    """Un-rounded reprojected positions are bit-identical, the nearest-view choice is identical, and the per-ray loss
+    maps (which encode the patch decision masks) match on every ray."""
+    g = util.load('losses_nosd.npz')
+    configs, inp, out = util.loss_case(g)
+    common = inp['common_data']
+    closest = loss_oracle.closest_other_view(common['poses'], inp['pixel_id'][:, 0].long())
+    assert numpy.array_equal(closest.numpy(), g['closest_view'])
+    pts = inp['rays_o'] + inp['rays_d'] * out['depth_coarse'].detach()[:, None]
+    pos = loss_oracle.reproject(pts, common['poses'][closest], common['intrinsics'][0])
+    assert util.linf(pos.numpy(), g['reprojected_depth_coarse']) == 0.0
+    pairs = {'PointsAugmentationDepthLoss02': ('depth_coarse', 'points_augmentation_depth_coarse', 'coarse_main', 'coarse_augmented'),
+             'ViewsAugmentationDepthLoss02': ('depth_coarse', 'views_augmentation_depth_coarse', 'coarse_main', 'coarse_augmented'),
+             'CoarseFineConsistencyLoss02': ('depth_coarse', 'depth_fine', 'coarse', 'fine')}
+    for name, (k1, k2, m1, m2) in pairs.items():
+        _, m = loss_oracle.consistency_loss(out[k1], out[k2], inp['indices_mask_nerf'], inp['rays_o'], inp['rays_d'],
+                                            inp['pixel_id'], common['poses'], common['images'], common['intrinsics'],
+                                            common['resolution'], [5, 5], 0.1)
+        assert util.linf(m['map1'].detach().numpy(), g[f'map_{name}_{name}_{m1}']) <= 1e-6, name
+        assert util.linf(m['map2'].detach().numpy(), g[f'map_{name}_{name}_{m2}']) <= 1e-6, name
+        frac = float(m['mask1'].float().mean()), float(m['mask2'].float().mean())
+        assert 0.05 < frac[0] < 0.95 and 0.05 < frac[1] < 0.95, (name, frac)   # the fixture exercises both outcomes

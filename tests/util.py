@@ -120,3 +120,32 @@ def grad_loss(out):
         elif base in ('depth_coarse', 'depth_fine'):
             loss = loss + 0.01 * (out[k] ** 2).mean()
     return loss
+
+
+LOSS_OUTPUT_KEYS = ('rgb_coarse', 'rgb_fine', 'points_augmentation_rgb_coarse', 'views_augmentation_rgb_coarse',
+                    'depth_coarse', 'depth_fine', 'points_augmentation_depth_coarse', 'views_augmentation_depth_coarse')
+
+
+def loss_case(golden: dict, device='cpu'):
+    """Rebuild (configs, input_dict, output_dict) of a G8 loss fixture from its recorded seeds.  ``common_data`` is
+    un-replicated (what LossComputer sees after it has taken [0])."""
+    scene = synth.synth_scene(int(golden['scene_seed']))
+    batch = synth.loss_batch(scene, int(golden['num_rays']), int(golden['num_sparse']), int(golden['batch_seed']))
+    sparse = bool(golden['sparse_in_batch'])
+    configs = synth.make_configs('config3')
+    configs['losses'] = synth.loss_configs()
+    if sparse:
+        configs['data_loader']['sparse_depth'] = {}
+    t = lambda a: torch.from_numpy(numpy.ascontiguousarray(a)).to(device)
+    input_dict = {
+        'iter_num': int(golden['iter_num']),
+        'rays_o': t(batch['rays_o']), 'rays_d': t(batch['rays_d']), 'pixel_id': t(batch['pixel_id']),
+        'target_rgb': t(batch['target_rgb']), 'indices_mask_nerf': t(batch['indices_mask_nerf']),
+        'common_data': {'poses': t(scene['poses']), 'images': t(scene['images']),
+                        'intrinsics': t(scene['intrinsics']), 'resolution': scene['resolution']},
+    }
+    if sparse:
+        input_dict['indices_mask_sparse_depth'] = t(batch['indices_mask_sparse_depth'])
+        input_dict['sparse_depth_values'] = t(batch['sparse_depth_values'])
+    output_dict = {k: t(batch[k]).clone().requires_grad_(True) for k in LOSS_OUTPUT_KEYS}
+    return configs, input_dict, output_dict
