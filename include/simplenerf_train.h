@@ -81,6 +81,22 @@ int snerf_patch_consistency_masks(const float* rays_o, const float* rays_d, cons
                                   unsigned char* mask1, unsigned char* mask2, float* rmse1, float* rmse2,
                                   snerf_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * O1  Adam update of every parameter tensor in one launch per 64 tensors.  Replaces the optimiser call of the
+ * reference's trainer, torch.optim.Adam(params, lr, betas).step() (src/Trainer01.py:102, :516-517; PyTorch 2.x
+ * single-tensor algorithm, weight_decay = 0, amsgrad = False), with the learning rate the trainer writes into
+ * param_groups before each step (:293-295).  Element-wise arithmetic and its order are those of the CPU path of that
+ * algorithm, bit for bit:
+ *     m <- fma(1-beta1, g - m, m)            v <- fma((1-beta2) g, g, beta2 v)
+ *     p <- p + (-(lr / (1-beta1^step)) m) / (sqrt(v) / sqrt(1-beta2^step) + eps)
+ * with the scalar factors evaluated in double on the host and rounded to float once, as Python/ATen do.
+ *   params, grads, exp_avg, exp_avg_sq   HOST arrays of num_tensors DEVICE pointers; grads[i] == NULL skips tensor i
+ *   sizes   HOST array of element counts   step  1-based step count of this update (after the increment)
+ */
+int snerf_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const long long* sizes, int num_tensors, long long step, double lr, double beta1, double beta2,
+                    double eps, snerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsimplenerf_hip.so')
@@ -62,6 +62,9 @@ SIGNATURES = {
     'snerf_patch_consistency_masks': (c_int, [_FP, _FP, _FP, _FP, c_void_p, c_void_p, c_longlong, _FP, _FP, _FP, c_int,
                                               c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, _FP, _FP,
                                               c_void_p]),
+    'snerf_adam_step': (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                POINTER(c_longlong), c_int, c_longlong, c_double, c_double, c_double, c_double,
+                                c_void_p]),
 }
 
 _lib = None

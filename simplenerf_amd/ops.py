@@ -440,3 +440,24 @@ def patch_consistency_masks(rays_o: Tensor, rays_d: Tensor, depth1: Tensor, dept
                 _ptr(mask1), _ptr(mask2), _ptr(rmse1), _ptr(rmse2), _stream())
         _lib.check(st, 'snerf_patch_consistency_masks')
     return (mask1, mask2, rmse1, rmse2) if with_rmse else (mask1, mask2)
+
+
+# ---------------------------------------------------------------------------------------------- f4 optimiser
+def adam_step(params: List[Tensor], grads: List[Optional[Tensor]], exp_avg: List[Tensor], exp_avg_sq: List[Tensor],
+              step: int, lr: float, beta1: float, beta2: float, eps: float) -> None:
+    """In-place Adam update of every tensor with a gradient (one launch per 64 tensors)."""
+    lib = _lib.load()
+    n = len(params)
+    if n == 0:
+        return
+    for name, group in (('param', params), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
+        for t in group:
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f'adam_step: {name} must be a contiguous float32 GPU tensor, got {t.dtype} on {t.device}')
+    ptrs = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    grads = [None if g is None else _dev(g, 'grad', tuple(p.shape)) for g, p in zip(grads, params)]
+    sizes = (ctypes.c_longlong * n)(*[p.numel() for p in params])
+    with torch.cuda.device(params[0].device):
+        st = lib.snerf_adam_step(ptrs(params), ptrs(grads), ptrs(exp_avg), ptrs(exp_avg_sq), sizes, n, int(step),
+                                 float(lr), float(beta1), float(beta2), float(eps), _stream())
+    _lib.check(st, 'snerf_adam_step')

@@ -1,0 +1,50 @@
+"""Optimiser of the training step on the HIP library: ``Adam(params, lr, betas)`` with the interface the reference's
+trainer uses from ``torch.optim.Adam`` (src/Trainer01.py:80, :102, :293-295, :360, :377, :516-517): ``param_groups``
+whose ``'lr'`` the trainer overwrites every iteration, ``zero_grad(set_to_none=True)``, ``step()``,
+``state_dict()`` / ``load_state_dict()``.
+
+It subclasses ``torch.optim.Optimizer`` for that bookkeeping only -- state layout (``step``, ``exp_avg``,
+``exp_avg_sq`` per parameter) and ``param_groups`` keys are those of ``torch.optim.Adam``, so the
+``optimizer_state_dict`` of a reference checkpoint loads here and vice versa.  The update itself is one HIP launch
+per 64 tensors (snerf_adam_step), bit-identical to PyTorch's CPU single-tensor Adam.  No torch fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError('the HIP Adam builds what the reference uses: weight_decay=0, amsgrad=False')
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                        capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False)
+        super().__init__(params, defaults)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            if group.get('weight_decay', 0) != 0 or group.get('amsgrad', False) or group.get('maximize', False):
+                raise NotImplementedError('weight_decay / amsgrad / maximize are not built')
+            by_step = {}
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                state = self.state[p]
+                if len(state) == 0:
+                    state['step'] = torch.tensor(0.0, dtype=torch.float32)
+                    state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state['step'] += 1
+                by_step.setdefault(int(state['step']), []).append(p)
+            beta1, beta2 = group['betas']
+            for step, ps in by_step.items():
+                ops.adam_step([p.data for p in ps], [p.grad for p in ps], [self.state[p]['exp_avg'] for p in ps],
+                              [self.state[p]['exp_avg_sq'] for p in ps], step, group['lr'], beta1, beta2, group['eps'])
+        return loss

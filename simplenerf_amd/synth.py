@@ -284,3 +284,23 @@ def loss_batch(scene: dict, num_rays: int, num_sparse: int, seed: int = 0) -> Di
         'indices_mask_nerf': numpy.arange(n) < num_rays, 'indices_mask_sparse_depth': numpy.arange(n) >= num_rays,
         'sparse_depth_values': sparse, **depths, **colours,
     }
+
+
+def optim_case(seed: int = 0) -> dict:
+    """Seeded parameters and per-step gradients for the optimiser fixtures: a few tensor shapes (odd sizes included)
+    with gradients spanning many magnitudes (zeros and denormal-sized second moments included), stepped at the
+    trainer iterations ``iters``; ``record`` lists the step counts whose state the fixture keeps."""
+    rng = numpy.random.RandomState(seed)
+    shapes = [(37,), (64, 63), (5,), (1,), (256, 3)]
+    params = [rng.uniform(-0.5, 0.5, size=s).astype(numpy.float32) for s in shapes]
+    iters = [0, 1, 2, 1000, 250000, 250001]
+    grads = []
+    for _ in iters:
+        step_grads = []
+        for s in shapes:
+            g = rng.standard_normal(s) * 10.0 ** rng.uniform(-6, 1, size=s)
+            g[rng.uniform(size=s) < 0.05] = 0.0
+            step_grads.append(g.astype(numpy.float32))
+        grads.append(step_grads)
+    grads[0][0][:4] = [1e-22, -3e-20, 0.0, 1e-30]
+    return {'params': params, 'grads': grads, 'iters': iters, 'record': (1, 2, 6)}

@@ -21,7 +21,7 @@ def test_fused_losses_match_reference(case):
     inp['common_data'] = {k: (v[None] if isinstance(v, torch.Tensor) else v) for k, v in inp['common_data'].items()}
     losses = LossComputer(configs).compute_losses(inp, out)
     assert inp['common_data']['poses'].dim() == 3          # un-replicated in place, like the reference
-    assert float(losses['TotalLoss']) == pytest.approx(float(g['TotalLoss']), rel=REL, abs=1e-9)
+    assert float(losses["TotalLoss"].detach()) == pytest.approx(float(g['TotalLoss']), rel=REL, abs=1e-9)
     for cfg in configs['losses']:
         assert float(losses[cfg['name']]['loss_value']) == pytest.approx(float(g[f"value_{cfg['name']}"]), rel=REL, abs=1e-9), cfg['name']
     losses['TotalLoss'].backward()

@@ -1,0 +1,58 @@
+"""Optimiser row on the GPU: the HIP Adam against torch.optim.Adam's CPU path (fixture and live)."""
+import numpy
+import pytest
+import torch
+
+from oracle import optim_oracle
+from simplenerf_amd import optim, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def test_adam_matches_reference_fixture_bit_for_bit():
+    g = util.load('optim_adam.npz')
+    case = synth.optim_case(int(g['seed']))
+    params = [torch.nn.Parameter(torch.from_numpy(p.copy()).to(DEV)) for p in case['params']]
+    opt = optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    for step, iter_num in enumerate(case['iters'], 1):
+        for group in opt.param_groups:
+            group['lr'] = float(g['lrs'][step - 1])
+        opt.zero_grad(set_to_none=True)
+        for p, grad in zip(params, case['grads'][step - 1]):
+            p.grad = torch.from_numpy(grad.copy()).to(DEV)
+        opt.step()
+        if step in case['record']:
+            for i, p in enumerate(params):
+                assert numpy.array_equal(p.detach().cpu().numpy(), g[f'step{step}_param{i}']), (step, i)
+                assert numpy.array_equal(opt.state[p]['exp_avg'].cpu().numpy(), g[f'step{step}_exp_avg{i}']), (step, i)
+                assert numpy.array_equal(opt.state[p]['exp_avg_sq'].cpu().numpy(), g[f'step{step}_exp_avg_sq{i}']), (step, i)
+    assert float(opt.state[params[0]]['step']) == len(case['iters'])
+
+
+def test_adam_on_the_full_model_matches_the_oracle_and_skips_gradless_tensors():
+    """All 90 tensors of the 4-MLP model (2.27 M parameters, two launches), three steps, one tensor without gradient."""
+    configs = synth.make_configs('config3')
+    shapes = util.model_param_shapes(configs)
+    sd = synth.synth_state_dict(shapes, 3)
+    names = list(sd)
+    assert len(names) == 90 and sum(v.size for v in sd.values()) == 2265488
+    params = [torch.nn.Parameter(torch.from_numpy(sd[k].copy()).to(DEV)) for k in names]
+    opt = optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    ref_p = [sd[k].copy() for k in names]
+    ref_m = [numpy.zeros_like(p) for p in ref_p]
+    ref_v = [numpy.zeros_like(p) for p in ref_p]
+    rng = numpy.random.RandomState(0)
+    for step in (1, 2, 3):
+        grads = [(rng.standard_normal(p.shape) * 10.0 ** rng.uniform(-5, 0)).astype(numpy.float32) for p in ref_p]
+        grads[7] = None
+        for p, gr in zip(params, grads):
+            p.grad = None if gr is None else torch.from_numpy(gr).to(DEV)
+        lr = optim_oracle.nerf_learning_rate(5e-4, 250, step * 1000)
+        opt.param_groups[0]['lr'] = lr
+        opt.step()
+        optim_oracle.adam_step(ref_p, grads, ref_m, ref_v, step, lr)
+    for i, k in enumerate(names):
+        assert numpy.array_equal(params[i].detach().cpu().numpy(), ref_p[i]), k
+    assert numpy.array_equal(params[7].detach().cpu().numpy(), sd[names[7]]) and len(opt.state[params[7]]) == 0

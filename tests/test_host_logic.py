@@ -99,3 +99,54 @@ def test_loss_computer_host_logic():
     out = {'rgb_coarse': torch.zeros(4, 3), 'rgb_fine': torch.zeros(4, 3)}
     with pytest.raises(RuntimeError, match='expected a tensor on the GPU'):
         LossComputer({**configs, 'losses': [{'name': 'MSE01', 'weight': 1}]}).compute_losses(inp, out)
+
+
+def test_lr_decayers_follow_the_reference():
+    from simplenerf_amd.lr_decayers.LearningRateDecayerFactory import get_lr_decayer
+    g = util.load('optim_adam.npz')
+    nerf = get_lr_decayer({'optimizer': {'lr_decayer_name': 'NeRFLearningRateDecayer01', 'lr_initial': 5e-4, 'lr_decay': 250}})
+    mip = get_lr_decayer({'num_iterations': 500000,
+                          'optimizer': {'lr_decayer_name': 'MipNeRFLearningRateDecayer01', 'lr_initial': 5e-4,
+                                        'lr_final': 5e-6, 'lr_decay_steps': 2500, 'lr_decay_mult': 0.01}})
+    for it, a, b in zip(g['probe_iters'], g['nerf_lr'], g['mip_lr']):
+        assert nerf.get_updated_learning_rate(int(it)) == float(a)          # bit-identical doubles
+        assert mip.get_updated_learning_rate(int(it)) == pytest.approx(float(b), rel=1e-15)
+    with pytest.raises(RuntimeError, match='Unknown lr decayer'):
+        get_lr_decayer({'optimizer': {'lr_decayer_name': 'CosineDecayer01'}})
+
+
+def test_optimizer_state_and_checkpoints_interchange_with_the_reference_format(tmp_path):
+    """state_dict layout = torch.optim.Adam's (what a reference checkpoint holds); model keys carry the DataParallel
+    ``module.`` prefix on disk and load with or without it."""
+    from simplenerf_amd import checkpoint, optim
+    g = util.load('optim_adam.npz')
+    configs = synth.make_configs('config1')
+    model = get_model(configs, None)
+    ours = optim.Adam(list(model.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    ref = torch.optim.Adam(list(model.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    assert sorted(ours.state_dict()['param_groups'][0]) == list(g['state_dict_group_keys'])
+    for p in model.parameters():
+        p.grad = torch.ones_like(p)
+    ref.step()                                          # CPU torch Adam creates the reference-format state
+    ours.load_state_dict(ref.state_dict())
+    sd = ours.state_dict()
+    assert sorted(sd['state'][0]) == list(g['state_dict_state_keys']) and float(sd['state'][0]['step']) == 1.0
+    ref2 = torch.optim.Adam(list(model.parameters()), lr=1e-3)
+    ref2.load_state_dict(sd)                            # and back
+    assert ref2.param_groups[0]['lr'] == 5e-4
+    with pytest.raises(RuntimeError, match='GPU'):      # stepping needs the HIP library and device tensors
+        ours.step()
+    with pytest.raises(NotImplementedError):
+        optim.Adam(list(model.parameters()), weight_decay=0.1)
+
+    path = tmp_path / 'Model_Iter000010.tar'
+    checkpoint.save_checkpoint(path, 10, model, ours)
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) == {'iteration_num', 'model_state_dict', 'optimizer_state_dict'}
+    assert all(k.startswith('module.') for k in raw['model_state_dict'])
+    other = get_model(configs, None)
+    assert checkpoint.load_checkpoint(path, other, optim.Adam(list(other.parameters()))) == 10
+    for (k, a), (_, b) in zip(model.state_dict().items(), other.state_dict().items()):
+        assert torch.equal(a, b), k
+    torch.save({'iteration_num': 3, 'model_state_dict': model.state_dict()}, path)   # un-prefixed names load too
+    assert checkpoint.load_checkpoint(path, other) == 3

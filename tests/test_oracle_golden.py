@@ -177,7 +177,7 @@ def test_loss_oracle_matches_reference(case):
     g = util.load(f'losses_{case}.npz')
     configs, input_dict, output_dict = util.loss_case(g)
     values = loss_oracle.compute_losses(configs, input_dict, output_dict)
-    assert float(values['TotalLoss']) == pytest.approx(float(g['TotalLoss']), rel=2e-6, abs=1e-9)
+    assert float(torch.as_tensor(values['TotalLoss']).detach()) == pytest.approx(float(g['TotalLoss']), rel=2e-6, abs=1e-9)
     for cfg in configs['losses']:
         assert float(values[cfg['name']]) == pytest.approx(float(g[f"value_{cfg['name']}"]), rel=2e-6, abs=1e-9), cfg['name']
     if isinstance(values['TotalLoss'], torch.Tensor) and values['TotalLoss'].requires_grad:
@@ -211,3 +211,31 @@ def test_reprojection_and_masks_match_reference():
         assert util.linf(m['map2'].detach().numpy(), g[f'map_{name}_{name}_{m2}']) <= 1e-6, name
         frac = float(m['mask1'].float().mean()), float(m['mask2'].float().mean())
         assert 0.05 < frac[0] < 0.95 and 0.05 < frac[1] < 0.95, (name, frac)   # the fixture exercises both outcomes
+
+
+# ---------------------------------------------------------------- G10 optimiser + learning-rate schedules
+from oracle import optim_oracle  # noqa: E402
+
+
+def test_adam_oracle_is_bit_identical_to_torch_cpu_adam():
+    g = util.load('optim_adam.npz')
+    case = synth.optim_case(int(g['seed']))
+    params = [p.copy() for p in case['params']]
+    m = [numpy.zeros_like(p) for p in params]
+    v = [numpy.zeros_like(p) for p in params]
+    for step, iter_num in enumerate(case['iters'], 1):
+        lr = optim_oracle.nerf_learning_rate(5e-4, 250, iter_num)
+        assert lr == float(g['lrs'][step - 1])
+        optim_oracle.adam_step(params, case['grads'][step - 1], m, v, step, lr)
+        if step in case['record']:
+            for i in range(len(params)):
+                assert numpy.array_equal(params[i], g[f'step{step}_param{i}']), (step, i)
+                assert numpy.array_equal(m[i], g[f'step{step}_exp_avg{i}']), (step, i)
+                assert numpy.array_equal(v[i], g[f'step{step}_exp_avg_sq{i}']), (step, i)
+
+
+def test_learning_rate_schedules_match_reference():
+    g = util.load('optim_adam.npz')
+    for it, nerf, mip in zip(g['probe_iters'], g['nerf_lr'], g['mip_lr']):
+        assert optim_oracle.nerf_learning_rate(5e-4, 250, int(it)) == float(nerf)
+        assert optim_oracle.mipnerf_learning_rate(5e-4, 5e-6, 500000, 2500, 0.01, int(it)) == pytest.approx(float(mip), rel=1e-15)
