@@ -82,6 +82,82 @@ int snerf_patch_consistency_masks(const float* rays_o, const float* rays_d, cons
                                   snerf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * B1  training-batch assembly.  Replaces DataPreprocessor.load_cached_next_batch -> load_nerf_cached_batch /
+ * load_sparse_depth_cached_batch (src/data_preprocessors/DataPreprocessor01.py:514-551, :586-636, :655-704) and the ray
+ * cache they read (preprocess_nerf_data :284-349: ~100 B per pixel of every training view).  Instead of gathering
+ * rows of a precomputed cache, each row's rays are recomputed from its view's camera (bit-identical to the cached
+ * numpy values, same arithmetic as K1), so the only gathers left are the target colour and the sparse-depth tables.
+ *
+ * snerf_camera_table: per-view camera constants on the device.
+ *   intrinsics device (num_views,3,3)   poses device (num_views,4,4) processed camera-to-world (what the reference
+ *   passes to get_rays, :299)           table device (num_views, SNERF_CAMERA_FLOATS); a singular intrinsic yields NaNs
+ */
+#define SNERF_CAMERA_FLOATS 24
+int snerf_camera_table(const float* intrinsics, const float* poses, int num_views, int height, int width, float* table,
+                       snerf_stream_t stream);
+
+typedef struct snerf_batch {
+    float* rays_o;                  /* device (n,3) */
+    float* rays_d;                  /* device (n,3) */
+    float* view_dirs;               /* device (n,3) */
+    float* rays_o_ndc;              /* device (n,3); NULL when ndc == 0 */
+    float* rays_d_ndc;              /* device (n,3); NULL when ndc == 0 */
+    int* pixel_id;                  /* device (n,3) int32 (view, x, y) */
+    float* target_rgb;              /* device (n,3); sparse-depth rows hold -1 (the loader's fill value, :598) */
+    float* near;                    /* device (n,1) */
+    float* far;                     /* device (n,1) */
+    float* near_ndc;                /* device (n,1); NULL when ndc == 0 */
+    float* far_ndc;                 /* device (n,1); NULL when ndc == 0 */
+    float* sparse_depth_values;     /* device (n,1) or NULL; pixel-ray rows hold -1 (:689-693) */
+    float* sparse_depth_errors;     /* device (n,1) or NULL */
+    float* sparse_depth_values_ndc; /* device (n,1) or NULL */
+    unsigned char* mask_pixel_rays; /* device (n) bytes: indices_mask_nerf */
+    unsigned char* mask_sparse_rays;/* device (n) bytes: indices_mask_sparse_depth, or NULL */
+} snerf_batch;
+
+/*   indices   device (n) int64 global pixel indices  view*height*width + y*width + x; the first num_pixel_rays rows
+ *             are pixel rays, the rest sparse-depth rays (the concatenation order of select_batch_indices :553-584).
+ *             An index outside [0, num_views*height*width) leaves its row at the loader's -1 fill with both masks 0.
+ *   images    device (num_views,height,width,3)     sparse_*  device (num_views*height*width) dense tables or NULL
+ *   near      also the near plane of the NDC warp (get_ndc_rays(..., near), :309) */
+int snerf_assemble_batch(const long long* indices, long long num_rays, long long num_pixel_rays,
+                         const float* camera_table, int num_views, int height, int width, const float* images,
+                         const float* sparse_depths, const float* sparse_errors, const float* sparse_depths_ndc, int ndc,
+                         float near, float far, float near_ndc, float far_ndc, const snerf_batch* out,
+                         snerf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * B2  shuffled index stream.  Replaces the host-side index list of generate_indices / select_batch_indices (:252-270,
+ * :556-563: numpy.arange + numpy.random.shuffle per epoch, sliced per batch, copied to the device) by positions
+ * [first, first+count) of a keyed pseudo-random PERMUTATION of the candidate set, computed on the fly (balanced
+ * Feistel network with cycle walking; nothing of size "all rays" is ever stored or shuffled).  The numpy stream itself
+ * cannot be reproduced on a device; callers that need the reference's exact order pass its indices to
+ * snerf_assemble_batch instead.
+ *   domain      number of candidates in an epoch; output position j holds candidate perm_{seed,epoch}(j)
+ *   candidates  device (domain) int64 list to index (the sparse-depth pixels, :441), or NULL: the candidates are the
+ *               pixels of the crop window rows [crop_y0,crop_y1) x columns [crop_x0,crop_x1) of every view
+ *               (generate_indices' precrop :258-268; the full image is 0,height,0,width) and
+ *               domain must equal num_views*(crop_y1-crop_y0)*(crop_x1-crop_x0)
+ *   out         device (count) int64 global pixel indices
+ */
+int snerf_shuffled_indices(unsigned long long seed, unsigned long long epoch, long long first, long long count,
+                           long long domain, const long long* candidates, int num_views, int height, int width,
+                           int crop_y0, int crop_y1, int crop_x0, int crop_x1, long long* out, snerf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * B3  training draws on the device.  Replaces the CPU-generator draws the reference makes per chunk and copies over
+ * (src/models/SimpleNeRF01.py:299 stratified jitter, :341 inverse-CDF u, :670 density noise) by Philox4x32-10
+ * (Salmon et al., SC'11; Random123 known-answer vectors hold) in counter mode: element (row, col) of a draw depends
+ * only on (seed, stream_id, first_row + row, col), so a ray's draws do not depend on how rays are sharded over ranks.
+ *   uniform: [0,1) with 24 random bits, like torch.rand;  normal: Box-Muller on pairs of 24-bit uniforms, times scale
+ *   out  device (num_rows, row_width)
+ */
+int snerf_random_uniform(unsigned long long seed, unsigned int stream_id, long long first_row, long long num_rows,
+                         int row_width, float* out, snerf_stream_t stream);
+int snerf_random_normal(unsigned long long seed, unsigned int stream_id, long long first_row, long long num_rows,
+                        int row_width, float scale, float* out, snerf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * O1  Adam update of every parameter tensor in one launch per 64 tensors.  Replaces the optimiser call of the
  * reference's trainer, torch.optim.Adam(params, lr, betas).step() (src/Trainer01.py:102, :516-517; PyTorch 2.x
  * single-tensor algorithm, weight_decay = 0, amsgrad = False), with the learning rate the trainer writes into

@@ -7,7 +7,8 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
+from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_uint, c_ulonglong,
+                    c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsimplenerf_hip.so')
@@ -27,6 +28,15 @@ class LossTerm(ctypes.Structure):
                 ('d_pred', c_void_p), ('channels', c_int), ('group', c_int), ('accumulate', c_int), ('weight', c_float)]
 
 
+class Batch(ctypes.Structure):
+    """struct snerf_batch"""
+    _fields_ = [(name, c_void_p) for name in (
+        'rays_o', 'rays_d', 'view_dirs', 'rays_o_ndc', 'rays_d_ndc', 'pixel_id', 'target_rgb', 'near', 'far', 'near_ndc',
+        'far_ndc', 'sparse_depth_values', 'sparse_depth_errors', 'sparse_depth_values_ndc', 'mask_pixel_rays',
+        'mask_sparse_rays')]
+
+
+CAMERA_FLOATS = 24
 LOSS_MAX_TERMS = 16
 LOSS_MAX_GROUPS = 16
 
@@ -62,6 +72,13 @@ SIGNATURES = {
     'snerf_patch_consistency_masks': (c_int, [_FP, _FP, _FP, _FP, c_void_p, c_void_p, c_longlong, _FP, _FP, _FP, c_int,
                                               c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, _FP, _FP,
                                               c_void_p]),
+    'snerf_camera_table': (c_int, [_FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
+    'snerf_assemble_batch': (c_int, [c_void_p, c_longlong, c_longlong, _FP, c_int, c_int, c_int, _FP, _FP, _FP, _FP, c_int,
+                                     c_float, c_float, c_float, c_float, POINTER(Batch), c_void_p]),
+    'snerf_shuffled_indices': (c_int, [c_ulonglong, c_ulonglong, c_longlong, c_longlong, c_longlong, c_void_p, c_int,
+                                       c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'snerf_random_uniform': (c_int, [c_ulonglong, c_uint, c_longlong, c_longlong, c_int, _FP, c_void_p]),
+    'snerf_random_normal': (c_int, [c_ulonglong, c_uint, c_longlong, c_longlong, c_int, c_float, _FP, c_void_p]),
     'snerf_adam_step': (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                 POINTER(c_longlong), c_int, c_longlong, c_double, c_double, c_double, c_double,
                                 c_void_p]),

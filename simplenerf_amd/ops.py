@@ -461,3 +461,113 @@ def adam_step(params: List[Tensor], grads: List[Optional[Tensor]], exp_avg: List
         st = lib.snerf_adam_step(ptrs(params), ptrs(grads), ptrs(exp_avg), ptrs(exp_avg_sq), sizes, n, int(step),
                                  float(lr), float(beta1), float(beta2), float(eps), _stream())
     _lib.check(st, 'snerf_adam_step')
+
+
+# ---------------------------------------------------------------------------------------------- f2 batch assembly
+def camera_table(intrinsics: Tensor, poses: Tensor, resolution) -> Tensor:
+    """(V, 24) per-view camera constants (inverse intrinsic, rotation, origin, NDC factors) on the device."""
+    lib = _lib.load()
+    v = poses.shape[0]
+    intrinsics, poses = _dev(intrinsics, 'intrinsics', (v, 3, 3)), _dev(poses, 'poses', (v, 4, 4))
+    table = torch.empty((v, _lib.CAMERA_FLOATS), dtype=torch.float32, device=poses.device)
+    with torch.cuda.device(poses.device):
+        st = lib.snerf_camera_table(_ptr(intrinsics), _ptr(poses), v, int(resolution[0]), int(resolution[1]), _ptr(table), _stream())
+    _lib.check(st, 'snerf_camera_table')
+    return table
+
+
+def assemble_batch(indices: Tensor, num_pixel_rays: int, table: Tensor, resolution, images: Tensor, ndc: bool, near: float,
+                   far: float, near_ndc: float = 0.0, far_ndc: float = 1.0, sparse_depths: Optional[Tensor] = None,
+                   sparse_errors: Optional[Tensor] = None, sparse_depths_ndc: Optional[Tensor] = None,
+                   with_sparse_mask: bool = False) -> Dict[str, Tensor]:
+    """One launch: rays (+NDC), view_dirs, pixel_id, target_rgb, near/far columns, sparse-depth columns and the row
+    masks for the global pixel ``indices`` (int64 GPU tensor); the first ``num_pixel_rays`` rows are pixel rays."""
+    lib = _lib.load()
+    if not indices.is_cuda or indices.dtype != torch.int64 or indices.dim() != 1:
+        raise RuntimeError(f'indices: expected a 1-D int64 GPU tensor, got {indices.dtype} {tuple(indices.shape)} on {indices.device}')
+    indices = indices.contiguous()
+    n, dev = indices.shape[0], indices.device
+    h, w = int(resolution[0]), int(resolution[1])
+    v = table.shape[0]
+    table = _dev(table, 'camera table', (v, _lib.CAMERA_FLOATS))
+    images = _dev(images, 'images', (v, h, w, 3))
+    tables = [None if t is None else _dev(t.reshape(-1), name, (v * h * w,)) for t, name in
+              ((sparse_depths, 'sparse_depths'), (sparse_errors, 'sparse_errors'), (sparse_depths_ndc, 'sparse_depths_ndc'))]
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    out = {'rays_o': f(n, 3), 'rays_d': f(n, 3), 'view_dirs': f(n, 3),
+           'pixel_id': torch.empty((n, 3), dtype=torch.int32, device=dev), 'target_rgb': f(n, 3), 'near': f(n, 1), 'far': f(n, 1),
+           'indices_mask_nerf': torch.empty((n,), dtype=torch.bool, device=dev)}
+    if ndc:
+        out.update(rays_o_ndc=f(n, 3), rays_d_ndc=f(n, 3), near_ndc=f(n, 1), far_ndc=f(n, 1))
+    for key, t in zip(('sparse_depth_values', 'sparse_depth_errors', 'sparse_depth_values_ndc'), tables):
+        if t is not None:
+            out[key] = f(n, 1)
+    if with_sparse_mask:
+        out['indices_mask_sparse_depth'] = torch.empty((n,), dtype=torch.bool, device=dev)
+    if n == 0:
+        return out
+    b = _lib.Batch()
+    for field, key in (('rays_o', 'rays_o'), ('rays_d', 'rays_d'), ('view_dirs', 'view_dirs'), ('rays_o_ndc', 'rays_o_ndc'),
+                       ('rays_d_ndc', 'rays_d_ndc'), ('pixel_id', 'pixel_id'), ('target_rgb', 'target_rgb'), ('near', 'near'),
+                       ('far', 'far'), ('near_ndc', 'near_ndc'), ('far_ndc', 'far_ndc'),
+                       ('sparse_depth_values', 'sparse_depth_values'), ('sparse_depth_errors', 'sparse_depth_errors'),
+                       ('sparse_depth_values_ndc', 'sparse_depth_values_ndc'), ('mask_pixel_rays', 'indices_mask_nerf'),
+                       ('mask_sparse_rays', 'indices_mask_sparse_depth')):
+        setattr(b, field, out[key].data_ptr() if key in out else None)
+    with torch.cuda.device(dev):
+        st = lib.snerf_assemble_batch(ctypes.c_void_p(indices.data_ptr()), n, int(num_pixel_rays), _ptr(table), v, h, w,
+                                      _ptr(images), _ptr(tables[0]), _ptr(tables[1]), _ptr(tables[2]), int(ndc), float(near),
+                                      float(far), float(near_ndc), float(far_ndc), ctypes.byref(b), _stream())
+    _lib.check(st, 'snerf_assemble_batch')
+    return out
+
+
+def shuffled_indices(seed: int, epoch: int, first: int, count: int, domain: int, device, candidates: Optional[Tensor] = None,
+                     num_views: int = 0, resolution=(0, 0), crop=None) -> Tensor:
+    """Positions [first, first+count) of epoch ``epoch``'s permutation of the candidate pixels, as global pixel indices."""
+    lib = _lib.load()
+    h, w = int(resolution[0]), int(resolution[1])
+    y0, y1, x0, x1 = crop if crop is not None else (0, h, 0, w)
+    if candidates is not None:
+        if not candidates.is_cuda or candidates.dtype != torch.int64 or tuple(candidates.shape) != (domain,):
+            raise RuntimeError(f'candidates: expected int64 GPU tensor ({domain},), got {candidates.dtype} {tuple(candidates.shape)}')
+        candidates = candidates.contiguous()
+        device = candidates.device
+    out = torch.empty((count,), dtype=torch.int64, device=device)
+    if count == 0:
+        return out
+    with torch.cuda.device(out.device):
+        st = lib.snerf_shuffled_indices(int(seed) & (2 ** 64 - 1), int(epoch), int(first), int(count), int(domain),
+                                        ctypes.c_void_p(0 if candidates is None else candidates.data_ptr()), int(num_views), h, w,
+                                        int(y0), int(y1), int(x0), int(x1), ctypes.c_void_p(out.data_ptr()), _stream())
+    _lib.check(st, 'snerf_shuffled_indices')
+    return out
+
+
+def random_uniform(seed: int, stream_id: int, first_row: int, shape, device) -> Tensor:
+    """[0,1) Philox draws of shape (rows, width...); element (r, c) depends only on (seed, stream_id, first_row + r, c)."""
+    lib = _lib.load()
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    rows = int(shape[0])
+    width = out.numel() // rows if rows else 1
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(out.device):
+        st = lib.snerf_random_uniform(int(seed) & (2 ** 64 - 1), int(stream_id) & 0xFFFFFFFF, int(first_row), rows, max(width, 1),
+                                      _ptr(out), _stream())
+    _lib.check(st, 'snerf_random_uniform')
+    return out
+
+
+def random_normal(seed: int, stream_id: int, first_row: int, shape, device, scale: float = 1.0) -> Tensor:
+    lib = _lib.load()
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    rows = int(shape[0])
+    width = out.numel() // rows if rows else 1
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(out.device):
+        st = lib.snerf_random_normal(int(seed) & (2 ** 64 - 1), int(stream_id) & 0xFFFFFFFF, int(first_row), rows, max(width, 1),
+                                     float(scale), _ptr(out), _stream())
+    _lib.check(st, 'snerf_random_normal')
+    return out

@@ -1,0 +1,125 @@
+"""Batch-assembly row on the GPU: assembler against batches produced by the reference's
+DataPreprocessor (G9), index stream and draws against the CPU oracle and their defining properties."""
+import numpy
+import pytest
+import torch
+
+from oracle import batch_oracle
+from simplenerf_amd import ops
+from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
+from tests import util
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+BATCH_KEYS = ('rays_o', 'rays_d', 'view_dirs', 'rays_o_ndc', 'rays_d_ndc', 'pixel_id', 'target_rgb', 'near', 'far',
+              'near_ndc', 'far_ndc', 'sparse_depth_values', 'sparse_depth_errors', 'sparse_depth_values_ndc',
+              'indices_mask_nerf', 'indices_mask_sparse_depth')
+
+
+def golden_scene(g, sparse=True):
+    scene = {k: g[k] for k in ('poses', 'intrinsics', 'images')}
+    scene.update(resolution=tuple(int(v) for v in g['resolution']), near=float(g['near']), far=float(g['far']),
+                 near_ndc=float(g['near_ndc']), far_ndc=float(g['far_ndc']), frame_nums=[0, 1, 2])
+    if sparse:
+        scene.update(sparse_depths=g['sparse_depths'], sparse_errors=g['sparse_errors'], sparse_depths_ndc=g['sparse_depths_ndc'])
+    return scene
+
+
+def loader_configs(**extra):
+    return {'data_loader': {'ndc': True, 'num_rays': 96, **extra}, 'device': [0]}
+
+
+def test_assembler_reproduces_reference_batches_bit_for_bit():
+    g = util.load('batch_assembly.npz')
+    asm = BatchAssembler(loader_configs(sparse_depth={'num_rays': 32}), golden_scene(g), DEV)
+    for b in range(3):
+        idx = torch.from_numpy(g[f'batch{b}_indices'])
+        batch = asm.get_next_batch(b, indices=idx[:96], indices_sparse=idx[96:])
+        assert batch['iter_num'] == b and batch['num_frames'] == 3
+        assert torch.equal(batch['indices'].cpu(), idx)
+        for k in BATCH_KEYS:
+            got = batch[k].cpu().numpy()
+            assert got.dtype == g[f'batch{b}_{k}'].dtype and got.shape == g[f'batch{b}_{k}'].shape, k
+            assert numpy.array_equal(got, g[f'batch{b}_{k}']), (b, k)
+        common = batch['common_data']
+        assert common['resolution'] == (48, 64) and tuple(common['images'].shape) == (1, 3, 48, 64, 3)
+        assert torch.equal(common['poses'][0].cpu(), torch.from_numpy(g['poses']))
+    image = asm.get_next_batch(5, image_num=1)
+    assert 'indices_mask_sparse_depth' not in image and 'sparse_depth_values' not in image
+    for k in ('indices', 'rays_o', 'rays_d_ndc', 'target_rgb', 'pixel_id', 'indices_mask_nerf'):
+        assert numpy.array_equal(image[k].cpu().numpy(), g[f'image1_{k}']), k
+
+
+def test_out_of_range_indices_keep_the_fill_value():
+    g = util.load('batch_assembly.npz')
+    asm = BatchAssembler(loader_configs(), golden_scene(g, sparse=False), DEV)
+    batch = asm.get_next_batch(0, indices=torch.tensor([5, -1, 3 * 48 * 64, 100]))
+    mask = batch['indices_mask_nerf'].cpu().numpy()
+    assert mask.tolist() == [True, False, False, True]
+    for k in ('rays_o', 'rays_d', 'view_dirs', 'rays_o_ndc', 'rays_d_ndc', 'target_rgb', 'near', 'far_ndc'):
+        assert (batch[k].cpu().numpy()[~mask] == -1).all(), k
+    assert (batch['pixel_id'].cpu().numpy()[~mask] == -1).all()
+
+
+@pytest.mark.parametrize('domain', [1, 3, 1000, 9216, 2 ** 16 + 1, 3 * 756 * 1008])
+def test_index_stream_matches_oracle_and_permutes(domain):
+    got = ops.shuffled_indices(11, 2, 0, domain, domain, DEV, num_views=1, resolution=(1, domain)).cpu().numpy()
+    if domain <= 2 ** 17:
+        assert numpy.array_equal(got, batch_oracle.shuffled_indices(11, 2, 0, domain, domain, num_views=1, height=1, width=domain))
+    else:
+        first = batch_oracle.shuffled_indices(11, 2, 0, 4096, domain, num_views=1, height=1, width=domain)
+        assert numpy.array_equal(got[:4096], first)
+    seen = numpy.zeros(domain, dtype=numpy.int32)
+    numpy.add.at(seen, got, 1)
+    assert (seen == 1).all()                                       # every candidate exactly once per epoch
+    part = ops.shuffled_indices(11, 2, domain // 3, domain - domain // 3, domain, DEV, num_views=1, resolution=(1, domain))
+    assert numpy.array_equal(part.cpu().numpy(), got[domain // 3:])
+
+
+def test_index_stream_crop_window_and_candidate_list():
+    g = util.load('batch_assembly.npz')
+    y0, y1, x0, x1 = batch_oracle.precrop_window(48, 64, 0.5)
+    domain = 3 * (y1 - y0) * (x1 - x0)
+    got = ops.shuffled_indices(5, 0, 0, domain, domain, DEV, num_views=3, resolution=(48, 64), crop=(y0, y1, x0, x1)).cpu().numpy()
+    assert numpy.array_equal(got, batch_oracle.shuffled_indices(5, 0, 0, domain, domain, num_views=3, height=48, width=64, crop=(y0, y1, x0, x1)))
+    assert numpy.array_equal(numpy.sort(got), g['precrop_candidates'])
+    cand = torch.from_numpy(g['sparse_candidates']).to(DEV)
+    got = ops.shuffled_indices(6, 1, 0, cand.shape[0], cand.shape[0], DEV, candidates=cand).cpu().numpy()
+    assert numpy.array_equal(numpy.sort(got), g['sparse_candidates'])
+    assert numpy.array_equal(got, batch_oracle.shuffled_indices(6, 1, 0, cand.shape[0], cand.shape[0], candidates=g['sparse_candidates']))
+
+
+def test_assembler_epochs_cover_every_candidate_and_shards_tile_the_batch():
+    g = util.load('batch_assembly.npz')
+    cfg = loader_configs(sparse_depth={'num_rays': 32}, precrop_fraction=0.5, precrop_iterations=10)
+    cfg['data_loader']['num_rays'] = 500
+    one = BatchAssembler(cfg, golden_scene(g), DEV)
+    halves = [BatchAssembler(cfg, golden_scene(g), DEV, rank=r, world_size=2) for r in range(2)]
+    pixel, sparse = [], []
+    for it in range(5):             # 2304 candidates / 500 per batch: the 5th batch is short and ends the epoch
+        batch = one.get_next_batch(it)
+        m = batch['indices_mask_nerf']
+        pixel.append(batch['indices'][m].cpu().numpy())
+        sparse.append(batch['indices'][batch['indices_mask_sparse_depth']].cpu().numpy())
+        parts = [h.get_next_batch(it) for h in halves]
+        for k in ('rays_o', 'target_rgb', 'sparse_depth_values', 'rays_d_ndc'):
+            both = torch.cat([p[k][p['indices_mask_nerf']] for p in parts] + [p[k][p['indices_mask_sparse_depth']] for p in parts])
+            assert torch.equal(both, torch.cat([batch[k][m], batch[k][~m]])), k
+    assert [len(p) for p in pixel] == [500, 500, 500, 500, 304] and one.epoch == 1 and one.i_batch == 0
+    assert numpy.array_equal(numpy.sort(numpy.concatenate(pixel)), g['precrop_candidates'])
+    assert numpy.array_equal(numpy.sort(numpy.concatenate(sparse)[:119]), g['sparse_candidates'])   # 119 sparse pixels: 3 full slices + 23
+    nxt = one.get_next_batch(5)['indices'][:500].cpu().numpy()
+    assert not numpy.array_equal(nxt, pixel[0])                       # new epoch, new order
+
+
+def test_draws_match_oracle_and_do_not_depend_on_sharding():
+    u = ops.random_uniform(9, 4, 0, (4096, 63), DEV)
+    assert numpy.array_equal(u.cpu().numpy(), batch_oracle.random_uniform(9, 4, 0, 4096, 63))
+    z = ops.random_normal(9, 5, 0, (4096, 190, 1), DEV, scale=1.5)
+    assert util.linf(z.cpu().numpy().reshape(4096, 190), batch_oracle.random_normal(9, 5, 0, 4096, 190, 1.5)) <= 1e-5
+    lo, hi = ops.random_normal(9, 5, 0, (1000, 190, 1), DEV, scale=1.5), ops.random_normal(9, 5, 1000, (3096, 190, 1), DEV, scale=1.5)
+    assert torch.equal(torch.cat([lo, hi]), z)
+    assert not torch.equal(ops.random_uniform(9, 6, 0, (4096, 63), DEV), u) and not torch.equal(ops.random_uniform(10, 4, 0, (4096, 63), DEV), u)
+    big = ops.random_normal(1, 0, 0, (1 << 20, 8), DEV)
+    assert abs(float(big.mean())) < 3e-3 and abs(float(big.std()) - 1) < 3e-3 and torch.isfinite(big).all()
+    assert ops.random_uniform(1, 0, 0, (0, 5), DEV).shape == (0, 5)

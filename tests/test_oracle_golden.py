@@ -239,3 +239,67 @@ def test_learning_rate_schedules_match_reference():
     for it, nerf, mip in zip(g['probe_iters'], g['nerf_lr'], g['mip_lr']):
         assert optim_oracle.nerf_learning_rate(5e-4, 250, int(it)) == float(nerf)
         assert optim_oracle.mipnerf_learning_rate(5e-4, 5e-6, 500000, 2500, 0.01, int(it)) == pytest.approx(float(mip), rel=1e-15)
+
+
+# ---------------------------------------------------------------- G9 batch assembly, index stream, draws
+from oracle import batch_oracle  # noqa: E402
+
+BATCH_KEYS = ('rays_o', 'rays_d', 'view_dirs', 'rays_o_ndc', 'rays_d_ndc', 'pixel_id', 'target_rgb', 'near', 'far',
+              'near_ndc', 'far_ndc', 'sparse_depth_values', 'sparse_depth_errors', 'sparse_depth_values_ndc',
+              'indices_mask_nerf', 'indices_mask_sparse_depth')
+
+
+def test_batch_oracle_matches_reference_batches_bit_for_bit():
+    g = util.load('batch_assembly.npz')
+    res = tuple(int(v) for v in g['resolution'])
+    cache = batch_oracle.build_ray_cache(g['poses'], g['intrinsics'], res, float(g['near']), True)
+    for b in range(3):
+        idx = g[f'batch{b}_indices']
+        out = batch_oracle.assemble_batch(idx, 96, cache, g['images'], float(g['near']), float(g['far']), True,
+                                          float(g['near_ndc']), float(g['far_ndc']), g['sparse_depths'], g['sparse_errors'],
+                                          g['sparse_depths_ndc'])
+        for k in BATCH_KEYS:
+            assert out[k].dtype == g[f'batch{b}_{k}'].dtype, k
+            assert numpy.array_equal(out[k], g[f'batch{b}_{k}']), (b, k)
+    out = batch_oracle.assemble_batch(g['image1_indices'], g['image1_indices'].size, cache, g['images'], float(g['near']),
+                                      float(g['far']), True)
+    for k in ('rays_o', 'rays_d_ndc', 'target_rgb', 'pixel_id', 'indices_mask_nerf'):
+        assert numpy.array_equal(out[k], g[f'image1_{k}']), k
+    assert not bool(g['image1_has_sparse']) and numpy.array_equal(g['image1_indices'], numpy.arange(res[0] * res[1]) + res[0] * res[1])
+    # candidate sets: sparse-depth pixels and the pre-crop window
+    assert numpy.array_equal(numpy.where(g['sparse_depths'].reshape(-1) > 0)[0], g['sparse_candidates'])
+    y0, y1, x0, x1 = batch_oracle.precrop_window(res[0], res[1], 0.5)
+    domain = 3 * (y1 - y0) * (x1 - x0)
+    window = batch_oracle.shuffled_indices(5, 0, 0, domain, domain, num_views=3, height=res[0], width=res[1], crop=(y0, y1, x0, x1))
+    assert numpy.array_equal(numpy.sort(window), g['precrop_candidates'])
+    assert int(g['after_precrop_count']) == g['precrop_candidates'].size    # the reference never leaves the crop
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors, philox4x32 with 10 rounds."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for counter, key, expect in kat:
+        got = batch_oracle.philox4x32_10(numpy.array(counter, dtype=numpy.uint32), key)
+        assert tuple(int(v) for v in got) == expect
+
+
+@pytest.mark.parametrize('domain', [1, 2, 3, 17, 1000, 9216, 2 ** 16, 2 ** 16 + 1])
+def test_index_stream_is_a_permutation_per_epoch(domain):
+    a = batch_oracle.shuffled_positions(11, 0, 0, domain, domain)
+    assert numpy.array_equal(numpy.sort(a), numpy.arange(domain))
+    pieces = numpy.concatenate([batch_oracle.shuffled_positions(11, 0, s, min(97, domain - s), domain) for s in range(0, domain, 97)])
+    assert numpy.array_equal(pieces, a)                               # slicing an epoch does not change it
+    if domain >= 1000:
+        b = batch_oracle.shuffled_positions(11, 1, 0, domain, domain)
+        assert (a == b).mean() < 0.01 and abs(float(numpy.corrcoef(a, numpy.arange(domain))[0, 1])) < 0.1
+
+
+def test_draw_statistics():
+    from scipy import stats
+    u = batch_oracle.random_uniform(9, 4, 0, 4096, 63).reshape(-1)
+    z = batch_oracle.random_normal(9, 5, 0, 4096, 63).reshape(-1)
+    assert 0.0 <= u.min() and u.max() < 1.0
+    assert stats.kstest(u, 'uniform').pvalue > 1e-3 and stats.kstest(z, 'norm').pvalue > 1e-3
+    assert numpy.array_equal(batch_oracle.random_uniform(9, 4, 100, 50, 63), u.reshape(4096, 63)[100:150])   # row-keyed
