@@ -14,9 +14,12 @@ forward, the activation-keeping training forward and the backward dgrad chain --
 Differences from the reference that a caller can observe:
   * ``model.chunk`` / ``model.netchunk`` are accepted and ignored -- the kernels tile the work themselves and the
     results do not depend on chunking;
-  * training-mode randomness (stratified jitter, inverse-CDF ``u``, density noise) is drawn on the device
-    (``torch.rand``/``randn`` on the GPU generator) instead of on the CPU generator; ``set_random_draws`` injects
-    explicit draws (used by the parity tests to replay the reference's CPU stream);
+  * training-mode randomness (stratified jitter, inverse-CDF ``u``, density noise) is drawn on the device by the
+    library's counter-based Philox4x32-10 (snerf_random_uniform / snerf_random_normal) instead of on the CPU
+    generator: element (ray, sample) of a draw is a function of (``configs['seed']``, number of training forwards so
+    far, kind of draw, ``input_batch['row_offset']`` + ray, sample) only, so a rank that renders rows
+    [row_offset, row_offset+n) of a batch draws what a single process would for those rows.  ``set_random_draws``
+    injects explicit draws (used by the parity tests to replay the reference's CPU stream);
   * ``predict_visibility`` (off in every shipped config) is not built;
   * gradients flow from ``rgb_*``, ``acc_*``, ``depth_*``, ``depth_ndc_*`` (incl. the augmentation-prefixed ones) and
     ``raw_sigma_*`` / ``raw_rgb*_*`` to the parameters -- a superset of what the shipped losses read (SURVEY 8a row
@@ -34,6 +37,8 @@ from .. import ops
 
 Tensor = torch.Tensor
 _SKIP_AFTER = 4  # reference: self.skips = [4]
+_DRAW_KINDS = ('t_rand', 'u', 'noise_coarse', 'noise_points_augmentation', 'noise_views_augmentation', 'noise_fine',
+               'noise_points_augmentation_fine', 'noise_views_augmentation_fine')
 
 
 class MlpParameters(torch.nn.Module):
@@ -145,6 +150,8 @@ class SimpleNeRFHip(torch.nn.Module):
         self.precision = ops.PRECISIONS[precision]
         self._packed: Dict[str, tuple] = {}
         self._draws: Optional[dict] = None
+        self.seed = int(configs.get('seed', 0))
+        self._train_calls = 0   # training-mode forwards so far: selects the Philox stream of each draw
 
     # ------------------------------------------------------------------------------------------
     def set_random_draws(self, draws: Optional[dict]) -> None:
@@ -191,15 +198,21 @@ class SimpleNeRFHip(torch.nn.Module):
         noise_std = float(mcfg['raw_noise_std'])
         perturb = bool(mcfg['perturb'] > 0.) and training
 
+        row_offset = int(batch.get('row_offset', 0))
+        call = self._train_calls
+        if training and draws is None:
+            self._train_calls += 1
+
         def draw(key, shape, normal):
             if not training:
                 return None
             if draws is not None:
                 t = draws.get(key)
                 return None if t is None else t.to(dev)
+            stream = call * len(_DRAW_KINDS) + _DRAW_KINDS.index(key)
             if normal:
-                return torch.randn(shape, device=dev) * noise_std if noise_std > 0. else None
-            return torch.rand(shape, device=dev) if perturb else None
+                return ops.random_normal(self.seed, stream, row_offset, shape, dev, noise_std) if noise_std > 0. else None
+            return ops.random_uniform(self.seed, stream, row_offset, shape, dev) if perturb else None
 
         out: Dict[str, Tensor] = {}
 

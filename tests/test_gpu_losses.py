@@ -23,7 +23,7 @@ def test_fused_losses_match_reference(case):
     assert inp['common_data']['poses'].dim() == 3          # un-replicated in place, like the reference
     assert float(losses["TotalLoss"].detach()) == pytest.approx(float(g['TotalLoss']), rel=REL, abs=1e-9)
     for cfg in configs['losses']:
-        assert float(losses[cfg['name']]['loss_value']) == pytest.approx(float(g[f"value_{cfg['name']}"]), rel=REL, abs=1e-9), cfg['name']
+        assert float(losses[cfg['name']]['loss_value'].detach()) == pytest.approx(float(g[f"value_{cfg['name']}"]), rel=REL, abs=1e-9), cfg['name']
     losses['TotalLoss'].backward()
     for k in util.LOSS_OUTPUT_KEYS:
         grad = out[k].grad

@@ -185,6 +185,29 @@ def test_train_forward_with_device_rng_is_statistically_sane():
     assert float((a['raw_sigma_coarse'] != b['raw_sigma_coarse']).float().mean()) > 0.3
 
 
+def test_training_draws_do_not_depend_on_how_rays_are_sharded():
+    """Philox draws are keyed by (seed, training call, kind, row_offset + ray, sample): two ranks that each take half of
+    a batch produce, row for row, what one process produces for the whole batch -- and another seed does not."""
+    cfg = synth.make_configs('config3')
+    g = util.load('e2e_config3_train_rand_plain.npz')
+    batch = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
+    n = batch['rays_o'].shape[0]
+    half = n // 2
+    keys = ('rgb_fine', 'depth_fine', 'z_vals_coarse', 'z_vals_fine', 'raw_sigma_coarse', 'points_augmentation_rgb_coarse',
+            'views_augmentation_depth_coarse')
+    with torch.no_grad():
+        whole = build(cfg, g).train()(batch)
+        parts = []
+        for lo, hi in ((0, half), (half, n)):
+            shard = {k: v[lo:hi] for k, v in batch.items()}
+            shard['row_offset'] = lo
+            parts.append(build(cfg, g).train()(shard))
+        other = build({**cfg, 'seed': 1}, g).train()(batch)
+    for k in keys:
+        assert torch.equal(torch.cat([p[k] for p in parts]), whole[k]), k
+    assert not torch.equal(other['z_vals_coarse'], whole['z_vals_coarse'])
+
+
 def test_cpu_tensors_are_rejected_not_silently_computed():
     cfg = synth.make_configs('config1')
     model = get_model(cfg, None).eval()  # parameters left on the CPU
