@@ -114,3 +114,37 @@ def allreduce_gradients(parameters, world_size: int, group=None) -> None:
         n = p.grad.numel()
         p.grad.copy_(flat[offset:offset + n].view_as(p.grad))
         offset += n
+
+
+def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch_size: Optional[int] = None,
+                   world_size: int = 1, group=None) -> Dict[str, Tensor]:
+    """One optimisation step over ``input_batch`` the way the reference's trainer does it (Trainer.train_one_iter,
+    src/Trainer01.py:60-107): gradients cleared, the batch cut into consecutive sub-batches, ``model`` ->
+    ``compute_losses`` -> ``TotalLoss.backward()`` per sub-batch (gradients accumulate: the step minimises the SUM of
+    the sub-batch means), one ``optimizer.step()``.  With ``world_size`` > 1 the accumulated gradients are averaged
+    over ranks by one all-reduce before the step.  Returns the summed loss values as device tensors (the reference
+    calls ``.item()`` on each, a host sync per loss per sub-batch; the caller decides when to read them)."""
+    optimizer.zero_grad(set_to_none=True)
+    n = input_batch['rays_o'].shape[0]
+    sub = int(sub_batch_size or n)
+    totals: Dict[str, Tensor] = {}
+    base = int(input_batch.get('row_offset', 0))
+    for start in range(0, n, sub):
+        piece = {}
+        for key, value in input_batch.items():
+            if isinstance(value, torch.Tensor):
+                piece[key] = value[start:start + sub]
+            elif key == 'common_data':
+                piece[key] = dict(value)
+            else:
+                piece[key] = value
+        piece['row_offset'] = base + start
+        losses = loss_computer.compute_losses(piece, model(piece))
+        losses['TotalLoss'].backward()
+        for name, entry in losses.items():
+            value = entry['loss_value'] if isinstance(entry, dict) else entry
+            value = value.detach() if isinstance(value, torch.Tensor) else torch.as_tensor(float(value))
+            totals[name] = totals[name] + value if name in totals else value
+    allreduce_gradients(model.parameters(), world_size, group)
+    optimizer.step()
+    return totals

@@ -450,12 +450,16 @@ def adam_step(params: List[Tensor], grads: List[Optional[Tensor]], exp_avg: List
     n = len(params)
     if n == 0:
         return
-    for name, group in (('param', params), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
-        for t in group:
-            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+    f32 = torch.float32
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        for name, t in (('param', p), ('exp_avg', m), ('exp_avg_sq', v)):
+            if not t.is_cuda or t.dtype != f32 or not t.is_contiguous():
                 raise RuntimeError(f'adam_step: {name} must be a contiguous float32 GPU tensor, got {t.dtype} on {t.device}')
+        if g is not None and (not g.is_cuda or g.dtype != f32 or g.shape != p.shape):
+            raise RuntimeError(f'adam_step: grad must be a float32 GPU tensor shaped like its parameter, got {g.dtype} '
+                               f'{tuple(g.shape)} on {g.device}')
+    grads = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
     ptrs = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
-    grads = [None if g is None else _dev(g, 'grad', tuple(p.shape)) for g, p in zip(grads, params)]
     sizes = (ctypes.c_longlong * n)(*[p.numel() for p in params])
     with torch.cuda.device(params[0].device):
         st = lib.snerf_adam_step(ptrs(params), ptrs(grads), ptrs(exp_avg), ptrs(exp_avg_sq), sizes, n, int(step),

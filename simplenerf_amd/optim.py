@@ -23,12 +23,37 @@ class Adam(torch.optim.Optimizer):
                         capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False)
         super().__init__(params, defaults)
 
+    # ``step`` counts live as Python ints while training (90 host tensors incremented one by one would cost more than
+    # the update itself); the ``step`` tensors torch.optim.Adam keeps in its state are refreshed whenever the state
+    # is read or replaced, so checkpoints carry them as usual.
+    def _count(self, p) -> int:
+        counts = self.__dict__.setdefault('_counts', {})
+        if p not in counts:
+            state = self.state[p]
+            counts[p] = int(state['step']) if 'step' in state else 0
+        return counts[p]
+
+    def _sync_step_tensors(self):
+        for p, count in self.__dict__.get('_counts', {}).items():
+            if 'step' in self.state[p]:
+                self.state[p]['step'].fill_(float(count))
+
+    def state_dict(self):
+        self._sync_step_tensors()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.__dict__['_counts'] = {}
+        self.__dict__['_tables'] = {}
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        counts = self.__dict__.setdefault('_counts', {})
         for group in self.param_groups:
             if group.get('weight_decay', 0) != 0 or group.get('amsgrad', False) or group.get('maximize', False):
                 raise NotImplementedError('weight_decay / amsgrad / maximize are not built')
@@ -41,10 +66,13 @@ class Adam(torch.optim.Optimizer):
                     state['step'] = torch.tensor(0.0, dtype=torch.float32)
                     state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state['step'] += 1
-                by_step.setdefault(int(state['step']), []).append(p)
+                counts[p] = self._count(p) + 1
+                by_step.setdefault(counts[p], []).append(p)
             beta1, beta2 = group['betas']
             for step, ps in by_step.items():
                 ops.adam_step([p.data for p in ps], [p.grad for p in ps], [self.state[p]['exp_avg'] for p in ps],
                               [self.state[p]['exp_avg_sq'] for p in ps], step, group['lr'], beta1, beta2, group['eps'])
+                # the kernel wrote the parameters behind autograd's back: bump their version counters, as an in-place
+                # torch op would, so that anything keyed on them (the model's packed-weight cache) sees the change
+                torch.autograd.graph.increment_version(ps)
         return loss

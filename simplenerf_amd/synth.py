@@ -304,3 +304,32 @@ def optim_case(seed: int = 0) -> dict:
         grads.append(step_grads)
     grads[0][0][:4] = [1e-22, -3e-20, 0.0, 1e-30]
     return {'params': params, 'grads': grads, 'iters': iters, 'record': (1, 2, 6)}
+
+
+def training_scene(seed: int = 0, num_views: int = 3, height: int = 756, width: int = 1008, sparse_fraction: float = 2e-3) -> dict:
+    """``synth_scene`` at a training resolution in the form ``BatchAssembler`` takes, plus dense sparse-depth tables
+    (true plane depth + noise on a random ``sparse_fraction`` of the pixels, -1 elsewhere)."""
+    scene = synth_scene(seed, num_views, height, width)
+    rng = numpy.random.RandomState(seed + 50)
+    has = rng.uniform(size=scene['true_depth'].shape) < sparse_fraction
+    depth = numpy.where(has, scene['true_depth'] + 0.05 * rng.standard_normal(has.shape), -1.0).astype(numpy.float32)
+    error = numpy.where(has, rng.uniform(0.1, 2.0, size=has.shape), -1.0).astype(numpy.float32)
+    return {**scene, 'near': 1.0, 'far': 6.0, 'near_ndc': 0.0, 'far_ndc': 1.0, 'frame_nums': list(range(num_views)),
+            'sparse_depths': depth.reshape(-1), 'sparse_errors': error.reshape(-1),
+            'sparse_depths_ndc': numpy.where(has, 1.0 - 1.0 / numpy.maximum(depth, 1e-3), -1.0).astype(numpy.float32).reshape(-1)}
+
+
+def training_configs(precision: str = 'fp32', num_rays: int = 2048, num_sparse: int = 2048, seed: int = 0) -> dict:
+    """The shipped LLFF experiment (src/NerfLlffTrainerTester01.py:245-440) restricted to the keys this build reads:
+    config-3 model, 2048 pixel rays + 2048 sparse-depth rays per iteration in sub-batches of 2048, the nine losses,
+    Adam(5e-4, 0.9, 0.999) with the NeRF exponential decay."""
+    cfg = make_configs('config3')
+    cfg['model']['hip_precision'] = precision
+    cfg['data_loader'].update(num_rays=num_rays, precrop_fraction=1, precrop_iterations=-1)
+    if num_sparse:
+        cfg['data_loader']['sparse_depth'] = {'num_rays': num_sparse}
+    cfg['losses'] = loss_configs()
+    cfg['optimizer'] = {'lr_decayer_name': 'NeRFLearningRateDecayer01', 'lr_initial': 5e-4, 'lr_decay': 250,
+                        'beta1': 0.9, 'beta2': 0.999}
+    cfg.update(sub_batch_size=2048, num_iterations=100000, seed=seed)
+    return cfg

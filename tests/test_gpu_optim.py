@@ -28,7 +28,7 @@ def test_adam_matches_reference_fixture_bit_for_bit():
                 assert numpy.array_equal(p.detach().cpu().numpy(), g[f'step{step}_param{i}']), (step, i)
                 assert numpy.array_equal(opt.state[p]['exp_avg'].cpu().numpy(), g[f'step{step}_exp_avg{i}']), (step, i)
                 assert numpy.array_equal(opt.state[p]['exp_avg_sq'].cpu().numpy(), g[f'step{step}_exp_avg_sq{i}']), (step, i)
-    assert float(opt.state[params[0]]['step']) == len(case['iters'])
+    assert float(opt.state_dict()['state'][0]['step']) == len(case['iters'])      # step tensors are refreshed on read
 
 
 def test_adam_on_the_full_model_matches_the_oracle_and_skips_gradless_tensors():
@@ -56,3 +56,24 @@ def test_adam_on_the_full_model_matches_the_oracle_and_skips_gradless_tensors():
     for i, k in enumerate(names):
         assert numpy.array_equal(params[i].detach().cpu().numpy(), ref_p[i]), k
     assert numpy.array_equal(params[7].detach().cpu().numpy(), sd[names[7]]) and len(opt.state[params[7]]) == 0
+
+
+def test_step_invalidates_the_models_packed_weights():
+    """The update happens outside autograd; the optimiser must still mark the parameters as changed so the renderer
+    re-packs them -- two training iterations must not render with the same weights."""
+    from simplenerf_amd import harness
+    from simplenerf_amd.models.ModelFactory import get_model
+    cfg = synth.make_configs('config1')
+    model = get_model(cfg, None).to(DEV).train()
+    batch = {k: torch.from_numpy(v).to(DEV) for k, v in synth.random_world_rays(64).items()}
+    opt = optim.Adam(list(model.parameters()), lr=1e-2)
+    versions = [p._version for p in model.parameters()]
+    with torch.no_grad():
+        before = model.eval()(batch)['rgb_coarse'].clone()
+    model.train()
+    (model(batch)['rgb_coarse'] ** 2).mean().backward()
+    opt.step()
+    assert all(p._version > v for p, v in zip(model.parameters(), versions))
+    with torch.no_grad():
+        after = model.eval()(batch)['rgb_coarse']
+    assert float((after - before).abs().max()) > 1e-4
