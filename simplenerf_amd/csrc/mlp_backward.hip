@@ -328,8 +328,13 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
     }
 }
 
-// B3: fixed-order sum over chunks, scattered into the reference-layout gradient tensors
+// B3: fixed-order sum over chunks, scattered into the reference-layout gradient tensors.  A block owns 64 consecutive
+// output elements; its four waves each fold a quarter of the chunks (coalesced 256-byte rows, eight independent loads
+// in flight per lane -- the small head/encoding jobs have few outputs but up to 512 chunks, so a single serial loop
+// per output would be pure HBM latency), then wave 0 adds the four quarter sums in order.  The summation tree depends
+// only on the chunk count, so results are bit-reproducible run to run.
 __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float* __restrict__ partial, GradPointers ptrs) {
+    __shared__ float quarter[4][64];
     const WgradJob& job = table.jobs[blockIdx.y];
     const float unscale =
         job.half ? 1.0f / wgrad_scale(__uint_as_float(reinterpret_cast<const unsigned*>(partial)[64 + job.dy_row0 / 32])) : 1.0f;
@@ -338,22 +343,52 @@ __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float
     const int in_cols = job.in_tiles * 32, rows_dy = job.out_tiles * 32;
     const long long nw = (long long)job.out_rows * job.in_rows;
     const long long total = nw + (grad_b ? job.out_rows : 0);
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        if (idx < nw) {
-            const int o = (int)(idx / job.in_rows), i = (int)(idx - (long long)o * job.in_rows);
-            const float* p = partial + job.partial_off + (long long)o * in_cols + i;
-            float s = 0.0f;
-            for (int c = 0; c < job.chunks; ++c) s += p[(long long)c * rows_dy * in_cols];
-            grad_w[(long long)o * job.w_ld + job.w_col + i] = s * unscale;
-        } else {
-            const int o = (int)(idx - nw);
-            const float* p = partial + job.bias_off + o;
-            float s = 0.0f;
-            for (int c = 0; c < job.chunks; ++c) s += p[(long long)c * rows_dy];
-            grad_b[o] = s;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = (int)((long long)job.chunks * wave / 4), c1 = (int)((long long)job.chunks * (wave + 1) / 4);
+    for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+        const long long idx = base + lane;
+        float s = 0.0f;
+        int o = 0, i = 0;
+        if (idx < total) {
+            const float* p;
+            long long stride;
+            if (idx < nw) {
+                o = (int)(idx / job.in_rows);
+                i = (int)(idx - (long long)o * job.in_rows);
+                p = partial + job.partial_off + (long long)o * in_cols + i;
+                stride = (long long)rows_dy * in_cols;
+            } else {
+                o = (int)(idx - nw);
+                p = partial + job.bias_off + o;
+                stride = rows_dy;
+            }
+            int c = c0;
+            for (; c + 8 <= c1; c += 8) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = p[(long long)(c + k) * stride];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += v[k];
+            }
+            for (; c < c1; ++c) s += p[(long long)c * stride];
         }
+        quarter[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && idx < total) {
+            const float sum = ((quarter[0][lane] + quarter[1][lane]) + quarter[2][lane]) + quarter[3][lane];
+            if (idx < nw) grad_w[(long long)o * job.w_ld + job.w_col + i] = sum * unscale;
+            else grad_b[o] = sum;
+        }
+        __syncthreads();
     }
+}
+
+// Register tile (NO, NI) per wave for a job of (out_tiles x in_tiles): the 4 waves must cover it as a WO x WI grid.
+inline void wave_tile(const WgradJob& j, int* no, int* ni) {
+    const int ot = j.out_tiles, it = j.in_tiles;
+    if (ot >= 4) { *no = ot / 4; *ni = it; return; }          // waves split the out tiles
+    if (ot == 2) { *no = 1; *ni = it >= 2 ? it / 2 : 1; return; }  // 2 x 2 wave grid (or 2 x 1)
+    *no = 1; *ni = it >= 4 ? it / 4 : 1;                        // one out tile: waves split the in tiles
 }
 
 struct Workspace {
@@ -370,22 +405,8 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples) {
         WgradJob j;
         j.dy_row0 = dy_row0; j.out_rows = out_rows; j.out_tiles = (out_rows + 31) / 32;
         j.x_row0 = x_row0; j.in_rows = in_rows; j.in_tiles = (in_rows + 31) / 32;
-        // workgroups per job ~ its share of the MFMA work: 256 for a full 8x8-tile product, at least 32
-        // Large products are MFMA-bound: ~256 workgroups, each with >= 32 wave blocks to amortise its 256 KB epilogue.
-        // Small products (heads, encodings) are DMA-latency-bound with tiny epilogues: as many workgroups as there are
-        // 8-block pieces, up to 512, so that every CU holds two of them.
-        const int tiles = j.out_tiles * j.in_tiles;
-        long long chunks, cap;
-        if (tiles >= 32) { chunks = 4LL * tiles; cap = blocks / 32; }
-        else { chunks = 512; cap = blocks / 8; }
-        if (chunks > cap) chunks = cap;
-        if (chunks < 1) chunks = 1;
         j.grad_rows = p.grad_rows(); j.act_rows = p.act_rows();
-        j.chunks = (int)chunks; j.blocks = blocks;
-        j.partial_off = off;
-        off += chunks * j.out_tiles * 32 * j.in_tiles * 32;
-        j.bias_off = off;
-        off += chunks * j.out_tiles * 32;
+        j.chunks = 1; j.blocks = blocks; j.partial_off = 0; j.bias_off = 0;
         j.w_param = w_param; j.w_ld = w_ld; j.w_col = w_col; j.b_param = b_param; j.half = 0;
         w.jobs.push_back(j);
     };
@@ -414,6 +435,38 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples) {
     std::stable_sort(w.jobs.begin(), w.jobs.end(), [](const WgradJob& a, const WgradJob& b) {
         return a.out_tiles * a.in_tiles > b.out_tiles * b.in_tiles;
     });
+    // Chunks (= workgroups, = partial sums to fold afterwards) per job.  Jobs of one register-tile class share a launch.
+    //  * Large products (>= 32 tiles) are MFMA-bound and hold one workgroup per CU (256 accumulator registers per
+    //    lane): the class as a whole gets ~256 workgroups, however many samples there are.  Every chunk ends with a
+    //    256 KB partial that the reduction has to read back, so more chunks than CUs only buys HBM traffic
+    //    (128 chunks x 8 trunk layers was 256 MB per backward call; now 64 MB).
+    //  * Small products (heads, encodings) are DMA-latency-bound with tiny epilogues: as many workgroups as there are
+    //    8-block pieces, up to 512, so that every CU holds two of them.
+    for (WgradJob& j : w.jobs) {
+        int no, ni;
+        wave_tile(j, &no, &ni);
+        long long chunks, cap;
+        if (j.out_tiles * j.in_tiles >= 32) {
+            int peers = 0;
+            for (const WgradJob& k : w.jobs) {
+                int ko, ki;
+                wave_tile(k, &ko, &ki);
+                peers += (ko == no && ki == ni && k.out_tiles * k.in_tiles >= 32);
+            }
+            chunks = (256 + peers - 1) / peers;
+            cap = blocks / 8;
+        } else {
+            chunks = 512;
+            cap = blocks / 8;
+        }
+        if (chunks > cap) chunks = cap;
+        if (chunks < 1) chunks = 1;
+        j.chunks = (int)chunks;
+        j.partial_off = off;
+        off += chunks * j.out_tiles * 32 * j.in_tiles * 32;
+        j.bias_off = off;
+        off += chunks * j.out_tiles * 32;
+    }
     w.partial_floats = off;
     w.total_floats = w.grads_floats + w.partial_floats;
     return w;
@@ -455,14 +508,6 @@ int launch_wgrad(const JobTable& table, const float* grads, const float* acts, f
     hipLaunchKernelGGL(kernel, dim3((unsigned)table.wg_start[table.count]), dim3(256), lds_bytes, stream, table, grads, acts,
                        partial, zeros);
     return snerf::check_launch("mlp_backward(wgrad)");
-}
-
-// Register tile (NO, NI) per wave for a job of (out_tiles x in_tiles): the 4 waves must cover it as a WO x WI grid.
-inline void wave_tile(const WgradJob& j, int* no, int* ni) {
-    const int ot = j.out_tiles, it = j.in_tiles;
-    if (ot >= 4) { *no = ot / 4; *ni = it; return; }          // waves split the out tiles
-    if (ot == 2) { *no = 1; *ni = it >= 2 ? it / 2 : 1; return; }  // 2 x 2 wave grid (or 2 x 1)
-    *no = 1; *ni = it >= 4 ? it / 4 : 1;                        // one out tile: waves split the in tiles
 }
 
 }  // namespace
@@ -579,7 +624,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     }
     GradPointers ptrs;
     for (int i = 0; i < num_params; ++i) ptrs.p[i] = param_grads[i];
-    hipLaunchKernelGGL(reduce_kernel, dim3(snerf::stride_grid(max_work, 256), table.count), dim3(256), 0, s, table, partial,
+    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)std::min<long long>((max_work + 63) / 64, 1024), table.count), dim3(256), 0, s, table, partial,
                        ptrs);
     rc = snerf::check_launch("mlp_backward(reduce)");
     if (rc != SNERF_OK) return rc;
