@@ -36,15 +36,17 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[U]) {
         for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
 }
 
-// dy[n] = (saved activation of the same feature > 0) ? acc : 0, in accumulator order
+// dy[n] = (the forward's activation of the same feature was > 0) ? acc : 0, in accumulator order.  The signs come
+// from the mask words the training forward wrote (MlpPlan::act_mask): 4 bytes per lane per two tiles instead of
+// re-reading the 32-sample x 32-feature activation tiles (1 KB instead of 32 KB per layer and wave block).
 template <int U>
-__device__ __forceinline__ void relu_backward(const f32x16 (&acc)[U], const float* __restrict__ act_tile, int lane,
+__device__ __forceinline__ void relu_backward(const f32x16 (&acc)[U], const unsigned* __restrict__ masks, int t0, int lane,
                                               float (&dy)[U * 16]) {
-    const int j = lane & 31, half = lane >> 5;
 #pragma unroll
-    for (int n = 0; n < U * 16; ++n) {
-        const int f = 32 * (n >> 4) + (n & 3) + 8 * ((n & 15) >> 2) + 4 * half;
-        dy[n] = act_tile[f * 32 + j] > 0.0f ? acc[n >> 4][n & 15] : 0.0f;
+    for (int u = 0; u < U; u += 2) {
+        const unsigned word = masks[((t0 + u) >> 1) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) dy[16 * u + r] = (word >> r) & 1u ? acc[u + (r >> 4)][r & 15] : 0.0f;
     }
 }
 
@@ -60,7 +62,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_kernel(ChainArgs a)
     const long long block = (long long)blockIdx.x * 4 + wave;
     const long long first = block * 32 + (lane & 31);
     const bool live = first < a.total;
-    const float* acts = a.acts + block * a.act_rows * 32;
+    const unsigned* masks = reinterpret_cast<const unsigned*>(a.acts + (block * a.act_rows + a.act_mask) * 32);
     float* grads = a.grads + block * a.grad_rows * 32;
 
     // ---- head gradients (pre-activation), stored as rows 0..3 of the head tile -----------------------------------
@@ -82,7 +84,9 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_kernel(ChainArgs a)
     if (VIEWDEP) {
         // d hv = W_rgb^T dpre, masked by the views-layer ReLU (:699-706)
         const float* wv = a.packed + a.views_out_w;
-        const float* hv_tile = acts + a.act_hv * 32;
+        unsigned hv_bits[VT / 2];
+#pragma unroll
+        for (int p = 0; p < VT / 2; ++p) hv_bits[p] = masks[((a.depth * WT) / 2 + p) * 64 + lane];
         float dyv[VT * 16];
 #pragma unroll
         for (int g = 0; g < VT * 4; ++g) {
@@ -91,9 +95,9 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_kernel(ChainArgs a)
             f32x4 w2 = *reinterpret_cast<const f32x4*>(wv + 2 * VT * 32 + 8 * g + 4 * half);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int f = 8 * g + 4 * half + q;
                 const float v = fmaf(w2[q], dhead[3], fmaf(w1[q], dhead[2], w0[q] * dhead[1]));
-                dyv[4 * g + q] = hv_tile[f * 32 + (lane & 31)] > 0.0f ? v : 0.0f;
+                const int n = 4 * g + q;   // register 16u + r of the views tile u
+                dyv[n] = (hv_bits[n >> 5] >> (n & 31)) & 1u ? v : 0.0f;
             }
         }
         store_acc_tile(dyv, grads + a.grad_yv * 32, lane);
@@ -128,7 +132,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_kernel(ChainArgs a)
     // ---- trunk, last layer first: dY_l = dh_{l+1} . [h_{l+1} > 0];  dh_l = W_l[:, h-columns]^T dY_l -------------
 #pragma unroll 1
     for (int l = a.depth - 1; l >= 0; --l) {
-        relu_backward<WT>(acc, acts + (a.act_h1 + l * a.width) * 32, lane, dy);
+        relu_backward<WT>(acc, masks, l * WT, lane, dy);
         store_acc_tile(dy, grads + (l * a.width) * 32, lane);
         if (l == 0) break;
         zero_acc<WT>(acc);
@@ -544,7 +548,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     a.packed = packed; a.acts = saved_acts; a.sigma = sigma; a.rgb = rgb; a.d_sigma = d_sigma; a.d_rgb = d_rgb;
     a.grads = grads; a.total = total; a.depth = plan.depth; a.width = plan.width;
     a.dgrad_offset = plan.dgrad_offset; a.pts_out_w = plan.pts_out_w(); a.views_out_w = plan.views_out_w();
-    a.act_rows = plan.act_rows(); a.act_h1 = plan.act_h(1); a.act_hv = plan.act_hv();
+    a.act_rows = plan.act_rows(); a.act_h1 = plan.act_h(1); a.act_hv = plan.act_hv(); a.act_mask = plan.act_mask();
     a.grad_rows = plan.grad_rows(); a.grad_feature = plan.grad_feature(); a.grad_yv = plan.grad_yv();
     a.grad_head = plan.grad_head();
     // partial[0..64): zero page for padded staging rows; partial[64..192): per-region max |dY| (f16x3)

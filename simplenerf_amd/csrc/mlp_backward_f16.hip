@@ -1,7 +1,7 @@
 // K7b (split-precision variant) -- the backward "dgrad" chain of the fused MLP on the fp16 matrix cores.
 //
 // Same computation as mlp_backward_chain_kernel (mlp_backward.hip): dX^T = W^T . dY^T layer by layer in reverse, ReLU
-// masks from the saved activations, every dY written as a [feature][32-sample] fp32 tile for the weight-gradient kernel.
+// masks from the forward's sign-bit words, every dY written as a [feature][32-sample] fp32 tile for the weight-gradient kernel.
 // Same arithmetic as mlp_forward_f16.hip: each operand is an fp16 hi/lo pair and each product is three MFMAs
 // (hi.hi + hi.lo + lo.hi) into an fp32 accumulator; W^T is pre-split at pack time (MlpPlan::half_dgrad_stages) and
 // streamed through the 3-slot LDS ring, one 32-row IN-feature tile (all of its k-steps over the OUT features) per unit.
@@ -64,16 +64,6 @@ __device__ __forceinline__ void renormalise(f32x16 (&acc)[U], float& gscale, flo
     gback = 1.0f / gscale;
 }
 
-// acc <- acc . [saved activation > 0]   (rows 32u..32u+31 of the activation tile)
-__device__ __forceinline__ void mask_tile(f32x16& acc, const float* __restrict__ rows, int lane) {
-    const int j = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-        acc[r] = rows[f * 32 + j] > 0.0f ? acc[r] : 0.0f;
-    }
-}
-
 template <int WT, int VT, bool VIEWDEP>
 __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfChainArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -105,7 +95,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
     const long long block = (long long)blockIdx.x * 4 + wave;
     const long long first = block * 32 + (lane & 31);
     const bool live = first < a.total;
-    const float* acts = a.acts + block * a.act_rows * 32;
+    const unsigned* masks = reinterpret_cast<const unsigned*>(a.acts + (block * a.act_rows + a.act_mask) * 32);
     float* grads = a.grads + block * a.grad_rows * 32;
 
     // ---- head gradients (pre-activation) -------------------------------------------------------------------------
@@ -134,7 +124,6 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
     if (VIEWDEP) {
         // d hv = W_rgb^T dpre masked by the views-layer ReLU -> stored, split into the operand of the first product
         const float* wv = a.packed + a.views_out_w;
-        const float* hv_tile = acts + a.act_hv * 32;
         f16x8 vh[VK], vl[VK];
         f32x16 dyvs[VT];
 #pragma unroll
@@ -149,9 +138,10 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
                 for (int q = 0; q < 4; ++q)
                     dyv[4 * g + q] = fmaf(w2[q], dhead[3], fmaf(w1[q], dhead[2], w0[q] * dhead[1]));
             }
-            mask_tile(dyv, hv_tile + 32 * u * 32, lane);
-            store_tile_rows_scaled(dyv, grads + (a.grad_yv + 32 * u) * 32, lane, gback);
         }
+        apply_relu_masks<VT>(dyvs, masks, a.depth * WT, lane);
+#pragma unroll
+        for (int u = 0; u < VT; ++u) store_tile_rows_scaled(dyvs[u], grads + (a.grad_yv + 32 * u) * 32, lane, gback);
         renormalise<VT>(dyvs, gscale, gback, a.dy_max ? a.dy_max + a.grad_yv / 32 : nullptr, lane);
 #pragma unroll
         for (int u = 0; u < VT; ++u) split_tile<false>(dyvs[u], vh[2 * u], vl[2 * u], vh[2 * u + 1], vl[2 * u + 1]);
@@ -201,13 +191,10 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
     // ---- trunk, last layer first: dY_l = dh_{l+1} . [h_{l+1} > 0];  dh_l = W_l[:, h-columns]^T dY_l -------------
 #pragma unroll 1
     for (int l = a.depth - 1; l >= 0; --l) {
-        const float* h_tile = acts + (a.act_h1 + l * a.width) * 32;
         float* dy_tile = grads + (l * a.width) * 32;
+        apply_relu_masks<WT>(acc, masks, l * WT, lane);
 #pragma unroll
-        for (int u = 0; u < WT; ++u) {
-            mask_tile(acc[u], h_tile + 32 * u * 32, lane);
-            store_tile_rows_scaled(acc[u], dy_tile + 32 * u * 32, lane, gback);
-        }
+        for (int u = 0; u < WT; ++u) store_tile_rows_scaled(acc[u], dy_tile + 32 * u * 32, lane, gback);
         unsigned* region = a.dy_max ? a.dy_max + (l * a.width) / 32 : nullptr;
         if (l == 0) {
             if (region) publish_max(region, tiles_max<WT>(acc) * gback, lane);

@@ -23,7 +23,7 @@ struct MlpArgs {
     long long bias_offset, feature_bias, views_bias, pts_out_w, pts_out_b, views_out_w, views_out_b;
     // training only: saved-activation tiles, [wave block][act_rows][32 samples] (mlp_plan.h)
     float* acts;
-    int act_rows, act_pev, act_h1, act_feature, act_hv;
+    int act_rows, act_pev, act_h1, act_feature, act_hv, act_mask;
 };
 
 // Arguments of the backward chain kernels (fp32: mlp_backward.hip, f16x3: mlp_backward_f16.hip)
@@ -38,7 +38,7 @@ struct ChainArgs {
     long long total;
     int depth, width;
     long long dgrad_offset, pts_out_w, views_out_w;
-    int act_rows, act_h1, act_hv;
+    int act_rows, act_h1, act_hv, act_mask;
     int grad_rows, grad_feature, grad_yv, grad_head;
     unsigned* dy_max;  // f16x3: per dY region (index = first tile row / 32) the max |dY| over the call, as float bits
 };
@@ -77,6 +77,20 @@ __device__ __forceinline__ void load_acc_tile(float (&h)[N], const float* __rest
         const int f = 32 * (n >> 4) + (n & 3) + 8 * ((n & 15) >> 2) + 4 * half;
         h[n] = tile[f * 32 + j];
     }
+}
+// ReLU sign bits (see MlpPlan::act_mask): bit r of a tile's 16-bit field = accumulator register r of this lane > 0.
+__device__ __forceinline__ unsigned relu_bits(const float* __restrict__ h) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= (h[r] > 0.0f ? 1u : 0u) << r;
+    return m;
+}
+// registers h[16u + r] of U (even) tiles starting at tile index t0 (even) -> mask words of this wave block
+template <int N>
+__device__ __forceinline__ void store_relu_masks(const float (&h)[N], unsigned* __restrict__ masks, int t0, int lane) {
+#pragma unroll
+    for (int u = 0; u < N / 16; u += 2)
+        masks[((t0 + u) >> 1) * 64 + lane] = relu_bits(h + 16 * u) | (relu_bits(h + 16 * (u + 1)) << 16);
 }
 // positional-encoding registers -> rows in the reference's encoding order (pads skipped)
 template <int PAIRS, int NREG>

@@ -226,6 +226,28 @@ __device__ __forceinline__ void split_encoding(const float (&pe)[NREG], f16x8 (&
 }
 
 
+// ReLU sign bits of U (even) finished accumulator tiles -> the mask words of this wave block (MlpPlan::act_mask), and
+// their use in the backward chain: acc <- acc . [the forward's activation was > 0].
+template <int U>
+__device__ __forceinline__ void store_relu_masks(const f32x16* acc, unsigned* __restrict__ masks, int t0, int lane) {
+#pragma unroll
+    for (int u = 0; u < U; u += 2) {
+        unsigned word = 0;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) word |= (acc[u + (r >> 4)][r & 15] > 0.0f ? 1u : 0u) << r;
+        masks[((t0 + u) >> 1) * 64 + lane] = word;
+    }
+}
+template <int U>
+__device__ __forceinline__ void apply_relu_masks(f32x16* acc, const unsigned* __restrict__ masks, int t0, int lane) {
+#pragma unroll
+    for (int u = 0; u < U; u += 2) {
+        const unsigned word = masks[((t0 + u) >> 1) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) acc[u + (r >> 4)][r & 15] = (word >> r) & 1u ? acc[u + (r >> 4)][r & 15] : 0.0f;
+    }
+}
+
 // One finished accumulator tile -> rows 32u .. 32u+31 of a [feature][32-sample] fp32 tile (training: saved activations).
 template <bool RELU>
 __device__ __forceinline__ void store_tile_rows(const f32x16& acc, float* __restrict__ rows, int lane) {

@@ -65,8 +65,10 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
 
     // training: every layer's input is kept for the backward pass as a [feature][32-sample] tile of this wave block
     float* tile = nullptr;
+    unsigned* masks = nullptr;
     if (STORE) {
         tile = a.acts + ((long long)blockIdx.x * 4 + wave) * a.act_rows * 32;
+        masks = reinterpret_cast<unsigned*>(tile + a.act_mask * 32);
         store_pe_tile<snerf::kPointsPairs, snerf::kPointsKSteps>(pe, tile, lane);
         if (VIEWDEP) store_pe_tile<snerf::kViewsPairs, snerf::kViewsKSteps>(pev, tile + a.act_pev * 32, lane);
     }
@@ -78,14 +80,20 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
     load_bias<WT>(acc, bias, half);
     gemm_segment<WT, 2, WT>(acc, pe, st);
     to_operand<WT, true>(acc, h);
-    if (STORE) store_acc_tile(h, tile + a.act_h1 * 32, lane);
+    if (STORE) {
+        store_acc_tile(h, tile + a.act_h1 * 32, lane);
+        store_relu_masks(h, masks, 0, lane);
+    }
 #pragma unroll 1
     for (int l = 1; l < a.depth; ++l) {
         load_bias<WT>(acc, bias + (long long)l * a.width, half);
         if (l == 5) gemm_segment<WT, 2, WT>(acc, pe, st);  // skip connection: [encoding | h] (:662-663)
         gemm_segment<WT, WT, WT>(acc, h, st);
         to_operand<WT, true>(acc, h);
-        if (STORE) store_acc_tile(h, tile + (a.act_h1 + l * a.width) * 32, lane);
+        if (STORE) {
+            store_acc_tile(h, tile + (a.act_h1 + l * a.width) * 32, lane);
+            store_relu_masks(h, masks, l * WT, lane);
+        }
     }
 
     // ---- density (and view-independent colour) head -------------------------------------------------
@@ -112,7 +120,10 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
         gemm_segment<VT, 1, WT>(accv, pev, st);
         float hv[VT * 16];
         to_operand<VT, true>(accv, hv);
-        if (STORE) store_acc_tile(hv, tile + a.act_hv * 32, lane);
+        if (STORE) {
+            store_acc_tile(hv, tile + a.act_hv * 32, lane);
+            store_relu_masks(hv, masks, a.depth * WT, lane);
+        }
         const float* wv = a.packed + a.views_out_w;
         const float* bv = a.packed + a.views_out_b;
 #pragma unroll
@@ -169,7 +180,7 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     a.pts_out_w = plan.pts_out_w(); a.pts_out_b = plan.pts_out_b();
     a.views_out_w = plan.views_out_w(); a.views_out_b = plan.views_out_b();
     a.acts = saved_acts; a.act_rows = plan.act_rows(); a.act_pev = plan.act_pev(); a.act_h1 = plan.act_h(1);
-    a.act_feature = plan.act_feature(); a.act_hv = plan.act_hv();
+    a.act_feature = plan.act_feature(); a.act_hv = plan.act_hv(); a.act_mask = plan.act_mask();
     hipStream_t s = (hipStream_t)stream;
     if (precision == SNERF_PRECISION_F16X3) return snerf::mlp_forward_f16x3(plan, a, train, s);
     const int key = plan.wt * 100 + plan.vt * 10 + (plan.sigma_pe ? 1 : 0);

@@ -72,7 +72,11 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
     for (int k = 0; k < 3; ++k) x[k] = a.origins[ray * 3 + k] + a.dirs[ray * 3 + k] * z;
 
     float* tile = nullptr;  // training: this wave block's saved-activation tiles (fp32, same layout as the fp32 path)
-    if (STORE) tile = a.acts + ((long long)blockIdx.x * 4 + wave) * a.act_rows * 32;
+    unsigned* masks = nullptr;
+    if (STORE) {
+        tile = a.acts + ((long long)blockIdx.x * 4 + wave) * a.act_rows * 32;
+        masks = reinterpret_cast<unsigned*>(tile + a.act_mask * 32);
+    }
     f16x8 pe_h[4], pe_l[4], pev_h[2], pev_l[2];
     {
         float pe[snerf::kPointsKSteps];
@@ -120,6 +124,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
         if (single) heads_from(acc[u], u);
         if (STORE) store_tile_rows<true>(acc[u], tile + (a.act_h1 + 32 * u) * 32, lane);
     }
+    if (STORE) store_relu_masks<WT>(acc, masks, 0, lane);
 #pragma unroll
     for (int u = 0; u < WT; ++u) split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
 
@@ -137,6 +142,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
             if (last) heads_from(acc[u], u);
             if (STORE) store_tile_rows<true>(acc[u], tile + (a.act_h1 + l * a.width + 32 * u) * 32, lane);
         }
+        if (STORE) store_relu_masks<WT>(acc, masks, l * WT, lane);
 #pragma unroll
         for (int u = 0; u < WT; ++u) split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
     }
@@ -176,6 +182,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
 #pragma unroll
             for (int c = 0; c < 3; ++c) col[c] += tile_dot_relu(acc[u], wv + c * VT * 32 + 32 * u, half);
         }
+        if (STORE) store_relu_masks<VT>(acc, masks, a.depth * WT, lane);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoidf((col[c] + __shfl_xor(col[c], 32, 64)) + bo[c]);
     }

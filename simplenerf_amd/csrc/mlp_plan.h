@@ -55,7 +55,12 @@ struct MlpPlan {
     int act_h(int l) const { return 96 + (l - 1) * width; }  // l = 1 .. depth
     int act_feature() const { return 96 + depth * width; }
     int act_hv() const { return 96 + (depth + 1) * width; }
-    int act_rows() const { return 96 + (depth + 1) * width + (view_dependent ? views_width : 0); }
+    // ReLU sign bits of every hidden tile, kept next to the activations for the backward chain: tile t = l*(width/32)+u
+    // for trunk layer l's output (then the views layer's tiles); 16 bits per lane per tile, two tiles per dword, one
+    // dword-row of 64 lanes = 2 rows of 32 floats.  The chain reads these 1 KB per layer instead of 32 KB of activations.
+    int mask_tiles() const { return depth * (width / 32) + (view_dependent ? views_width / 32 : 0); }
+    int act_mask() const { return 96 + (depth + 1) * width + (view_dependent ? views_width : 0); }
+    int act_rows() const { return act_mask() + 2 * ((mask_tiles() + 1) / 2); }
     int grad_y(int l) const { return l * width; }             // l = 0 .. depth-1
     int grad_feature() const { return depth * width; }
     int grad_yv() const { return (depth + 1) * width; }

@@ -135,8 +135,23 @@ def test_f16x3_chain_arithmetic_with_identical_masks():
     sigma16, rgb16, saved16 = mlp.forward_train(o, d, v, z, None, ops.PRECISION_F16X3)
     rows = saved.numel() // (((n * s + 127) // 128) * 4 * 32)
     a, b = saved.reshape(-1, rows, 32), saved16.reshape(-1, rows, 32)
-    for r0, r1 in ((0, 63), (64, 91), (96, rows)):  # encodings, view encodings, every layer's activations (pads excluded)
+    mask_rows = 2 * ((8 * 8 + 4 + 1) // 2)   # ReLU sign-bit words of the 64 trunk + 4 views tiles close every block's tile
+    for r0, r1 in ((0, 63), (64, 91), (96, rows - mask_rows)):  # encodings, view encodings, every layer's activations
         assert float((a[:, r0:r1] - b[:, r0:r1]).abs().max()) <= 1e-5 * max(1.0, float(a[:, r0:r1].abs().max()))
+    # the sign bits agree except where a pre-activation is within rounding of zero, and they are exactly the signs of
+    # the saved (post-ReLU) activations: bit r of tile t, lane (j, half) <-> feature 32t' + (r&3) + 8(r>>2) + 4 half
+    wa = a[:, rows - mask_rows:].contiguous().view(torch.int32).reshape(a.shape[0], -1, 64)
+    wb = b[:, rows - mask_rows:].contiguous().view(torch.int32).reshape(a.shape[0], -1, 64)
+    differing = (wa ^ wb).cpu().numpy().view(numpy.uint32)
+    assert numpy.unpackbits(differing.view(numpy.uint8)).mean() < 1e-4
+    h1 = a[:, 96:96 + 256].reshape(-1, 8, 32, 32)            # layer 0's output: (block, tile, feature in tile, sample)
+    lanes = torch.arange(64, device=DEV)
+    for t in (0, 5):
+        word = wa[:, t // 2, :] >> (16 * (t % 2))
+        for r in (0, 7, 15):
+            f = (r & 3) + 8 * (r >> 2) + 4 * (lanes >> 5)
+            expect = h1[:, t, f, lanes & 31] > 0
+            assert torch.equal(((word >> r) & 1).bool(), expect), (t, r)
     assert util.rel_linf(sigma16, sigma) < 1e-5 and util.linf(rgb16, rgb) < 1e-5
     for scale in (1.0, 1e-6, 1e-9):
         spread = numpy.exp(4 * rng.standard_normal((n, s, 1)))
