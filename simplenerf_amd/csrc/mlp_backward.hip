@@ -187,6 +187,19 @@ __device__ __forceinline__ void split_fragment(const float* __restrict__ row, in
     }
 }
 
+// One LDS-DMA instruction: every lane moves 16 bytes from its own global address to lds_base + 16 * lane (1 KiB per wave).
+// Issued through inline assembly on purpose: for the builtin, the compiler's wait-count insertion cannot tell which LDS
+// bytes an outstanding DMA will write (the ping-pong buffer is selected at run time), so it puts `s_waitcnt vmcnt(0)`
+// in front of the first LDS read that follows -- i.e. it waits for the PREFETCH of the next block before computing on
+// the current one, and the kernel runs as DMA time + compute time instead of their maximum (checked in the ISA and by
+// ablation builds).  Here the only vmcnt wait is the explicit one at the top of each iteration.  m0 carries the LDS
+// base address of the instruction; nothing else in these kernels uses it.
+__device__ __forceinline__ void lds_dma_16(const float* src, const float* lds_dst) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds_dst);   // 32-bit LDS byte address
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(src) : "memory", "m0");
+}
+
 constexpr int kMaxJobs = 16;
 struct JobTable {
     int count;
@@ -246,8 +259,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
             } else if (r - rows_dy < job.in_rows) {
                 src = acts + (b * job.act_rows + job.x_row0 + (r - rows_dy)) * 32 + c * 4;
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + q * 256), 16, 0, 0);
+            lds_dma_16(src, dst + q * 256);
         }
     };
 
@@ -256,6 +268,9 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
     const int a_base = wo * NO * 1024;
     const int b_base = rows_dy * 32 + wi * NI * 1024;
 
+    // (read once, before any DMA is in flight: a global load inside the loop makes the compiler wait for vmcnt(0),
+    // i.e. for the prefetch of the next block as well)
+    const float gk = F16 ? wgrad_scale(__uint_as_float(reinterpret_cast<const unsigned*>(zeros)[64 + job.dy_row0 / 32])) : 1.0f;
     if (b0 < b1) stage(b0, lds);
     for (long long b = b0; b < b1; ++b) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -264,7 +279,6 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
         if (b + 1 < b1) stage(b + 1, lds + ((b - b0 + 1) & 1) * buf_floats);
         if (active && F16) {
             // fp16-split product: two k-steps of 16 samples; dY scaled by one power of two per region (wgrad_scale)
-            const float gk = wgrad_scale(__uint_as_float(reinterpret_cast<const unsigned*>(zeros)[64 + job.dy_row0 / 32]));
 #pragma unroll 1
             for (int kk = 0; kk < 2; ++kk) {
                 const int c0 = 4 * kk + 2 * half;
