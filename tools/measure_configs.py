@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the other BASELINE.json configurations on one MI355X (not bench lines; numbers quoted in DESIGN.md).
-    python tools/measure_configs.py > gpurun_out/configs.json"""
+    python tools/measure_configs.py > gpurun_out/configs.json        (SNERF_PREC=f16x3 for the split-precision kernels)"""
 import json
 import os
 import sys
@@ -17,7 +17,7 @@ FLOP = {'main': 2 * 593408, 'ptsaug': 2 * 577280, 'viewsaug': 2 * 492032, 'small
 
 
 def model_for(kind, train=False):
-    cfg = synth.make_configs(kind)
+    cfg = synth.with_overrides(synth.make_configs(kind), hip_precision=os.environ.get('SNERF_PREC', 'fp32'))
     m = get_model(cfg, None)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
@@ -65,6 +65,8 @@ def main():
         flop = 4096 * (64 * (FLOP['main'] + FLOP['ptsaug'] + FLOP['viewsaug']) + 192 * FLOP['main'])
         res.append({'config': 'config3: train-mode forward, 4096 rays, main c+f + points-aug + views-aug, perturb + noise',
                     'ms': dt * 1e3, 'rays_per_s': 4096 / dt, 'tflops': flop / dt / 1e12})
+    for r in res:
+        r['precision'] = os.environ.get('SNERF_PREC', 'fp32')
     print(json.dumps(res, indent=1))
 
 
