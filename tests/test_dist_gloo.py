@@ -81,3 +81,62 @@ def test_two_rank_gradient_average_equals_full_batch(tmp_path):
     marker = str(tmp_path / 'done')
     mp.spawn(_grad_worker, args=(2, _free_port(), marker), nprocs=2, join=True)
     assert open(marker).read() == 'ok'
+
+
+class _StandInModel(torch.nn.Module):
+    """The renderer's interface (dict in, dict out) around a tiny CPU network; records the row offsets it is given."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.net = torch.nn.Sequential(torch.nn.Linear(3, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+        self.seen = []
+
+    def forward(self, batch):
+        self.seen.append((int(batch['row_offset']), batch['rays_o'].shape[0]))
+        return {'rgb_coarse': torch.sigmoid(self.net(batch['rays_o']))}
+
+
+class _StandInLosses:
+    def compute_losses(self, batch, out):
+        mse = torch.mean(torch.square(out['rgb_coarse'] - batch['target_rgb']))
+        return {'MSE01': {'loss_value': mse}, 'TotalLoss': mse}
+
+
+def _train_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        gen = torch.Generator().manual_seed(3)
+        full = {'rays_o': torch.randn(16, 3, generator=gen), 'target_rgb': torch.rand(16, 3, generator=gen), 'iter_num': 0,
+                'common_data': {'resolution': (4, 4)}}
+        # one process, whole batch, two sub-batches of 8
+        ref = _StandInModel()
+        ref_opt = torch.optim.SGD(ref.parameters(), lr=0.1)
+        ref_totals = harness.train_one_iter(ref, _StandInLosses(), ref_opt, full, sub_batch_size=8)
+        assert ref.seen == [(0, 8), (8, 8)]
+        # two ranks: rank r holds rows [4r, 4r+4) of each sub-batch, i.e. the union over ranks is the same batch
+        rows = torch.cat([torch.arange(4 * rank, 4 * rank + 4), 8 + torch.arange(4 * rank, 4 * rank + 4)])
+        mine = {k: (v[rows] if isinstance(v, torch.Tensor) else v) for k, v in full.items()}
+        mine['row_offset'] = 100 * rank
+        model = _StandInModel()
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        totals = harness.train_one_iter(model, _StandInLosses(), opt, mine, sub_batch_size=4, world_size=world)
+        assert model.seen == [(100 * rank, 4), (100 * rank + 4, 4)]
+        for a, b in zip(model.parameters(), ref.parameters()):     # averaged gradients == full-batch gradients
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+        both = totals['TotalLoss'].clone()
+        dist.all_reduce(both)
+        assert torch.allclose(both / world, ref_totals['TotalLoss'], rtol=1e-5)
+        if rank == 0:
+            open(tmp, 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_iteration_equals_single_process(tmp_path):
+    """harness.train_one_iter (sub-batching, loss accumulation, one gradient all-reduce, optimiser step) on two ranks
+    that each hold half of every sub-batch reproduces the single-process parameters."""
+    marker = str(tmp_path / 'done')
+    mp.spawn(_train_worker, args=(2, _free_port(), marker), nprocs=2, join=True)
+    assert open(marker).read() == 'ok'
