@@ -64,7 +64,11 @@ def test_step_invalidates_the_models_packed_weights():
     from simplenerf_amd import harness
     from simplenerf_amd.models.ModelFactory import get_model
     cfg = synth.make_configs('config1')
-    model = get_model(cfg, None).to(DEV).train()
+    model = get_model(cfg, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    # a dense field (density head scaled up): with PyTorch's default initialisation most rays composite to exactly 0
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 5, 200.0, 8.0).items()})
+    model = model.to(DEV).train()
     batch = {k: torch.from_numpy(v).to(DEV) for k, v in synth.random_world_rays(64).items()}
     opt = optim.Adam(list(model.parameters()), lr=1e-2)
     versions = [p._version for p in model.parameters()]
@@ -76,4 +80,4 @@ def test_step_invalidates_the_models_packed_weights():
     assert all(p._version > v for p, v in zip(model.parameters(), versions))
     with torch.no_grad():
         after = model.eval()(batch)['rgb_coarse']
-    assert float((after - before).abs().max()) > 1e-4
+    assert float(before.abs().max()) > 0.1 and float((after - before).abs().max()) > 1e-4
