@@ -189,10 +189,13 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
         }
     }
     // ---- trunk, last layer first: dY_l = dh_{l+1} . [h_{l+1} > 0];  dh_l = W_l[:, h-columns]^T dY_l -------------
+    unsigned relu_words[WT / 2];   // sign bits of the layer whose dY is formed next; requested one layer ahead
+    load_relu_words<WT>(relu_words, masks, (a.depth - 1) * WT, lane);
 #pragma unroll 1
     for (int l = a.depth - 1; l >= 0; --l) {
         float* dy_tile = grads + (l * a.width) * 32;
-        apply_relu_masks<WT>(acc, masks, l * WT, lane);
+        mask_with_words<WT>(acc, relu_words);
+        if (l > 0) load_relu_words<WT>(relu_words, masks, (l - 1) * WT, lane);   // in flight during this layer's products
 #pragma unroll
         for (int u = 0; u < WT; ++u) store_tile_rows_scaled(acc[u], dy_tile + 32 * u * 32, lane, gback);
         unsigned* region = a.dy_max ? a.dy_max + (l * a.width) / 32 : nullptr;

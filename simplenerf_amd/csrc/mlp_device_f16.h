@@ -248,6 +248,21 @@ __device__ __forceinline__ void apply_relu_masks(f32x16* acc, const unsigned* __
     }
 }
 
+// The same in two steps, so that the words of the NEXT layer can be requested before a long stretch of matrix work and
+// their memory latency is hidden behind it (load_relu_words early, mask_with_words when the tiles are finished).
+template <int U>
+__device__ __forceinline__ void load_relu_words(unsigned (&words)[U / 2], const unsigned* __restrict__ masks, int t0, int lane) {
+#pragma unroll
+    for (int p = 0; p < U / 2; ++p) words[p] = masks[((t0 >> 1) + p) * 64 + lane];
+}
+template <int U>
+__device__ __forceinline__ void mask_with_words(f32x16* acc, const unsigned (&words)[U / 2]) {
+#pragma unroll
+    for (int u = 0; u < U; u += 2)
+#pragma unroll
+        for (int r = 0; r < 32; ++r) acc[u + (r >> 4)][r & 15] = (words[u >> 1] >> r) & 1u ? acc[u + (r >> 4)][r & 15] : 0.0f;
+}
+
 // One finished accumulator tile -> rows 32u .. 32u+31 of a [feature][32-sample] fp32 tile (training: saved activations).
 template <bool RELU>
 __device__ __forceinline__ void store_tile_rows(const f32x16& acc, float* __restrict__ rows, int lane) {
