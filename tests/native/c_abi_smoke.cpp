@@ -1,0 +1,124 @@
+// A torch-free consumer of the C ABI: plain HIP runtime + include/*.h, linked against libsimplenerf_hip.so.
+// Generates the rays of a small frame, their coarse depths, a shuffled epoch of pixel indices, Philox draws, one Adam
+// step and a display conversion, and checks invariants on the host.  Built and run by tests/test_gpu_native.py.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "simplenerf_hip.h"
+#include "simplenerf_train.h"
+
+#define HIP_OK(x)                                                                      \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) { std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } \
+    } while (0)
+#define SNERF_OK_(x)                                                                   \
+    do {                                                                               \
+        if ((x) != 0) { std::printf("ABI error at %s:%d: %s\n", __FILE__, __LINE__, snerf_last_error()); return 3; } \
+    } while (0)
+#define CHECK(cond)                                                                    \
+    do {                                                                               \
+        if (!(cond)) { std::printf("check failed at %s:%d: %s\n", __FILE__, __LINE__, #cond); return 4; } \
+    } while (0)
+
+template <typename T>
+static T* dev(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) std::abort();
+    return static_cast<T*>(p);
+}
+template <typename T>
+static std::vector<T> host(const T* d, size_t n) {
+    std::vector<T> h(n);
+    if (hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) std::abort();
+    return h;
+}
+
+int main() {
+    CHECK(snerf_abi_version() == SNERF_ABI_VERSION);
+    const int h = 24, w = 32;
+    const long long n = (long long)h * w;
+    const float intrinsic[9] = {40.f, 0.f, 16.f, 0.f, 40.f, 12.f, 0.f, 0.f, 1.f};
+    const float pose[16] = {1, 0, 0, 0.1f, 0, 1, 0, -0.2f, 0, 0, 1, 0.3f, 0, 0, 0, 1};
+
+    // K1 + K2
+    float *rays_o = dev<float>(3 * n), *rays_d = dev<float>(3 * n), *dirs = dev<float>(3 * n), *o_ndc = dev<float>(3 * n),
+          *d_ndc = dev<float>(3 * n);
+    SNERF_OK_(snerf_generate_rays(h, w, intrinsic, pose, 0.f, 1, 1.f, 0, n, rays_o, rays_d, dirs, o_ndc, d_ndc, nullptr));
+    float *near = dev<float>(n), *far = dev<float>(n), *depths = dev<float>(n * 16);
+    std::vector<float> zeros(n, 0.f), ones(n, 1.f);
+    HIP_OK(hipMemcpy(near, zeros.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(far, ones.data(), n * 4, hipMemcpyHostToDevice));
+    SNERF_OK_(snerf_coarse_depths(near, far, n, 16, 0, nullptr, depths, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    auto hd = host(dirs, 3 * n);
+    auto ho = host(rays_o, 3 * n);
+    auto hz = host(depths, n * 16);
+    for (long long i = 0; i < n; ++i) {
+        const float nrm = std::sqrt(hd[3 * i] * hd[3 * i] + hd[3 * i + 1] * hd[3 * i + 1] + hd[3 * i + 2] * hd[3 * i + 2]);
+        CHECK(std::fabs(nrm - 1.f) < 1e-6f);
+        CHECK(ho[3 * i] == 0.1f && ho[3 * i + 1] == -0.2f && ho[3 * i + 2] == 0.3f);
+        CHECK(hz[16 * i] == 0.f && hz[16 * i + 15] == 1.f && hz[16 * i + 7] < hz[16 * i + 8]);
+    }
+
+    // B2: one epoch of the index stream is a permutation of the pixels
+    long long* idx = dev<long long>(n);
+    SNERF_OK_(snerf_shuffled_indices(42, 0, 0, n, n, nullptr, 1, h, w, 0, h, 0, w, idx, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    auto hi = host(idx, n);
+    std::vector<int> seen(n, 0);
+    for (long long v : hi) { CHECK(v >= 0 && v < n); seen[v]++; }
+    for (int c : seen) CHECK(c == 1);
+
+    // B3: Philox known answer -- counter (row 0, block 0, stream 0), key 0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8
+    float* u = dev<float>(4);
+    SNERF_OK_(snerf_random_uniform(0, 0, 0, 1, 4, u, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    auto hu = host(u, 4);
+    const unsigned kat[4] = {0x6627e8d5u, 0xe169c58du, 0xbc57ac4cu, 0x9b00dbd8u};
+    for (int k = 0; k < 4; ++k) CHECK(hu[k] == (float)(kat[k] >> 8) * 5.9604644775390625e-8f);
+
+    // O1: one Adam step on two tensors (the second without a gradient is left alone)
+    std::vector<float> p0(1000, 1.f), g0(1000, 0.5f), p1(10, 2.f);
+    float *dp0 = dev<float>(1000), *dg0 = dev<float>(1000), *dm0 = dev<float>(1000), *dv0 = dev<float>(1000);
+    float *dp1 = dev<float>(10), *dm1 = dev<float>(10), *dv1 = dev<float>(10);
+    HIP_OK(hipMemcpy(dp0, p0.data(), 4000, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dg0, g0.data(), 4000, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dp1, p1.data(), 40, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(dm0, 0, 4000)); HIP_OK(hipMemset(dv0, 0, 4000)); HIP_OK(hipMemset(dm1, 0, 40)); HIP_OK(hipMemset(dv1, 0, 40));
+    float* params[2] = {dp0, dp1};
+    const float* grads[2] = {dg0, nullptr};
+    float* ms[2] = {dm0, dm1};
+    float* vs[2] = {dv0, dv1};
+    const long long sizes[2] = {1000, 10};
+    SNERF_OK_(snerf_adam_step(params, grads, ms, vs, sizes, 2, 1, 1e-3, 0.9, 0.999, 1e-8, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    auto q0 = host(dp0, 1000);
+    auto q1 = host(dp1, 10);
+    for (float v : q0) CHECK(std::fabs(v - (1.f - 1e-3f)) < 1e-6f);   // first Adam step moves by lr * sign(g)
+    for (float v : q1) CHECK(v == 2.f);
+
+    // f3: display conversion rounds half to even and clips
+    const float rgb[6] = {0.5f / 255.f, 1.5f / 255.f, 2.f, -1.f, 0.25f, 1.f};
+    const float dep[2] = {-3.f, 7.f};
+    float *drgb = dev<float>(6), *ddep = dev<float>(2), *ddep_out = dev<float>(2);
+    unsigned char* img = dev<unsigned char>(6);
+    HIP_OK(hipMemcpy(drgb, rgb, 24, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(ddep, dep, 8, hipMemcpyHostToDevice));
+    SNERF_OK_(snerf_to_display(drgb, ddep, 2, img, ddep_out, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    auto himg = host(img, 6);
+    auto hdep = host(ddep_out, 2);
+    CHECK(himg[0] == 0 && himg[1] == 2 && himg[2] == 255 && himg[3] == 0 && himg[4] == 64 && himg[5] == 255);
+    CHECK(hdep[0] == 0.f && hdep[1] == 7.f);
+
+    // errors are status codes with a message, not crashes
+    CHECK(snerf_coarse_depths(nullptr, nullptr, 4, 8, 0, nullptr, nullptr, nullptr) == SNERF_E_INVALID);
+    CHECK(snerf_last_error()[0] != 0);
+    std::printf("c_abi_smoke: OK\n");
+    return 0;
+}
