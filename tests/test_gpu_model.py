@@ -293,3 +293,42 @@ def test_full_frame_render_equals_blockwise_and_sharded_ranges():
         assert torch.equal(torch.cat([p[k] for p in parts], 0), direct[k])
     img, dep = harness.to_display(whole['rgb_coarse'], whole['depth_coarse'])
     assert img.shape == (n, 3) and img.dtype == torch.uint8 and float(dep.min()) >= 0
+
+
+def test_full_size_frame_properties_and_eight_way_shards():
+    """BASELINE config 2/4 at full size (fern 1008 x 756 = 762 048 rays, 64+128 samples, 8x256 coarse+fine) through
+    size-independent properties: sorted depths inside [0,1] whose fine set contains every coarse depth, non-negative
+    weights summing to acc <= 1, colours inside [0, acc], NDC depth inside [0,1]; the union of the eight per-rank ray
+    ranges of the sharded render is bit-identical to the unsharded frame; the f16x3 kernels agree with the fp32 ones to
+    the parity tolerance on all but the few rays whose resampling hit the sample_pdf discontinuity."""
+    from simplenerf_amd import harness
+    cfg = synth.make_configs('config2')
+    g = util.load('e2e_config2_consistent.npz')
+    model = build(cfg, g).eval()
+    cam = synth.camera('fern', 0)
+    h, w = cam['resolution']
+    n = h * w
+    assert n == 762048
+    rgb_blocks = []
+    with torch.no_grad():
+        for start in range(0, n, 65536):
+            count = min(65536, n - start)
+            out = model(harness.frame_batch(cam, True, DEV, start, count), retraw=True)
+            zc, zf, wf, acc, rgb = out['z_vals_coarse'], out['z_vals_fine'], out['weights_fine'], out['acc_fine'], out['rgb_fine']
+            assert zc.shape == (count, 64) and zf.shape == (count, 192)
+            assert bool((zf[:, 1:] >= zf[:, :-1]).all()) and float(zf.min()) >= 0.0 and float(zf.max()) <= 1.0
+            pos = torch.searchsorted(zf, zc.contiguous()).clamp(max=191)
+            assert torch.equal(torch.gather(zf, 1, pos), zc)                     # the merged set keeps every coarse depth
+            assert float(wf.min()) >= 0.0 and float((wf.sum(1) - acc).abs().max()) <= 1e-5 and float(acc.max()) <= 1.0 + 1e-5
+            assert float(rgb.min()) >= 0.0 and bool((rgb <= acc[:, None] + 1e-5).all())
+            assert float(out['depth_ndc_fine'].min()) >= 0.0 and float(out['depth_ndc_fine'].max()) <= 1.0 + 1e-5
+            assert all(torch.isfinite(v).all() for v in out.values())
+            rgb_blocks.append(rgb)
+    whole = torch.cat(rgb_blocks)
+    shards = [harness.render_rays_blockwise(model, cam, True, DEV, *harness.shard_range(n, r, 8), keys=('rgb_fine',))['rgb_fine']
+              for r in range(8)]
+    assert [s.shape[0] for s in shards] == [95256] * 8 and torch.equal(torch.cat(shards), whole)
+    fast = build(cfg, g, 'f16x3').eval()
+    other = harness.render_frame(fast, cam, True, DEV, keys=('rgb_fine',))['rgb_fine']
+    off = ((other - whole).abs().max(1)[0] > 1e-4).float().mean()
+    assert float(off) < 0.01, float(off)
