@@ -221,3 +221,37 @@ def test_losses_on_outputs_without_gradient_path_fail_loudly():
     assert not out['weights_coarse'].requires_grad and not out['depth_var_coarse'].requires_grad
     with pytest.raises(RuntimeError):
         out['depth_var_coarse'].sum().backward()
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+def test_full_size_training_batch_properties(precision):
+    """BASELINE config 5 at full size (4096 rays, four MLPs, 64 + 192 samples) through size-independent properties:
+    the gradient of a sum-type loss over the whole batch equals the accumulated gradients of its two 2048-ray halves
+    (the reference's sub-batching), doubles when the loss doubles, and is bit-reproducible run to run."""
+    from simplenerf_amd import harness
+    cfg = synth.with_overrides(synth.make_configs('config3'), perturb=False, raw_noise_std=0.0, hip_precision=precision)
+    model = get_model(cfg, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
+    model = model.to(DEV).train()
+    batch = harness.frame_batch(synth.camera('fern', 0), True, DEV, 300000, 4096)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    target = torch.rand((4096, 3), device=DEV, generator=gen)
+
+    def grads(rows, scale):
+        model.zero_grad(set_to_none=True)
+        for lo, hi in rows:
+            out = model({k: v[lo:hi] for k, v in batch.items()})
+            loss = sum(((out[k] - target[lo:hi]) ** 2).sum() for k in out if k.endswith(('rgb_coarse', 'rgb_fine')) and 'raw' not in k)
+            loss = loss + 0.1 * sum((out[k] ** 2).sum() for k in out if k.endswith(('depth_ndc_coarse', 'depth_ndc_fine')))
+            (scale * loss).backward()
+        return [p.grad.clone() for p in model.parameters()]
+
+    whole = grads([(0, 4096)], 1.0)
+    again = grads([(0, 4096)], 1.0)
+    halves = grads([(0, 2048), (2048, 4096)], 1.0)
+    double = grads([(0, 4096)], 2.0)
+    assert all(torch.isfinite(g).all() and float(g.abs().max()) > 0 for g in whole)
+    for a, b, c, d in zip(whole, again, halves, double):
+        assert torch.equal(a, b)                                              # fixed-order reductions
+        assert rel_to_max(c, a) < 1e-4 and rel_to_max(d, 2 * a) < 1e-5
