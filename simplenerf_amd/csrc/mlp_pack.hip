@@ -1,12 +1,41 @@
 // Weight packer: reference-layout parameters (nn.Linear weight (out,in) row-major + bias) -> the MFMA-operand-
 // ordered stream described in mlp_layout.h.  A pure permutation with zero fill; HBM-bound and tiny (2.4 MB per
 // 8x256 MLP), run once per parameter update.
+#include <algorithm>
+
 #include "mlp_plan.h"
 
 namespace {
 
-__global__ void __launch_bounds__(256) pack_segment_kernel(const float* __restrict__ w, snerf::Segment s,
-                                                           float* __restrict__ packed) {
+// Launch batching: the stream of one MLP has ~40 segments and ~36 f16x3 stages of a few KB each; one launch per piece
+// made a re-pack (needed after every optimiser step) ~95 tiny GPU operations.  Pieces are grouped into kernarg-sized
+// tables instead (blockIdx.y = piece), ~10 launches per re-pack.
+constexpr int kSegmentsPerLaunch = 16;
+struct SegmentTable {
+    const float* w[kSegmentsPerLaunch];
+    snerf::Segment seg[kSegmentsPerLaunch];
+};
+constexpr int kStagesPerLaunch = 8;
+struct StageTable {
+    const float* w[kStagesPerLaunch][3];
+    snerf::MlpPlan::HalfStage stage[kStagesPerLaunch];
+};
+constexpr int kCopiesPerLaunch = 16;
+struct CopyTable {
+    const float* src[kCopiesPerLaunch];
+    long long dst[kCopiesPerLaunch];
+    int count[kCopiesPerLaunch];
+};
+
+__global__ void __launch_bounds__(256) copy_rows_kernel(CopyTable t, float* __restrict__ packed) {
+    const float* __restrict__ src = t.src[blockIdx.y];
+    float* __restrict__ dst = packed + t.dst[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t.count[blockIdx.y]; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(256) pack_segment_kernel(SegmentTable table, float* __restrict__ packed) {
+    const snerf::Segment& s = table.seg[blockIdx.y];
+    const float* __restrict__ w = table.w[blockIdx.y];
     const long long total = (long long)s.ksteps * s.tiles * 64;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
@@ -41,9 +70,11 @@ __device__ __forceinline__ void out_store(_Float16* out, long long base, int lan
     out[base + 512 + lane * 8 + j] = lo;
 }
 
-__global__ void __launch_bounds__(256) pack_half_stage_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
-                                                              const float* __restrict__ w2, snerf::MlpPlan::HalfStage st,
-                                                              float* __restrict__ packed) {
+__global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, float* __restrict__ packed) {
+    const snerf::MlpPlan::HalfStage& st = table.stage[blockIdx.y];
+    const float* __restrict__ w0 = table.w[blockIdx.y][0];
+    const float* __restrict__ w1 = table.w[blockIdx.y][1];
+    const float* __restrict__ w2 = table.w[blockIdx.y][2];
     const int unit_ks = st.unit_floats / 512;
     const long long total = (long long)st.tiles * unit_ks * 512;  // one thread per (u, ks, lane, j): 512 elements per k-step
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -116,25 +147,56 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(packed, 0, sizeof(float) * (size_t)plan.total_floats, s);
     if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_pack: memset: %s", hipGetErrorString(e));
-    for (const std::vector<snerf::Segment>* list : {&plan.segments, &plan.dgrad_segments}) {
-        for (const snerf::Segment& seg : *list) {
-            const long long total = (long long)seg.ksteps * seg.tiles * 64;
-            hipLaunchKernelGGL(pack_segment_kernel, dim3(snerf::stride_grid(total, 256)), dim3(256), 0, s,
-                               params[seg.param], seg, packed);
+    {
+        SegmentTable table;
+        int n = 0;
+        long long most = 0;
+        auto flush = [&]() {
+            if (n == 0) return;
+            hipLaunchKernelGGL(pack_segment_kernel, dim3(snerf::stride_grid(most, 256), n), dim3(256), 0, s, table, packed);
+            n = 0;
+            most = 0;
+        };
+        for (const std::vector<snerf::Segment>* list : {&plan.segments, &plan.dgrad_segments}) {
+            for (const snerf::Segment& seg : *list) {
+                table.w[n] = params[seg.param];
+                table.seg[n] = seg;
+                most = std::max(most, (long long)seg.ksteps * seg.tiles * 64);
+                if (++n == kSegmentsPerLaunch) flush();
+            }
         }
+        flush();
     }
-    for (const std::vector<snerf::MlpPlan::HalfStage>* list : {&plan.half_stages, &plan.half_dgrad_stages}) {
-        for (const snerf::MlpPlan::HalfStage& st : *list) {
-            const long long total = (long long)st.tiles * (st.unit_floats / 512) * 512;
-            hipLaunchKernelGGL(pack_half_stage_kernel, dim3(snerf::stride_grid(total, 256)), dim3(256), 0, s,
-                               params[st.seg[0].param], params[st.seg[st.nseg > 1 ? 1 : 0].param],
-                               params[st.seg[st.nseg > 2 ? 2 : 0].param], st, packed);
+    {
+        StageTable table;
+        int n = 0;
+        long long most = 0;
+        auto flush = [&]() {
+            if (n == 0) return;
+            hipLaunchKernelGGL(pack_half_stage_kernel, dim3(snerf::stride_grid(most, 256), n), dim3(256), 0, s, table, packed);
+            n = 0;
+            most = 0;
+        };
+        for (const std::vector<snerf::MlpPlan::HalfStage>* list : {&plan.half_stages, &plan.half_dgrad_stages}) {
+            for (const snerf::MlpPlan::HalfStage& st : *list) {
+                for (int k = 0; k < 3; ++k) table.w[n][k] = params[st.seg[k < st.nseg ? k : 0].param];
+                table.stage[n] = st;
+                most = std::max(most, (long long)st.tiles * (st.unit_floats / 512) * 512);
+                if (++n == kStagesPerLaunch) flush();
+            }
         }
+        flush();
     }
+    CopyTable copies;
+    int ncopies = 0;
     auto copy = [&](long long dst, const float* src, long long n) {
-        if (e == hipSuccess) e = hipMemcpyAsync(packed + dst, src, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, s);
+        copies.src[ncopies] = src;
+        copies.dst[ncopies] = dst;
+        copies.count[ncopies] = (int)n;
+        ++ncopies;
     };
     const int d = plan.depth;
+    SNERF_REQUIRE(d + 6 <= kCopiesPerLaunch, "mlp_pack: depth %d exceeds the copy table", d);
     for (int l = 0; l < d; ++l) copy(plan.trunk_bias(l), params[2 * l + 1], plan.width);
     copy(plan.pts_out_w(), params[2 * d], (long long)plan.pts_out_rows * plan.width);
     copy(plan.pts_out_b(), params[2 * d + 1], plan.pts_out_rows);
@@ -144,6 +206,7 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
         copy(plan.views_out_w(), params[2 * d + 6], 3LL * plan.views_width);
         copy(plan.views_out_b(), params[2 * d + 7], 3);
     }
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(4, ncopies), dim3(256), 0, s, copies, packed);
     if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_pack: copy: %s", hipGetErrorString(e));
     return snerf::check_launch("mlp_pack");
 }
