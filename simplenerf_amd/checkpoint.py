@@ -33,7 +33,7 @@ def save_checkpoint(path, iter_num: int, model: torch.nn.Module, optimizer: Opti
 def load_checkpoint(path, model: torch.nn.Module, optimizer: Optional[torch.optim.Optimizer] = None,
                     map_location=None) -> int:
     """Loads model (and optimiser, when given and present) state; returns ``iteration_num``."""
-    state = torch.load(path, map_location=map_location, weights_only=False)
+    state = torch.load(path, map_location=map_location)   # tensors, dicts and ints only: loads under weights_only=True
     model.load_state_dict(from_reference_names(state['model_state_dict']))
     if optimizer is not None and 'optimizer_state_dict' in state:
         optimizer.load_state_dict(state['optimizer_state_dict'])

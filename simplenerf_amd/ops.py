@@ -343,6 +343,8 @@ def _mask(t: Optional[Tensor], name: str, n: int) -> Optional[Tensor]:
     return t.contiguous()
 
 
+# scratch of snerf_loss_forward (block partials + completion counter), one per device; calls on one device are ordered
+# by the stream they are enqueued on -- callers that evaluate losses on several streams at once need one buffer each
 _loss_workspaces: Dict[torch.device, Tensor] = {}
 
 

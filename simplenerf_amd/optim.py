@@ -45,7 +45,6 @@ class Adam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self.__dict__['_counts'] = {}
-        self.__dict__['_tables'] = {}
 
     @torch.no_grad()
     def step(self, closure=None):
