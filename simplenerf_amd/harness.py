@@ -102,9 +102,11 @@ def allreduce_gradients(parameters, world_size: int, group=None) -> None:
     (all gradients flattened into a single buffer: 2 265 488 floats = 9.06 MB for the 4-MLP model).
     Equivalent to the reference's DataParallel, which gathers the per-device outputs and takes the loss mean over the
     whole batch (src/Trainer01.py:93-96), when every rank holds the same number of rays."""
+    if world_size == 1:
+        return
     import torch.distributed as dist
     params = [p for p in parameters if p.grad is not None]
-    if not params or world_size == 1:
+    if not params:
         return
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

@@ -73,6 +73,19 @@ class MlpParameters(torch.nn.Module):
             self.views_output_linear = lin(wv, 3)
 
     def abi_params(self) -> List[Tensor]:
+        """Parameters in the order of the C ABI.  The list is cached (it is asked for ~16 times per training iteration);
+        Parameter objects survive ``.to()`` / ``load_state_dict`` / optimiser steps, and a re-assigned first or last layer
+        invalidates the cache."""
+        cached = self.__dict__.get('_abi_params')
+        last = self.views_output_linear.bias if self.view_dependent else self.pts_output_linear.bias
+        if cached is not None and cached[0] is self.pts_linears[0].weight and cached[-1] is last and \
+                cached[1] is self.pts_linears[0].bias:
+            return cached
+        out = self._build_abi_params()
+        self.__dict__['_abi_params'] = out
+        return out
+
+    def _build_abi_params(self) -> List[Tensor]:
         out = []
         for layer in self.pts_linears:
             out += [layer.weight, layer.bias]
@@ -166,7 +179,9 @@ class SimpleNeRFHip(torch.nn.Module):
     def _packed_mlp(self, name: str) -> ops.PackedMlp:
         module: MlpParameters = getattr(self, name)
         params = module.abi_params()
-        stamp = tuple((p.data_ptr(), p._version) for p in params)
+        # staleness stamp: every parameter's in-place version counter (optimiser steps, load_state_dict, manual edits)
+        # plus the storage address of the first one (a .to(device) / re-materialisation moves them all)
+        stamp = (params[0].data_ptr(),) + tuple(p._version for p in params)
         entry = self._packed.get(name)
         if entry is None or entry[0] != stamp or entry[1].buffer.device != params[0].device:
             packed = entry[1] if entry is not None and entry[1].buffer.device == params[0].device \

@@ -18,7 +18,9 @@ PRECISIONS = {'fp32': PRECISION_FP32, 'f16x3': PRECISION_F16X3}
 
 
 def _stream() -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw hipStream_t of torch's current stream on the current device (the C-level getter: ~30x cheaper than building a
+    # torch.cuda.Stream object, and this runs ~50 times per training iteration)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _dev(t: Optional[Tensor], name: str, shape=None) -> Optional[Tensor]:
