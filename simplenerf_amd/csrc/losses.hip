@@ -220,7 +220,9 @@ __global__ void __launch_bounds__(256) patch_masks_kernel(PatchArgs a) {
     const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (ray >= a.num_rays) return;
-    if (a.ray_mask && !a.ray_mask[ray]) {
+    const long long view_id = a.pixel_id[3 * ray];
+    // rows outside the pixel-ray mask, and rows whose view index is not a view (a loader's -1 fill), decide nothing
+    if ((a.ray_mask && !a.ray_mask[ray]) || view_id < 0 || view_id >= a.num_views) {
         if (lane == 0) {
             a.mask1[ray] = 0;
             a.mask2[ray] = 0;
@@ -230,7 +232,7 @@ __global__ void __launch_bounds__(256) patch_masks_kernel(PatchArgs a) {
         return;
     }
     const int hx = a.patch_x / 2, hy = a.patch_y / 2;
-    const long long view_a = a.pixel_id[3 * ray], x_a = a.pixel_id[3 * ray + 1], y_a = a.pixel_id[3 * ray + 2];
+    const long long view_a = view_id, x_a = a.pixel_id[3 * ray + 1], y_a = a.pixel_id[3 * ray + 2];
     // nearest other view: second entry of a stable sort of the origin distances (kthvalue(.., 2), :128-132)
     const float* pa = a.poses + view_a * 16;
     const float oax = pa[3], oay = pa[7], oaz = pa[11];

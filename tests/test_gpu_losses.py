@@ -141,6 +141,18 @@ def test_losses_train_the_renderer_end_to_end():
         assert any(k.startswith(prefix) and v > 0 for k, v in norms.items()), prefix
 
 
+def test_patch_masks_ignore_rows_without_a_view():
+    """A row whose view index is the loader's -1 fill (or past the last view) must not be dereferenced."""
+    scene = synth.synth_scene(0)
+    d = lambda a: torch.from_numpy(numpy.ascontiguousarray(a)).to(DEV)
+    pixel_id = torch.tensor([[0, 10, 10], [-1, -1, -1], [3, 5, 5], [1, 20, 20]], dtype=torch.int32, device=DEV)
+    rays = torch.zeros(4, 3, device=DEV)
+    depth = torch.full((4,), 4.0, device=DEV)
+    m1, m2 = ops.patch_consistency_masks(rays, rays - torch.tensor([0.0, 0.0, 1.0], device=DEV), depth, depth, None, pixel_id,
+                                         d(scene['poses']), d(scene['intrinsics'][0]), d(scene['images']), [5, 5], 0.1)
+    assert not bool(m1[1]) and not bool(m2[1]) and not bool(m1[2]) and not bool(m2[2])
+
+
 def test_loss_errors():
     with pytest.raises(RuntimeError, match='expected a tensor on the GPU'):
         ops.LossTermSpec(torch.zeros(4), torch.zeros(4), None, None, 0, 1.0)
