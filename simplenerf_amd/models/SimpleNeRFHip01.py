@@ -176,6 +176,52 @@ class SimpleNeRFHip(torch.nn.Module):
         sample_pdf has a rounding-dependent discontinuity; works in eval mode too)."""
         self._draws = draws
 
+    def invalidate_packed(self) -> None:
+        """Force the next forward to re-pack every MLP's weights (used before a graph capture, so that the re-pack is
+        part of the captured work and not skipped because the weights happen to be current at capture time)."""
+        self._packed = {name: (None, entry[1]) for name, entry in self._packed.items()}
+
+    def training_draw_shapes(self, n: int) -> Dict[str, tuple]:
+        """Shapes of the draws one training-mode forward over ``n`` rays consumes, keyed like ``set_random_draws``."""
+        mcfg = self.configs['model']
+        s_c = mcfg['coarse_mlp']['num_samples']
+        shapes: Dict[str, tuple] = {}
+        if mcfg['perturb'] > 0.:
+            shapes['t_rand'] = (n, s_c)
+        noisy = float(mcfg['raw_noise_std']) > 0.
+        if noisy:
+            shapes['noise_coarse'] = (n, s_c, 1)
+            for prefix, level, _ in self._train_only:
+                if level == 'coarse':
+                    shapes[f'noise_{prefix[:-1]}'] = (n, s_c, 1)
+        if self.fine_mlp_needed:
+            s_f = mcfg['fine_mlp']['num_samples']
+            if mcfg['perturb'] > 0.:
+                shapes['u'] = (n, s_f)
+            if noisy:
+                shapes['noise_fine'] = (n, s_c + s_f, 1)
+                for prefix, level, _ in self._train_only:
+                    if level == 'fine':
+                        shapes[f'noise_{prefix[:-1]}_fine'] = (n, s_c + s_f, 1)
+        return shapes
+
+    def draw_training_randomness(self, n: int, row_offset: int, device, out: Optional[Dict[str, Tensor]] = None
+                                 ) -> Dict[str, Tensor]:
+        """The draws the next training-mode forward would make itself, produced up front (and counted as that forward's):
+        pass the result to ``set_random_draws``.  ``out`` supplies pre-allocated tensors to fill (static graph inputs)."""
+        call = self._train_calls
+        self._train_calls += 1
+        noise_std = float(self.configs['model']['raw_noise_std'])
+        draws = {}
+        for key, shape in self.training_draw_shapes(n).items():
+            stream = call * len(_DRAW_KINDS) + _DRAW_KINDS.index(key)
+            target = None if out is None else out[key]
+            if key.startswith('noise'):
+                draws[key] = ops.random_normal(self.seed, stream, row_offset, shape, device, noise_std, out=target)
+            else:
+                draws[key] = ops.random_uniform(self.seed, stream, row_offset, shape, device, out=target)
+        return draws
+
     def _packed_mlp(self, name: str) -> ops.PackedMlp:
         module: MlpParameters = getattr(self, name)
         params = module.abi_params()

@@ -552,10 +552,19 @@ def shuffled_indices(seed: int, epoch: int, first: int, count: int, domain: int,
     return out
 
 
-def random_uniform(seed: int, stream_id: int, first_row: int, shape, device) -> Tensor:
-    """[0,1) Philox draws of shape (rows, width...); element (r, c) depends only on (seed, stream_id, first_row + r, c)."""
+def _draw_target(shape, device, out: Optional[Tensor]) -> Tensor:
+    if out is None:
+        return torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous():
+        raise RuntimeError(f'draw target: expected a contiguous float32 GPU tensor of shape {tuple(shape)}')
+    return out
+
+
+def random_uniform(seed: int, stream_id: int, first_row: int, shape, device, out: Optional[Tensor] = None) -> Tensor:
+    """[0,1) Philox draws of shape (rows, width...); element (r, c) depends only on (seed, stream_id, first_row + r, c).
+    ``out`` (optional) receives the draws in place (static buffers of a captured graph)."""
     lib = _lib.load()
-    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    out = _draw_target(shape, device, out)
     rows = int(shape[0])
     width = out.numel() // rows if rows else 1
     if out.numel() == 0:
@@ -567,9 +576,10 @@ def random_uniform(seed: int, stream_id: int, first_row: int, shape, device) -> 
     return out
 
 
-def random_normal(seed: int, stream_id: int, first_row: int, shape, device, scale: float = 1.0) -> Tensor:
+def random_normal(seed: int, stream_id: int, first_row: int, shape, device, scale: float = 1.0,
+                  out: Optional[Tensor] = None) -> Tensor:
     lib = _lib.load()
-    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    out = _draw_target(shape, device, out)
     rows = int(shape[0])
     width = out.numel() // rows if rows else 1
     if out.numel() == 0:

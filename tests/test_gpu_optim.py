@@ -81,3 +81,58 @@ def test_step_invalidates_the_models_packed_weights():
     with torch.no_grad():
         after = model.eval()(batch)['rgb_coarse']
     assert float(before.abs().max()) > 0.1 and float((after - before).abs().max()) > 1e-4
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+def test_graphed_training_pass_equals_eager(precision):
+    """harness.GraphedTrainStep (one captured HIP graph: re-pack, forwards, losses, backward) against the same pass run
+    eagerly: identical loss values and bit-identical parameter gradients, on the capture call and on a later replay
+    with another batch; and the optimiser step between replays is seen by the next one (re-pack inside the graph)."""
+    from simplenerf_amd import harness
+    from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
+    from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
+    from simplenerf_amd.models.ModelFactory import get_model
+    cfg = synth.training_configs(precision, num_rays=192, num_sparse=64)
+    cfg['losses'] = synth.loss_configs(iter_weighted=False)
+    scene = synth.training_scene(0, 3, 48, 64, sparse_fraction=0.05)
+    models = []
+    for _ in range(2):
+        m = get_model(cfg, None)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 9, 200.0, 8.0).items()})
+        models.append(m.to(DEV).train())
+    eager, graphed = models
+    batcher = BatchAssembler(cfg, scene, DEV)
+    losses = LossComputer(cfg)
+    step = harness.GraphedTrainStep(graphed, losses, batcher.get_next_batch(0))
+    opt_e, opt_g = optim.Adam(list(eager.parameters()), lr=1e-3), optim.Adam(list(graphed.parameters()), lr=1e-3)
+    for it in range(3):
+        batch = batcher.get_next_batch(it)
+        eager.set_random_draws(eager.draw_training_randomness(256, 0, DEV))
+        piece = dict(batch)
+        piece['common_data'] = dict(batch['common_data'])
+        opt_e.zero_grad(set_to_none=True)
+        ref = losses.compute_losses(piece, eager(piece))
+        ref['TotalLoss'].backward()
+        totals = step(batch)
+        assert float(totals['TotalLoss']) == float(ref['TotalLoss'].detach()), it
+        for (name, a), b in zip(eager.named_parameters(), graphed.parameters()):
+            assert torch.equal(a.grad, b.grad), (it, name)
+        opt_e.step()
+        opt_g.step()
+    for a, b in zip(eager.parameters(), graphed.parameters()):
+        assert torch.equal(a, b)
+    # a short batch (end of an epoch) goes through the same pass without the graph, into the same gradient buffers
+    batch = {k: (v[:200] if isinstance(v, torch.Tensor) else v) for k, v in batcher.get_next_batch(3).items()}
+    grad_ptrs = [p.grad.data_ptr() for p in graphed.parameters()]
+    eager.set_random_draws(eager.draw_training_randomness(200, 0, DEV))
+    piece = dict(batch)
+    piece['common_data'] = dict(batch['common_data'])
+    opt_e.zero_grad(set_to_none=True)
+    ref = losses.compute_losses(piece, eager(piece))
+    ref['TotalLoss'].backward()
+    totals = step(batch)
+    assert float(totals['TotalLoss']) == float(ref['TotalLoss'].detach())
+    assert [p.grad.data_ptr() for p in graphed.parameters()] == grad_ptrs
+    for a, b in zip(eager.parameters(), graphed.parameters()):
+        assert torch.equal(a.grad, b.grad)

@@ -1,0 +1,25 @@
+"""Training iteration time with the reference sub-batch size (2048) and with the whole batch in one pass (4096)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from simplenerf_amd import harness, optim, synth
+from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
+from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
+from simplenerf_amd.models.ModelFactory import get_model
+DEV = torch.device('cuda', 0)
+for sub in (2048, 4096):
+    cfg = synth.training_configs('f16x3'); cfg['sub_batch_size'] = sub
+    model = get_model(cfg, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
+    model = model.to(DEV).train()
+    batcher = BatchAssembler(cfg, synth.training_scene(), DEV)
+    losses = LossComputer(cfg); opt = optim.Adam(list(model.parameters()), lr=5e-4)
+    it = [20000]
+    def step():
+        it[0] += 1
+        return harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it[0]), sub)
+    for _ in range(2): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(6): tot = step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 6
+    print(f'sub_batch_size {sub}: {dt*1e3:.2f} ms/iter, TotalLoss {float(tot["TotalLoss"]):.5f}, peak {torch.cuda.max_memory_allocated()/2**30:.1f} GB')
