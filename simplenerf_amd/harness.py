@@ -24,13 +24,28 @@ def shard_range(num_rays: int, rank: int, world_size: int) -> Tuple[int, int]:
     return first, min(num_rays, first + per) - first
 
 
+_columns: Dict[tuple, Tensor] = {}
+
+
+def _constant_column(value: float, rows: int, device: torch.device) -> Tensor:
+    """(rows,1) tensor filled with ``value`` (the near/far columns of a frame's batch are constants: built once per
+    value and size, shared read-only between batches instead of being re-filled every step)."""
+    key = (value, rows, device)
+    col = _columns.get(key)
+    if col is None:
+        if len(_columns) > 64:
+            _columns.clear()
+        col = _columns[key] = torch.full((rows, 1), value, dtype=torch.float32, device=device)
+    return col
+
+
 def frame_batch(camera: dict, ndc: bool, device, first_ray: int = 0, num_rays: Optional[int] = None) -> Dict[str, Tensor]:
     """Input dictionary for rays [first_ray, first_ray+num_rays) of a frame, generated on the device (K1)."""
     h, w = camera['resolution']
     if num_rays is None:
         num_rays = h * w - first_ray
     batch = ops.generate_rays((h, w), camera['intrinsic'], camera['pose'], camera['near'], ndc, device, first_ray, num_rays)
-    col = lambda v: torch.full((num_rays, 1), float(v), dtype=torch.float32, device=device)
+    col = lambda v: _constant_column(float(v), num_rays, torch.device(device))
     batch['near'], batch['far'] = col(camera['near']), col(camera['far'])
     if ndc:
         batch['near_ndc'], batch['far_ndc'] = col(camera.get('near_ndc', 0.0)), col(camera.get('far_ndc', 1.0))
