@@ -24,6 +24,7 @@ struct MlpArgs {
     // training only: saved-activation tiles, [wave block][act_rows][32 samples] (mlp_plan.h)
     float* acts;
     int act_rows, act_pev, act_h1, act_feature, act_hv, act_mask;
+    int const_floats;       // biases + head weights: packed[bias_offset, bias_offset + const_floats), staged in LDS
 };
 
 // Arguments of the backward chain kernels (fp32: mlp_backward.hip, f16x3: mlp_backward_f16.hip)

@@ -42,6 +42,12 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
 
     SlabStream<WT> st;
     st.start(a.packed, lds, lane, wave);
+    // Biases and head weights are staged in LDS once per workgroup: as global loads at the top of every layer their L2
+    // latency sat between two layers' MFMAs (and a global load in the layer loop makes the compiler drain the DMA).
+    float* consts = lds + 2 * SlabStream<WT>::kBufFloats;
+    for (int i = threadIdx.x * 4; i < a.const_floats; i += 256 * 4)
+        *reinterpret_cast<f32x4*>(consts + i) = *reinterpret_cast<const f32x4*>(a.packed + a.bias_offset + i);
+    __syncthreads();
 
     // ---- inputs of this lane's sample -------------------------------------------------------------
     const long long first = ((long long)blockIdx.x * 4 + wave) * 32 + (lane & 31);
@@ -74,7 +80,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
     }
 
     // ---- trunk ------------------------------------------------------------------------------------
-    const float* bias = a.packed + a.bias_offset;
+    const float* bias = consts;
     f32x16 acc[WT];
     float h[WT * 16];
     load_bias<WT>(acc, bias, half);
@@ -97,8 +103,8 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
     }
 
     // ---- density (and view-independent colour) head -------------------------------------------------
-    const float* wout = a.packed + a.pts_out_w;
-    const float* bout = a.packed + a.pts_out_b;
+    const float* wout = consts + (a.pts_out_w - a.bias_offset);
+    const float* bout = consts + (a.pts_out_b - a.bias_offset);
     float sigma = head_dot<WT * 16>(h, wout, half) + bout[0];
     if (a.noise) sigma += a.noise[g];
     sigma = fmaxf(sigma, 0.0f);
@@ -108,13 +114,13 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoidf(head_dot<WT * 16>(h, wout + (c + 1) * WT * 32, half) + bout[c + 1]);
     } else {
         // feature = feature_linear(h), no activation (:683)
-        load_bias<WT>(acc, a.packed + a.feature_bias, half);
+        load_bias<WT>(acc, consts + (a.feature_bias - a.bias_offset), half);
         gemm_segment<WT, WT, WT>(acc, h, st);
         to_operand<WT, false>(acc, h);
         if (STORE) store_acc_tile(h, tile + a.act_feature * 32, lane);
         // views layer over [feature | rest of the point encoding (points-aug only) | view encoding] (:633, :695-699)
         f32x16 accv[VT];
-        load_bias<VT>(accv, a.packed + a.views_bias, half);
+        load_bias<VT>(accv, consts + (a.views_bias - a.bias_offset), half);
         gemm_segment<VT, WT, WT>(accv, h, st);
         if (SIGMA_PE) gemm_segment<VT, 2, WT>(accv, pe, st);
         gemm_segment<VT, 1, WT>(accv, pev, st);
@@ -124,8 +130,8 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
             store_acc_tile(hv, tile + a.act_hv * 32, lane);
             store_relu_masks(hv, masks, a.depth * WT, lane);
         }
-        const float* wv = a.packed + a.views_out_w;
-        const float* bv = a.packed + a.views_out_b;
+        const float* wv = consts + (a.views_out_w - a.bias_offset);
+        const float* bv = consts + (a.views_out_b - a.bias_offset);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoidf(head_dot<VT * 16>(hv, wv + c * VT * 32, half) + bv[c]);
     }
@@ -139,16 +145,20 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
     }
 }
 
+constexpr int kMaxConstFloats = 5120;   // LDS reserved for the bias / head block (20 KB; the 8x256 main MLP needs 12.6 KB)
+
 template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE>
 int launch(const MlpArgs& a, hipStream_t stream) {
+    if (a.const_floats > kMaxConstFloats)
+        return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: bias/head block of %d floats exceeds its LDS area", a.const_floats);
     const long long blocks = (a.total + 127) / 128;
     if (blocks > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: too many samples in one call");
-    const size_t lds_bytes = 2 * sizeof(float) * SlabStream<WT>::kBufFloats;
+    const size_t lds_bytes = sizeof(float) * (2 * SlabStream<WT>::kBufFloats + (size_t)a.const_floats);
     auto kernel = mlp_forward_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE>;
     static bool configured = false;  // raising the dynamic-LDS cap is idempotent; racing threads only repeat it
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes);
+                                           (int)(sizeof(float) * (2 * SlabStream<WT>::kBufFloats + kMaxConstFloats)));
         if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured = true;
     }
@@ -177,6 +187,7 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     a.noise = sigma_noise; a.sigma = sigma; a.rgb = rgb;
     a.total = num_rays * num_samples; a.samples = num_samples; a.depth = plan.depth; a.width = plan.width;
     a.bias_offset = plan.bias_offset; a.feature_bias = plan.feature_bias(); a.views_bias = plan.views_bias();
+    a.const_floats = (int)((plan.dgrad_offset - plan.bias_offset + 3) / 4 * 4);
     a.pts_out_w = plan.pts_out_w(); a.pts_out_b = plan.pts_out_b();
     a.views_out_w = plan.views_out_w(); a.views_out_b = plan.views_out_b();
     a.acts = saved_acts; a.act_rows = plan.act_rows(); a.act_pev = plan.act_pev(); a.act_h1 = plan.act_h(1);
