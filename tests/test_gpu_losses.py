@@ -165,3 +165,45 @@ def test_loss_errors():
         ops.patch_consistency_masks(torch.zeros(4, 3, device=DEV), torch.zeros(4, 3, device=DEV), z, z, None,
                                     torch.zeros(4, 3, dtype=torch.int32, device=DEV), torch.zeros(1, 4, 4, device=DEV),
                                     torch.eye(3, device=DEV), torch.zeros(1, 8, 8, 3, device=DEV), [5, 5], 0.1)
+
+
+def test_loss_variants_match_oracle():
+    """Configurations outside the shipped one, against the CPU oracle: augmentations that also have FINE MLPs (MSE02/03
+    then read two colours each, SparseDepthMSE02/03 switch to the MAIN model's depth_fine, the augmentation depth losses
+    add a fine pair) and a model without a fine MLP (coarse-only losses; CoarseFineConsistencyLoss02 contributes 0)."""
+    import copy
+    g = util.load('losses_full.npz')
+    base_cfg, inp_cpu, out_cpu = util.loss_case(g, 'cpu')
+    rng = numpy.random.RandomState(4)
+    n = inp_cpu['rays_o'].shape[0]
+    extra = {}
+    for aug in ('points_augmentation', 'views_augmentation'):
+        extra[f'{aug}_rgb_fine'] = torch.from_numpy(rng.uniform(0, 1, (n, 3)).astype(numpy.float32))
+        extra[f'{aug}_depth_fine'] = out_cpu['depth_fine'].detach() + torch.from_numpy((0.3 * rng.standard_normal(n)).astype(numpy.float32))
+
+    def run(cfg, keys):
+        ref_out = {k: (out_cpu[k] if k in out_cpu else extra[k]).detach().clone().requires_grad_(True) for k in keys}
+        ref = loss_oracle.compute_losses(cfg, copy.copy(inp_cpu), ref_out)
+        ref['TotalLoss'].backward()
+        dev_inp = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in inp_cpu.items() if k != 'common_data'}
+        dev_inp['common_data'] = {k: (v.to(DEV)[None] if isinstance(v, torch.Tensor) else v) for k, v in inp_cpu['common_data'].items()}
+        dev_out = {k: ref_out[k].detach().to(DEV).requires_grad_(True) for k in keys}
+        got = LossComputer(cfg).compute_losses(dev_inp, dev_out)
+        got['TotalLoss'].backward()
+        assert float(got['TotalLoss'].detach()) == pytest.approx(float(ref['TotalLoss'].detach()), rel=REL)
+        for c in cfg['losses']:
+            assert float(got[c['name']]['loss_value'].detach()) == pytest.approx(float(torch.as_tensor(ref[c['name']]).detach()), rel=REL, abs=1e-9), c['name']
+        for k in keys:
+            a = dev_out[k].grad
+            b = ref_out[k].grad
+            a = torch.zeros_like(dev_out[k]) if a is None else a
+            b = torch.zeros_like(ref_out[k]) if b is None else b
+            assert float((a.cpu() - b).abs().max()) <= REL * max(float(b.abs().max()), 1e-12), k
+
+    cfg = copy.deepcopy(base_cfg)
+    for aug in ('points_augmentation', 'views_augmentation'):
+        cfg['model'][aug]['fine_mlp'] = copy.deepcopy(cfg['model'][aug]['coarse_mlp'])
+    run(cfg, list(util.LOSS_OUTPUT_KEYS) + list(extra))
+    cfg = copy.deepcopy(base_cfg)
+    del cfg['model']['fine_mlp']
+    run(cfg, [k for k in util.LOSS_OUTPUT_KEYS if not k.endswith('_fine')])
