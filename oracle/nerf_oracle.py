@@ -274,6 +274,12 @@ def render_chunk(params: Dict[str, Tensor], configs: dict, batch: Dict[str, Tens
         raw, comp = shade('fine_model.', mcfg['fine_mlp'], z_fine, rand.get('noise_fine'))
         out['z_vals_fine'] = z_fine
         emit('', 'fine', raw, comp)
+        if training:        # fine-level augmentation MLPs on the same fine points (render_rays :234-263)
+            for cfg_key, short in _AUG:
+                if cfg_key in mcfg and 'fine_mlp' in mcfg[cfg_key]:
+                    raw, comp = shade(f'{short}_fine_model.', mcfg[cfg_key]['fine_mlp'], z_fine,
+                                      rand.get(f'noise_{cfg_key}_fine'))
+                    emit(f'{cfg_key}_', 'fine', raw, comp)
     if not retraw:
         for level in ('coarse', 'fine'):
             for k in ('z_vals', 'visibility', 'weights'):

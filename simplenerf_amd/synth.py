@@ -56,6 +56,7 @@ def make_configs(kind: str, model_name: str = 'SimpleNeRFHip01') -> dict:
       'headline'  128+128, 8x256 coarse+fine, NDC (the metric configuration)
       'config3'   config2 + points-augmentation + views-augmentation coarse MLPs
       'headline_world'  headline but non-NDC (world-space rays)
+      'config3f'  config3 with fine-level augmentation MLPs as well
     """
     model = {
         'name': model_name,
@@ -85,6 +86,12 @@ def make_configs(kind: str, model_name: str = 'SimpleNeRFHip01') -> dict:
         model['fine_mlp'] = mlp_config(128)
         model['points_augmentation'] = {'coarse_mlp': mlp_config(sigma_pe_degree=3)}
         model['views_augmentation'] = {'coarse_mlp': mlp_config(use_view_dirs=False, view_dependent_rgb=False)}
+    elif kind == 'config3f':      # config3 + FINE augmentation MLPs (supported by the reference, not in its shipped configs)
+        model['coarse_mlp'] = mlp_config(64)
+        model['fine_mlp'] = mlp_config(128)
+        model['points_augmentation'] = {'coarse_mlp': mlp_config(sigma_pe_degree=3), 'fine_mlp': mlp_config(sigma_pe_degree=3)}
+        model['views_augmentation'] = {'coarse_mlp': mlp_config(use_view_dirs=False, view_dependent_rgb=False),
+                                       'fine_mlp': mlp_config(use_view_dirs=False, view_dependent_rgb=False)}
     else:
         raise KeyError(kind)
     return {

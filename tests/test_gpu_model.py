@@ -145,6 +145,22 @@ def test_train_forward_matches_reference(variant, profile):
     check_outputs(out, ref, strict_fine=(profile == 'consistent'), tag=f'train/{variant}/{profile}')
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+def test_train_forward_with_fine_augmentation_mlps_matches_reference(precision):
+    """config3f: six MLP passes per training forward (main, points-aug, views-aug at the coarse AND the fine level)."""
+    g = util.load('e2e_config3f_train_det_consistent.npz')
+    cfg = synth.with_overrides(synth.make_configs('config3f'), perturb=False, raw_noise_std=0.0)
+    model = build(cfg, g, precision).train()
+    with torch.no_grad():
+        out = model({k: v.to(DEV) for k, v in util.golden_batch(g).items()})
+    ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
+    assert 'points_augmentation_rgb_fine' in out and 'views_augmentation_depth_fine' in out
+    # the main fine model shares the coarse weights ('consistent'), but the fine AUGMENTATION fields are independent
+    # random MLPs: a resampled depth that sits in another bin than the reference's (sample_pdf discontinuity, DESIGN.md
+    # section 4) can land in their dense geometry, so fine-level outputs are gated per ray with the outlier allowance
+    check_outputs(out, ref, strict_fine=False, tag=f'train/config3f/{precision}')
+
+
 @pytest.mark.parametrize('kind,profile', [('config2', 'dense'), ('headline', 'dense'), ('headline_world', 'dense'),
                                           ('config2', 'plain')])
 def test_fine_pass_on_reference_samples(kind, profile):

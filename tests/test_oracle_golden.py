@@ -137,6 +137,18 @@ def test_render_train_matches_reference(variant, profile):
         assert util.rel_linf(out[k], v) < 2e-5, k
 
 
+def test_render_train_with_fine_augmentation_mlps_matches_reference():
+    """config3f: fine-level points-/views-augmentation MLPs on the fine samples (reference :234-263), deterministic."""
+    g = util.load('e2e_config3f_train_det_consistent.npz')
+    cfg = synth.with_overrides(synth.make_configs('config3f'), perturb=False, raw_noise_std=0.0)
+    out = oracle.render(util.golden_params(cfg, g), cfg, util.golden_batch(g), training=True)
+    ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
+    assert sorted(out.keys()) == sorted(ref.keys())
+    assert 'points_augmentation_rgb_fine' in ref and 'views_augmentation_depth_fine' in ref
+    for k, v in ref.items():
+        assert util.rel_linf(out[k], v) < 2e-5, k
+
+
 # ---------------------------------------------------------------- G7 parameter gradients
 def oracle_grads(cfg, g):
     """Autograd through the oracle's training-mode forward with the fixed scalar loss of tools/make_golden.py."""
