@@ -44,23 +44,26 @@ struct UnitStream {
 
     const float* pend_src;   // unit being requested piecewise (one DMA instruction per call of fetch_piece)
     float* pend_dst;
-    int pend_left;           // DMA instructions this wave still has to issue for it
+    int pend_left;           // DMA instructions this wave still has to issue for it (<= 0: all requested)
+    int step;                // floats per piece: 1024 while a unit is being requested, 0 when there is none
     int issued;              // DMA instructions issued for the youngest requested unit (>= its piece count)
 
-    // Branch-free on purpose: a conditional here would cut the unrolled MFMA loop into basic blocks and the fragment reads
-    // could no longer be scheduled a k-step ahead.  Once the unit's pieces are all requested the same (last) piece is simply
-    // requested again -- idempotent, and it only happens where a unit has more k-step pairs than its second successor has
-    // pieces (a few times per pass).  `issued` feeds the counted vmcnt of the next acquire().
+    // Branch-free AND select-free on purpose: a conditional here would cut the unrolled MFMA loop into basic blocks, and a
+    // compare/select per piece costs ~15 scalar instructions -- with one wave per SIMD every instruction the wave issues
+    // between two MFMAs beyond ~5 delays the matrix pipe.  So a piece is ALWAYS "advance by `step`, request 1 KiB per
+    // wave": once the unit's own pieces are all requested the stream simply keeps being read (into the rest of the same
+    // ring slot: a slot holds the largest unit, and a unit is never followed by fewer than one maximum unit of readable
+    // stream -- the zero runway of MlpPlan), and when there is no unit to request `step` is 0 and the same valid KiB
+    // goes to the dump area again.  `issued` feeds the counted vmcnt of the next acquire().
     __device__ __forceinline__ void fetch_piece() {
 #ifdef SNERF_ABL_NODMA
-        pend_left -= pend_left > 0 ? 1 : 0;
+        pend_left -= 1;
         return;
 #endif
-        const int adv = pend_left > 0 ? 1024 : 0;
-        pend_src += adv; pend_dst += adv;
+        pend_src += step; pend_dst += step;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pend_src + lane * 4),
                                          (__attribute__((address_space(3))) void*)pend_dst, 16, 0, 0);
-        pend_left -= pend_left > 0 ? 1 : 0;
+        pend_left -= 1;
         ++issued;
     }
     __device__ __forceinline__ void finish_fetch() {
@@ -72,12 +75,14 @@ struct UnitStream {
         pend_src = stream_base;
         pend_dst = lds + kUnitBuffers * kUnitBufFloats + wave * 256;  // dump: 4 KiB right after the ring
         pend_left = 0;
+        step = 0;
         issued = 0;
     }
     __device__ __forceinline__ void begin_fetch(int ksteps, int into_slot) {
         pend_src = fetch_ptr + wave * 256 - 1024;   // fetch_piece pre-increments
         pend_dst = lds + into_slot * kUnitBufFloats + wave * 256 - 1024;
         pend_left = ksteps >> 1;
+        step = 1024;
         issued = 0;
         fetch_ptr += ksteps * 512;
     }
@@ -86,7 +91,7 @@ struct UnitStream {
         finish_fetch();
     }
     __device__ __forceinline__ void start(const float* first, float* lds_base, int ks0, int ks1, int lane_, int wave_) {
-        fetch_ptr = first; stream_base = first; lds = lds_base; slot = 0; lane = lane_; wave = wave_; pend_left = 0; issued = 0;
+        fetch_ptr = first; stream_base = first; lds = lds_base; slot = 0; lane = lane_; wave = wave_; pend_left = 0; step = 0; issued = 0;
         fetch(ks0, 0);
         if (ks1 > 0) fetch(ks1, 1);
         if (ks1 <= 0) issued_next_none();
@@ -137,34 +142,50 @@ struct TileSplitter {
 // acc += W[tile rows, segment columns] . X over NKS k-steps; `p` walks the unit (lane offset already applied).
 // Fragments for k-step ks+1 are requested before the MFMAs of k-step ks are issued (LDS latency hides under 96 MFMA
 // cycles), and `side.step()` slots one slice of the previous tile's ReLU + hi/lo split (VALU) behind each k-step's MFMAs.
+// LDS fragment reads the compiler does not see, with counted waits that carry the destination registers as a
+// dependency (everything that uses them is ordered after the wait).  `byte_offset` folds to an immediate once the caller's
+// k-step loop is unrolled.
+__device__ __forceinline__ f16x8 lds_read_f16x8(unsigned lds_byte_address, int byte_offset) {
+    f16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_address), "i"(byte_offset) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait_all_but_two(f16x8& a, f16x8& b) {
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b)::"memory");
+}
+__device__ __forceinline__ void lds_wait_all(f16x8& a, f16x8& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+}
+
+// Three MFMAs per k-step on the fp16 pipe (hi*hi, hi*lo, lo*hi).  The weight fragments of k-step ks+1 are requested
+// BEFORE the MFMAs of k-step ks, into the other register pair, and k-step ks waits with lgkmcnt(2) -- "all but the two
+// newest LDS reads".  With compiler-visible reads this software pipeline does not survive: the register allocator folds
+// the two fragment pairs into one and the wait-count pass puts lgkmcnt(0) right behind each pair of reads, so every
+// k-step paid the full LDS latency (~130 cycles) in front of 96 cycles of MFMAs -- the matrix pipe was 41-42 % busy
+// (PMC) and a third of all wave cycles were parked at s_waitcnt.
 template <int NKS, int NB, typename Side>
 __device__ __forceinline__ void seg_mfma(f32x16& acc, const float*& p, const f16x8 (&bh)[NB], const f16x8 (&bl)[NB],
                                          const Side& side, int side_first, UnitStream& st) {
     static_assert(NB >= NKS, "operand array too short");
-    f16x8 ah = *reinterpret_cast<const f16x8*>(p);
-    f16x8 al = *reinterpret_cast<const f16x8*>(p + 256);
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+    f16x8 ah = lds_read_f16x8(base, 0);
+    f16x8 al = lds_read_f16x8(base, 1024);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         f16x8 nah = ah, nal = al;
-#ifndef SNERF_ABL_NOLDSREAD
         if (ks + 1 < NKS) {
-            nah = *reinterpret_cast<const f16x8*>(p + (ks + 1) * 512);
-            nal = *reinterpret_cast<const f16x8*>(p + (ks + 1) * 512 + 256);
+            nah = lds_read_f16x8(base, (ks + 1) * 2048);
+            nal = lds_read_f16x8(base, (ks + 1) * 2048 + 1024);
+            lds_wait_all_but_two(ah, al);
+        } else {
+            lds_wait_all(ah, al);
         }
-#endif
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
         if (side_first + ks < 8) side.step(side_first + ks);
         if ((ks & 1) == 0) st.fetch_piece();
         ah = nah; al = nal;
-        // Pin the issue order per k-step: the two fragment reads of the NEXT k-step, then this k-step's three MFMAs, then
-        // the VALU slice.  Left to itself the scheduler (at the 256-VGPR ceiling) serialises read -> wait -> MFMA through
-        // one register quad and exposes the LDS latency on every k-step.
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // MFMA
-        if ((ks & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (the LDS-DMA piece)
-        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0); // VALU
     }
     p += NKS * 512;
 }
