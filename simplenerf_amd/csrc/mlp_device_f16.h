@@ -44,26 +44,24 @@ struct UnitStream {
 
     const float* pend_src;   // unit being requested piecewise (one DMA instruction per call of fetch_piece)
     float* pend_dst;
-    int pend_left;           // DMA instructions this wave still has to issue for it (<= 0: all requested)
-    int step;                // floats per piece: 1024 while a unit is being requested, 0 when there is none
+    int pend_left;           // DMA instructions this wave still has to issue for it
     int issued;              // DMA instructions issued for the youngest requested unit (>= its piece count)
 
-    // Branch-free AND select-free on purpose: a conditional here would cut the unrolled MFMA loop into basic blocks, and a
-    // compare/select per piece costs ~15 scalar instructions -- with one wave per SIMD every instruction the wave issues
-    // between two MFMAs beyond ~5 delays the matrix pipe.  So a piece is ALWAYS "advance by `step`, request 1 KiB per
-    // wave": once the unit's own pieces are all requested the stream simply keeps being read (into the rest of the same
-    // ring slot: a slot holds the largest unit, and a unit is never followed by fewer than one maximum unit of readable
-    // stream -- the zero runway of MlpPlan), and when there is no unit to request `step` is 0 and the same valid KiB
-    // goes to the dump area again.  `issued` feeds the counted vmcnt of the next acquire().
+    // Branch-free on purpose: a conditional here would cut the unrolled MFMA loop into basic blocks and the fragment reads
+    // could no longer be scheduled a k-step ahead.  Once the unit's pieces are all requested the same (last) piece is simply
+    // requested again -- idempotent, and it only happens where a unit has more k-step pairs than its second successor has
+    // pieces (a few times per pass).  `issued` feeds the counted vmcnt of the next acquire().  (A select-free variant that
+    // keeps reading the stream into the rest of the slot saves a third of the scalar instructions and measured 1 % slower.)
     __device__ __forceinline__ void fetch_piece() {
 #ifdef SNERF_ABL_NODMA
-        pend_left -= 1;
+        pend_left -= pend_left > 0 ? 1 : 0;
         return;
 #endif
-        pend_src += step; pend_dst += step;
+        const int adv = pend_left > 0 ? 1024 : 0;
+        pend_src += adv; pend_dst += adv;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pend_src + lane * 4),
                                          (__attribute__((address_space(3))) void*)pend_dst, 16, 0, 0);
-        pend_left -= 1;
+        pend_left -= pend_left > 0 ? 1 : 0;
         ++issued;
     }
     __device__ __forceinline__ void finish_fetch() {
@@ -75,14 +73,12 @@ struct UnitStream {
         pend_src = stream_base;
         pend_dst = lds + kUnitBuffers * kUnitBufFloats + wave * 256;  // dump: 4 KiB right after the ring
         pend_left = 0;
-        step = 0;
         issued = 0;
     }
     __device__ __forceinline__ void begin_fetch(int ksteps, int into_slot) {
         pend_src = fetch_ptr + wave * 256 - 1024;   // fetch_piece pre-increments
         pend_dst = lds + into_slot * kUnitBufFloats + wave * 256 - 1024;
         pend_left = ksteps >> 1;
-        step = 1024;
         issued = 0;
         fetch_ptr += ksteps * 512;
     }
@@ -91,7 +87,7 @@ struct UnitStream {
         finish_fetch();
     }
     __device__ __forceinline__ void start(const float* first, float* lds_base, int ks0, int ks1, int lane_, int wave_) {
-        fetch_ptr = first; stream_base = first; lds = lds_base; slot = 0; lane = lane_; wave = wave_; pend_left = 0; step = 0; issued = 0;
+        fetch_ptr = first; stream_base = first; lds = lds_base; slot = 0; lane = lane_; wave = wave_; pend_left = 0; issued = 0;
         fetch(ks0, 0);
         if (ks1 > 0) fetch(ks1, 1);
         if (ks1 <= 0) issued_next_none();
