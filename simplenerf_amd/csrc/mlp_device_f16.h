@@ -4,6 +4,8 @@
 #include "mlp_device.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kUnitBufFloats = 22 * 512;  // largest unit: 22 k-steps x 2 KiB (views layer of the points-aug MLP)
 constexpr int kUnitBuffers = 3;
@@ -206,13 +208,20 @@ __device__ __forceinline__ void split_tile(const f32x16& acc, f16x8& h0, f16x8& 
     h0[0] = (_Float16)acc[0]; l0[0] = (_Float16)acc[1]; h1[0] = (_Float16)acc[8]; l1[0] = (_Float16)acc[9];
     return;
 #endif
+    // two values at a time, so that each conversion is one packed instruction (v_cvt_pk_f16_f32, round to nearest even)
+    // and the halves land in adjacent lanes of the fragment without separate packing moves
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float a = acc[j], b = acc[8 + j];
-        if (RELU) { a = fmaxf(a, 0.0f); b = fmaxf(b, 0.0f); }
-        const _Float16 ah = (_Float16)a, bh = (_Float16)b;
-        h0[j] = ah; l0[j] = (_Float16)(a - (float)ah);
-        h1[j] = bh; l1[j] = (_Float16)(b - (float)bh);
+    for (int j = 0; j < 8; j += 2) {
+        f32x2 a = {acc[j], acc[j + 1]}, b = {acc[8 + j], acc[9 + j]};
+        if (RELU) {
+            a = {fmaxf(a[0], 0.0f), fmaxf(a[1], 0.0f)};
+            b = {fmaxf(b[0], 0.0f), fmaxf(b[1], 0.0f)};
+        }
+        const f16x2 ah = __builtin_convertvector(a, f16x2), bh = __builtin_convertvector(b, f16x2);
+        const f16x2 al = __builtin_convertvector(a - __builtin_convertvector(ah, f32x2), f16x2);
+        const f16x2 bl = __builtin_convertvector(b - __builtin_convertvector(bh, f32x2), f16x2);
+        h0[j] = ah[0]; h0[j + 1] = ah[1]; l0[j] = al[0]; l0[j + 1] = al[1];
+        h1[j] = bh[0]; h1[j + 1] = bh[1]; l1[j] = bl[0]; l1[j + 1] = bl[1];
     }
 }
 
