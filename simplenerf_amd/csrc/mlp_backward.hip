@@ -178,12 +178,17 @@ __device__ __forceinline__ void split_fragment(const float* __restrict__ row, in
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(row + ((c0 ^ swz) << 2));
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + (((c0 + 1) ^ swz) << 2));
     sum += (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    // two values at a time: every conversion is one packed instruction and the halves land in adjacent fragment lanes
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float a = v0[j] * k, b = v1[j] * k;
-        const _Float16 ah = (_Float16)a, bh = (_Float16)b;
-        hi[j] = ah; lo[j] = (_Float16)(a - (float)ah);
-        hi[4 + j] = bh; lo[4 + j] = (_Float16)(b - (float)bh);
+    for (int j = 0; j < 4; j += 2) {
+        const f32x2 a = f32x2{v0[j], v0[j + 1]} * k, b = f32x2{v1[j], v1[j + 1]} * k;
+        const f16x2 ah = __builtin_convertvector(a, f16x2), bh = __builtin_convertvector(b, f16x2);
+        const f16x2 al = __builtin_convertvector(a - __builtin_convertvector(ah, f32x2), f16x2);
+        const f16x2 bl = __builtin_convertvector(b - __builtin_convertvector(bh, f32x2), f16x2);
+        hi[j] = ah[0]; hi[j + 1] = ah[1]; lo[j] = al[0]; lo[j + 1] = al[1];
+        hi[4 + j] = bh[0]; hi[5 + j] = bh[1]; lo[4 + j] = bl[0]; lo[5 + j] = bl[1];
     }
 }
 
