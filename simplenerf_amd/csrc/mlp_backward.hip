@@ -39,15 +39,19 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[U]) {
 // dy[n] = (the forward's activation of the same feature was > 0) ? acc : 0, in accumulator order.  The signs come
 // from the mask words the training forward wrote (MlpPlan::act_mask): 4 bytes per lane per two tiles instead of
 // re-reading the 32-sample x 32-feature activation tiles (1 KB instead of 32 KB per layer and wave block).
+// The words of a layer are requested one layer ahead of their use (load_relu_words), so that their L2 latency hides under
+// the layer's products instead of sitting in front of them.
 template <int U>
-__device__ __forceinline__ void relu_backward(const f32x16 (&acc)[U], const unsigned* __restrict__ masks, int t0, int lane,
-                                              float (&dy)[U * 16]) {
+__device__ __forceinline__ void load_relu_words(unsigned (&words)[U / 2], const unsigned* __restrict__ masks, int t0, int lane) {
 #pragma unroll
-    for (int u = 0; u < U; u += 2) {
-        const unsigned word = masks[((t0 + u) >> 1) * 64 + lane];
+    for (int p = 0; p < U / 2; ++p) words[p] = masks[((t0 >> 1) + p) * 64 + lane];
+}
+template <int U>
+__device__ __forceinline__ void relu_backward(const f32x16 (&acc)[U], const unsigned (&words)[U / 2], float (&dy)[U * 16]) {
 #pragma unroll
-        for (int r = 0; r < 32; ++r) dy[16 * u + r] = (word >> r) & 1u ? acc[u + (r >> 4)][r & 15] : 0.0f;
-    }
+    for (int u = 0; u < U; u += 2)
+#pragma unroll
+        for (int r = 0; r < 32; ++r) dy[16 * u + r] = (words[u >> 1] >> r) & 1u ? acc[u + (r >> 4)][r & 15] : 0.0f;
 }
 
 template <int WT, int VT, bool VIEWDEP>
@@ -130,9 +134,12 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_kernel(ChainArgs a)
         }
     }
     // ---- trunk, last layer first: dY_l = dh_{l+1} . [h_{l+1} > 0];  dh_l = W_l[:, h-columns]^T dY_l -------------
+    unsigned relu_words[WT / 2];
+    load_relu_words<WT>(relu_words, masks, (a.depth - 1) * WT, lane);
 #pragma unroll 1
     for (int l = a.depth - 1; l >= 0; --l) {
-        relu_backward<WT>(acc, masks, l * WT, lane, dy);
+        relu_backward<WT>(acc, relu_words, dy);
+        if (l > 0) load_relu_words<WT>(relu_words, masks, (l - 1) * WT, lane);   // in flight during this layer's products
         store_acc_tile(dy, grads + (l * a.width) * 32, lane);
         if (l == 0) break;
         zero_acc<WT>(acc);
