@@ -136,3 +136,21 @@ def test_graphed_training_pass_equals_eager(precision):
     assert [p.grad.data_ptr() for p in graphed.parameters()] == grad_ptrs
     for a, b in zip(eager.parameters(), graphed.parameters()):
         assert torch.equal(a.grad, b.grad)
+
+
+def test_readme_quick_start_runs():
+    """The snippet in README.md (training iteration + frame render through the reference's interfaces)."""
+    from simplenerf_amd import harness
+    from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
+    from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
+    from simplenerf_amd.models.ModelFactory import get_model
+    cfg = synth.training_configs('f16x3', num_rays=256, num_sparse=64)
+    model = get_model(cfg, None).cuda().train()
+    batches = BatchAssembler(cfg, synth.training_scene(0, 3, 48, 64, 0.05), 'cuda:0')
+    losses, opt = LossComputer(cfg), optim.Adam(list(model.parameters()), lr=5e-4)
+    totals = harness.train_one_iter(model, losses, opt, batches.get_next_batch(0), 160)
+    assert torch.isfinite(totals['TotalLoss'])
+    cam = synth.camera('fern', 0, downscale=16)
+    frame = harness.render_frame(model.eval(), cam, True, 'cuda:0')
+    h, w = cam['resolution']
+    assert frame['rgb_fine'].shape == (h * w, 3) and torch.isfinite(frame['rgb_fine']).all()
