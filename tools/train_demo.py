@@ -2,7 +2,8 @@
 """End-to-end training sanity run on one MI355X: the synthetic 3-view plane scene (synth.training_scene at 96x128),
 every stage on the device (BatchAssembler -> SimpleNeRFHip -> LossComputer -> optim.Adam with the NeRF decay), a few
 hundred iterations.  Prints the loss curve and the PSNR of a training view rendered before and after.
-    python tools/train_demo.py [iterations]            (SNERF_PREC=f16x3 for the split-precision kernels)"""
+    python tools/train_demo.py [iterations]            (SNERF_PREC=f16x3 for the split-precision kernels;
+                                                        SNERF_GRAPH=1 replays the pass from one HIP graph)"""
 import json
 import math
 import os
@@ -47,17 +48,31 @@ def main():
     decayer = get_lr_decayer(cfg)
     before = psnr_of_view(model, scene, 0)
     curve = []
+    graphed = None
+    if os.environ.get('SNERF_GRAPH') == '1':
+        graphed = harness.GraphedTrainStep(model, losses, batcher.get_next_batch(0))
+        batcher = BatchAssembler(cfg, scene, DEV)       # restart the index stream after the sample batch
+    worst = 0.0
     t0 = time.perf_counter()
     for it in range(iters):
         for group in opt.param_groups:
             group['lr'] = decayer.get_updated_learning_rate(it)
-        totals = harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it), cfg['sub_batch_size'])
+        if graphed is None:
+            totals = harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it), cfg['sub_batch_size'])
+        else:
+            totals = graphed(batcher.get_next_batch(it))
+            opt.step()
+        if it % 50 == 0:
+            value = float(totals['TotalLoss'])
+            if not math.isfinite(value):
+                raise SystemExit(f'non-finite loss at iteration {it}')
+            worst = max(worst, value)
         if it % max(1, iters // 10) == 0 or it == iters - 1:
             curve.append({'iter': it, 'TotalLoss': float(totals['TotalLoss']), 'MSE01': float(totals['MSE01'])})
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     after = psnr_of_view(model, scene, 0)
-    print(json.dumps({'precision': precision, 'iterations': iters, 'seconds': dt, 'psnr_view0_before': before,
+    print(json.dumps({'precision': precision, 'graph': graphed is not None, 'iterations': iters, 'seconds': dt, 'psnr_view0_before': before,
                       'psnr_view0_after': after, 'curve': curve}, indent=1))
 
 
