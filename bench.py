@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: rays/sec of the ray-marching hot path (coarse+fine, 128+128 samples, 8x256 MLPs).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (--train: BASELINE config 5 instead, see train_bench)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
@@ -89,8 +89,70 @@ def pmc_traffic(precision):
     return None
 
 
+def train_bench(args, rank, world, device, dist):
+    """--train: BASELINE config 5 instead of the headline metric.  One step = the reference's training iteration
+    (Trainer.train_one_iter) with every stage on the device: batch assembly (2048 pixel + 2048 sparse-depth rows per GPU,
+    each rank a slice of one global index stream), four MLPs forward, nine losses, backward, ONE all-reduce of the
+    flattened gradients (RCCL) for N > 1, Adam with the decayed rate.  Weak scaling: 4096 rows per GPU."""
+    from simplenerf_amd import optim
+    from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
+    from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
+    from simplenerf_amd.lr_decayers.LearningRateDecayerFactory import get_lr_decayer
+    rows = 2048
+    cfg = synth.training_configs(args.precision, num_rays=rows * world, num_sparse=rows * world)
+    model = get_model(cfg, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
+    model = model.to(device).train()
+    batcher = BatchAssembler(cfg, synth.training_scene(), device, rank=rank, world_size=world)
+    losses = LossComputer(cfg)
+    opt = optim.Adam(list(model.parameters()), lr=cfg['optimizer']['lr_initial'],
+                     betas=(cfg['optimizer']['beta1'], cfg['optimizer']['beta2']))
+    decayer = get_lr_decayer(cfg)
+    state = {'iter': 20000}
+
+    def step():
+        it = state['iter']
+        state['iter'] += 1
+        for group in opt.param_groups:
+            group['lr'] = decayer.get_updated_learning_rate(it)
+        return harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it), cfg['sub_batch_size'], world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        per_gpu = 2 * rows
+        flop = per_gpu * (64 * 2 * (593408 + 577280 + 492032) + 192 * 2 * 593408) * 3      # forward x3 (dgrad + wgrad)
+        print(json.dumps({
+            'metric': 'training rays/sec (config 5: forward + backward + optimiser, 4 MLPs, 9 losses)',
+            'value': per_gpu * world * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'f16x3', 'data': 'synthetic',
+            'config': {'workload': 'config 5: 2048 pixel + 2048 sparse-depth rows per GPU in two sub-batches, main coarse+fine '
+                                   '+ points-aug + views-aug MLPs (64 + 192 samples), nine shipped losses, Adam, NeRF LR decay',
+                       'rows_per_gpu': per_gpu, 'parallelism': f'row-shard x{world}' + (' + 1 gradient all-reduce/step' if world > 1 else '')},
+            'algorithmic_tflops': flop * world * args.steps / elapsed / 1e12}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--train', action='store_true',
+                    help='measure BASELINE config 5 (training iteration) instead of the headline render metric')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
@@ -122,6 +184,13 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.train:
+        train_bench(args, rank, world, device, dist)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     configs = synth.make_configs('headline')
     camera = synth.camera('fern', 0)
