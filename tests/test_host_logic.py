@@ -150,3 +150,25 @@ def test_optimizer_state_and_checkpoints_interchange_with_the_reference_format(t
         assert torch.equal(a, b), k
     torch.save({'iteration_num': 3, 'model_state_dict': model.state_dict()}, path)   # un-prefixed names load too
     assert checkpoint.load_checkpoint(path, other) == 3
+
+
+def test_batch_assembler_epoch_and_shard_arithmetic():
+    """Host logic of BatchAssembler without a GPU: epoch slicing (the reference's indices[i:i+n] with the wrap rule,
+    DataPreprocessor01.py:559-563) and the per-rank slice of a batch."""
+    from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
+    asm = BatchAssembler.__new__(BatchAssembler)
+    cursor = epoch = 0
+    seen = []
+    for _ in range(7):
+        first, count, cursor, epoch = asm._next_slice(cursor, epoch, 300, 1000)
+        seen.append((first, count, cursor, epoch))
+    assert seen[:4] == [(0, 300, 300, 0), (300, 300, 600, 0), (600, 300, 900, 0), (900, 100, 0, 1)]   # short last slice
+    assert seen[4] == (0, 300, 300, 1)
+    assert asm._next_slice(700, 0, 300, 1000) == (700, 300, 0, 1)                                     # exact fit wraps too
+    for world in (1, 2, 3, 8):
+        covered = []
+        for rank in range(world):
+            asm.rank, asm.world_size = rank, world
+            first, count = asm._shard(40, 100)
+            covered += list(range(first, first + count))
+        assert covered == list(range(40, 140))
