@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
         apply_relu_masks<VT>(dyvs, masks, a.depth * WT, lane);
 #pragma unroll
         for (int u = 0; u < VT; ++u) store_tile_rows_scaled(dyvs[u], grads + (a.grad_yv + 32 * u) * 32, lane, gback);
+        st.note_vmem(16 * VT);
         renormalise<VT>(dyvs, gscale, gback, a.dy_max ? a.dy_max + a.grad_yv / 32 : nullptr, lane);
 #pragma unroll
         for (int u = 0; u < VT; ++u) split_tile<false>(dyvs[u], vh[2 * u], vl[2 * u], vh[2 * u + 1], vl[2 * u + 1]);
@@ -153,6 +154,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
             for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
             seg_mfma<VK>(acc[u], unit, vh, vl, none, 8, st);
             store_tile_rows_scaled(acc[u], grads + (a.grad_feature + 32 * u) * 32, lane, gback);
+            st.note_vmem(16);
         }
         renormalise<WT>(acc, gscale, gback, a.dy_max ? a.dy_max + a.grad_feature / 32 : nullptr, lane);
 #pragma unroll
@@ -198,6 +200,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
         if (l > 0) load_relu_words<WT>(relu_words, masks, (l - 1) * WT, lane);   // in flight during this layer's products
 #pragma unroll
         for (int u = 0; u < WT; ++u) store_tile_rows_scaled(acc[u], dy_tile + 32 * u * 32, lane, gback);
+        st.note_vmem(16 * WT);
         unsigned* region = a.dy_max ? a.dy_max + (l * a.width) / 32 : nullptr;
         if (l == 0) {
             if (region) publish_max(region, tiles_max<WT>(acc) * gback, lane);

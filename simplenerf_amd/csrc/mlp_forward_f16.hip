@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
         tile_bias(acc[u], bias + 32 * u, half);
         seg_mfma<4>(acc[u], unit, pe_h, pe_l, none, 8, st);
         if (single) heads_from(acc[u], u);
-        if (STORE) store_tile_rows<true>(acc[u], tile + (a.act_h1 + 32 * u) * 32, lane);
+        if (STORE) { store_tile_rows<true>(acc[u], tile + (a.act_h1 + 32 * u) * 32, lane); st.note_vmem(16); }
     }
     if (STORE) store_relu_masks<WT>(acc, masks, 0, lane);
 #pragma unroll
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
             if (l == 5) seg_mfma<4>(acc[u], unit, pe_h, pe_l, none, 8, st);  // skip connection [encoding | h]
             seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
             if (last) heads_from(acc[u], u);
-            if (STORE) store_tile_rows<true>(acc[u], tile + (a.act_h1 + l * a.width + 32 * u) * 32, lane);
+            if (STORE) { store_tile_rows<true>(acc[u], tile + (a.act_h1 + l * a.width + 32 * u) * 32, lane); st.note_vmem(16); }
         }
         if (STORE) store_relu_masks<WT>(acc, masks, l * WT, lane);
 #pragma unroll
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
             const float* unit = next_unit();
             tile_bias(acc[u], bf + 32 * u, half);
             seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
-            if (STORE) store_tile_rows<false>(acc[u], tile + (a.act_feature + 32 * u) * 32, lane);
+            if (STORE) { store_tile_rows<false>(acc[u], tile + (a.act_feature + 32 * u) * 32, lane); st.note_vmem(16); }
         }
 #pragma unroll
         for (int u = 0; u < WT; ++u) split_tile<false>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
             seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
             if (SIGMA_PE) seg_mfma<4>(acc[u], unit, pe_h, pe_l, none, 8, st);
             seg_mfma<2>(acc[u], unit, pev_h, pev_l, none, 8, st);
-            if (STORE) store_tile_rows<true>(acc[u], tile + (a.act_hv + 32 * u) * 32, lane);
+            if (STORE) { store_tile_rows<true>(acc[u], tile + (a.act_hv + 32 * u) * 32, lane); st.note_vmem(16); }
 #pragma unroll
             for (int c = 0; c < 3; ++c) col[c] += tile_dot_relu(acc[u], wv + c * VT * 32 + 32 * u, half);
         }
