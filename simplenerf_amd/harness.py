@@ -247,3 +247,60 @@ class GraphedTrainStep:
             self.weights_key = key
         self.graph.replay()
         return self.totals
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# frame writer: what the reference's Tester does with a predicted frame (src/Tester01.py:69-92), without
+# its skimage dependency -- PNG through zlib, .npy through numpy
+def _png_bytes(array) -> bytes:
+    import struct
+    import zlib
+    import numpy
+    a = numpy.ascontiguousarray(array)
+    if a.dtype != numpy.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
+        raise RuntimeError(f'PNG writer takes uint8 (h,w) or (h,w,3) arrays, got {a.dtype} {a.shape}')
+    h, w = a.shape[:2]
+    rows = numpy.concatenate([numpy.zeros((h, 1), dtype=numpy.uint8), a.reshape(h, -1)], axis=1)   # filter type 0 per row
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    header = struct.pack('>IIBBBBB', w, h, 8, 2 if a.ndim == 3 else 0, 0, 0, 0)
+    return b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', header) + chunk(b'IDAT', zlib.compress(rows.tobytes(), 6)) + chunk(b'IEND', b'')
+
+
+def save_image(path, image) -> None:
+    """``image``: uint8 (h,w,3) array or tensor (e.g. ``to_display`` output reshaped); ``.png`` or ``.npy`` by suffix."""
+    import os
+    import numpy
+    path = os.fspath(path)
+    os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+    array = image.cpu().numpy() if isinstance(image, torch.Tensor) else numpy.asarray(image)
+    if path.endswith('.png'):
+        with open(path, 'wb') as f:
+            f.write(_png_bytes(array))
+    elif path.endswith('.npy'):
+        numpy.save(path, array)
+    else:
+        raise RuntimeError(f'Unknown image format: {path}')
+
+
+def save_depth(path, depth, as_png: bool = False) -> None:
+    """``depth``: float (h,w); ``.npy`` keeps the values (plus a PNG preview when ``as_png``), ``.png`` stores
+    round(depth / depth.max() * 255) like the reference (src/Tester01.py:80-92)."""
+    import os
+    import numpy
+    path = os.fspath(path)
+    os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+    array = depth.cpu().numpy() if isinstance(depth, torch.Tensor) else numpy.asarray(depth)
+    preview = numpy.round(array / array.max() * 255).astype('uint8')
+    if path.endswith('.png'):
+        with open(path, 'wb') as f:
+            f.write(_png_bytes(preview))
+    elif path.endswith('.npy'):
+        numpy.save(path, array)
+        if as_png:
+            with open(os.path.splitext(path)[0] + '.png', 'wb') as f:
+                f.write(_png_bytes(preview))
+    else:
+        raise RuntimeError(f'Unknown depth format: {path}')

@@ -172,3 +172,41 @@ def test_batch_assembler_epoch_and_shard_arithmetic():
             first, count = asm._shard(40, 100)
             covered += list(range(first, first + count))
         assert covered == list(range(40, 140))
+
+
+def test_frame_writer_round_trips(tmp_path):
+    """harness.save_image / save_depth (the Tester's frame writer, reference src/Tester01.py:69-92): the PNG decodes
+    back to the same pixels (parsed here with zlib only), .npy keeps the values, unknown suffixes raise."""
+    import struct
+    import zlib
+    import numpy
+    from simplenerf_amd import harness
+
+    def decode(path):
+        data = open(path, 'rb').read()
+        assert data[:8] == b'\x89PNG\r\n\x1a\n'
+        pos, chunks = 8, {}
+        while pos < len(data):
+            (n,), tag = struct.unpack('>I', data[pos:pos + 4]), data[pos + 4:pos + 8]
+            body = data[pos + 8:pos + 8 + n]
+            assert struct.unpack('>I', data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xFFFFFFFF
+            chunks[tag] = chunks.get(tag, b'') + body
+            pos += 12 + n
+        w, h, depth, colour = struct.unpack('>IIBB', chunks[b'IHDR'][:10])
+        channels = 3 if colour == 2 else 1
+        rows = numpy.frombuffer(zlib.decompress(chunks[b'IDAT']), dtype=numpy.uint8).reshape(h, 1 + w * channels)
+        assert depth == 8 and (rows[:, 0] == 0).all()
+        return rows[:, 1:].reshape((h, w, 3) if channels == 3 else (h, w))
+
+    rng = numpy.random.RandomState(0)
+    image = rng.randint(0, 256, size=(37, 53, 3)).astype(numpy.uint8)
+    harness.save_image(tmp_path / 'frames' / '0001.png', torch.from_numpy(image))
+    assert numpy.array_equal(decode(tmp_path / 'frames' / '0001.png'), image)
+    harness.save_image(tmp_path / 'frames' / '0001.npy', image)
+    assert numpy.array_equal(numpy.load(tmp_path / 'frames' / '0001.npy'), image)
+    depth = rng.uniform(0.5, 9.0, size=(37, 53)).astype(numpy.float32)
+    harness.save_depth(tmp_path / 'depth' / '0001.npy', depth, as_png=True)
+    assert numpy.array_equal(numpy.load(tmp_path / 'depth' / '0001.npy'), depth)
+    assert numpy.array_equal(decode(tmp_path / 'depth' / '0001.png'), numpy.round(depth / depth.max() * 255).astype('uint8'))
+    with pytest.raises(RuntimeError, match='Unknown image format'):
+        harness.save_image(tmp_path / 'x.jpg', image)
