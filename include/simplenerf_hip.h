@@ -91,9 +91,13 @@ int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* params, int n
 
 enum snerf_precision {
     SNERF_PRECISION_FP32 = 0, /* fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 FMA chains */
-    SNERF_PRECISION_F16X3 = 1 /* every operand split into two fp16 (hi + lo, ~22 significand bits), three fp16 MFMAs per
-                                 product (hi.hi + hi.lo + lo.hi), fp32 accumulate: fp32-grade results at 3/16 of the
-                                 fp32-MFMA time */
+    SNERF_PRECISION_F16X3 = 1, /* every operand split into two fp16 (hi + lo, ~22 significand bits), three fp16 MFMAs per
+                                  product (hi.hi + hi.lo + lo.hi), fp32 accumulate: fp32-grade results at 3/16 of the
+                                  fp32-MFMA time */
+    SNERF_PRECISION_F16 = 2    /* 16-bit mode: one fp16 MFMA per product (11 significand bits per operand), fp32 accumulate,
+                                  fp32 master weights, biases, heads and outputs; training keeps activations as fp16 and
+                                  layer gradients as bf16 (half the HBM traffic).  NOT within the fp32 parity bar: results
+                                  agree with the fp32 path to ~1e-3 (tests/test_gpu_f16.py states the tolerances) */
 };
 
 /*   origins, dirs   device (num_rays,3): the rays the depths are measured along (NDC rays when ndc)

@@ -20,10 +20,10 @@
 // rate: under the HBM roofline, overlapped with the matrix work.
 #include <algorithm>
 
-#include "mlp_device.h"
+#include "mlp_device_f16.h"
 
 namespace snerf {
-int mlp_backward_chain_f16x3(const MlpPlan& plan, const ChainArgs& a, hipStream_t stream);  // mlp_backward_f16.hip
+int mlp_backward_chain_f16x3(const MlpPlan& plan, const ChainArgs& a, int products, hipStream_t stream);  // mlp_backward_f16.hip
 }
 
 namespace {
@@ -162,9 +162,20 @@ struct WgradJob {
     int w_param, w_ld, w_col;           // destination: grad of params[w_param] (out_rows x w_ld), columns from w_col
     int b_param;                        // bias destination or -1
     int half;                           // 1: computed by the f16x3 kernel with dY scaled by wgrad_scale(max of its region)
+    // 16-bit tiles (SNERF_PRECISION_F16) are addressable per 16-row piece only:
+    int dy_skip;                        // rows of the first dY tile that belong to another job (head tile: sigma | rgb rows)
+    int x_kind;                         // SEG_ACC: X rows in natural order; SEG_POINTS_PE / SEG_VIEWS_PE: X is an encoding
+                                        // tile in REGISTER order -- column p of the product is encoding index
+                                        // pe_index(p) and only indices in [feat_lo, feat_hi) belong to this job
+    int feat_lo, feat_hi;
 };
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// Encoding index held at position p of a 16-bit encoding tile (forward: store_pieces of the pe_h fragments), or -1.
+__host__ __device__ inline int pe_position_feature(int p, int kind) {
+    const int c = p & 15;
+    const int n = 8 * (p >> 4) + 4 * (c >> 3) + (c & 3), h = (c >> 2) & 1;
+    return snerf::pe_feature(n, h, kind == snerf::SEG_POINTS_PE ? snerf::kPointsPairs : snerf::kViewsPairs, 16);
+}
 
 // One power-of-two scale per dY region for the f16x3 weight-gradient product (the contraction runs over the samples, so a
 // per-sample factor cannot be pulled out): max |dY| -> [2^9, 2^10).  Samples whose gradients are < 6e-11 of the largest
@@ -358,6 +369,172 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
     }
 }
 
+
+// ---- 16-bit weight gradients (SNERF_PRECISION_F16) ---------------------------------------------------------------
+// dW = dY . X^T with X kept as fp16 and dY as bf16 operand PIECES (mlp_device_f16.h store_pieces: 1 KiB = 32 samples x
+// 16 features, sample-major).  The contraction runs over the samples, so both operands are read back TRANSPOSED with
+// ds_read_b64_tr_b16 (4 samples x 16 features per 16-lane group; two reads = the 8 samples of a lane's k-step fragment):
+// X fragments go to the MFMA as they are, dY fragments are widened bf16 -> fp32, scaled by the region's power of two
+// (wgrad_scale) and narrowed to fp16 -- 2 of the 10 fragments of the large products.  One fp16 MFMA per product.
+// Bound: HBM (1 KiB per sample and 256x256 layer, against 32 MFMA cycles per wave and piece pair).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32x2 lds_read_tr16(unsigned lds_byte_address, int byte_offset) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_address), "i"(byte_offset) : "memory");
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ void after_lds_wait(T& v) {  // orders every use of v behind the preceding s_waitcnt asm
+    asm volatile("" : "+v"(v));
+}
+union Frag16 {
+    u32x2 d[2];
+    f16x8 h;
+};
+
+constexpr int kPairBytes = 2304;   // LDS image of one 32-row tile: piece 0 at +0, piece 1 at +1152 (bank phase +32 dwords:
+constexpr int kPieceGap = 1152;    // the two 16-lane groups of a half-wave read different pieces of the same tile)
+constexpr int kWgrad16Buffers = 3;
+
+template <int NO, int NI>
+__global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const unsigned short* __restrict__ grads,
+                                                         const unsigned short* __restrict__ acts, float* __restrict__ partial,
+                                                         const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    int ji = 0;
+    while (ji + 1 < table.count && (int)blockIdx.x >= table.wg_start[ji + 1]) ++ji;
+    const WgradJob& job = table.jobs[ji];
+    const int chunk = blockIdx.x - table.wg_start[ji];
+    const int rows_dy = job.out_tiles * 32;
+    const int wgrid_i = job.in_tiles / NI;
+    const int wo = wave / wgrid_i, wi = wave - wo * wgrid_i;
+    const bool active = wo * NO < job.out_tiles;
+    const long long per = (job.blocks + job.chunks - 1) / job.chunks;
+    const long long b0 = chunk * per, b1 = (b0 + per < job.blocks) ? b0 + per : job.blocks;
+
+    f32x16 acc[NO][NI];
+    float bsum[NO];
+#pragma unroll
+    for (int oo = 0; oo < NO; ++oo) {
+        bsum[oo] = 0.0f;
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[oo][ii][r] = 0.0f;
+    }
+
+    // Staging: one LDS-DMA instruction per piece (lane-linear 1 KiB).  Every wave issues the same number of instructions
+    // per block (surplus ones repeat the last piece) so that a counted vmcnt can leave later blocks in flight.
+    const int pieces_dy = job.out_tiles * 2, pieces = pieces_dy + job.in_tiles * 2;
+    const int per_wave = (pieces + 3) >> 2;
+    const int dy_pieces_real = (job.dy_skip + job.out_rows + 15) >> 4, x_pieces_real = (job.in_rows + 15) >> 4;
+    const int buf_floats = (job.out_tiles + job.in_tiles) * (kPairBytes / 4);
+    auto stage = [&](long long b, float* dst) {
+        for (int k = 0; k < per_wave; ++k) {
+            int q = wave + 4 * k;
+            if (q >= pieces) q = pieces - 1;
+            const float* src = zeros + (lane & 15) * 4;   // zero page: 256 bytes
+            if (q < pieces_dy) {
+                if (q < dy_pieces_real)
+                    src = reinterpret_cast<const float*>(grads + ((b * job.grad_rows + job.dy_row0) * 32 + q * 512)) + lane * 4;
+            } else if (q - pieces_dy < x_pieces_real) {
+                src = reinterpret_cast<const float*>(acts + ((b * job.act_rows + job.x_row0) * 32 + (q - pieces_dy) * 512)) + lane * 4;
+            }
+            lds_dma_16(src, dst + (q >> 1) * (kPairBytes / 4) + (q & 1) * (kPieceGap / 4));
+        }
+    };
+
+    // transposed-read address of this lane inside a tile image (T10): 16-lane group = (piece s, sample octet hh); lane
+    // 4q+p of the group points at sample row q, feature columns 4p..4p+3 of the piece
+    const int grp = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+    const unsigned lane_off = (grp & 1) * kPieceGap + 32 * (8 * (grp >> 1) + q4) + 16 * (p4 & 1) + 8 * (p4 >> 1);
+    const float gk = wgrad_scale(__uint_as_float(reinterpret_cast<const unsigned*>(zeros)[64 + job.dy_row0 / 32]));
+
+    const long long nblocks = b1 - b0;
+    for (int k = 0; k < kWgrad16Buffers - 1; ++k)
+        if (k < nblocks) stage(b0 + k, lds + k * buf_floats);
+    for (long long n = 0; n < nblocks; ++n) {
+        // block n must have landed; blocks n+1 (and the stores of nobody: this kernel stores only at the end) may fly
+        const long long ahead = nblocks - 1 - n < kWgrad16Buffers - 2 ? nblocks - 1 - n : kWgrad16Buffers - 2;
+        wait_vmcnt((int)ahead * per_wave);
+        __builtin_amdgcn_s_barrier();   // every wave's pieces of block n are in; everyone finished reading block n-1
+        if (n + kWgrad16Buffers - 1 < nblocks)
+            stage(b0 + n + kWgrad16Buffers - 1, lds + ((n + kWgrad16Buffers - 1) % kWgrad16Buffers) * buf_floats);
+        if (active) {
+            const unsigned cur = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(lds + (n % kWgrad16Buffers) * buf_floats) + lane_off;
+            const unsigned a_addr = cur + wo * NO * kPairBytes;
+            const unsigned b_addr = cur + (job.out_tiles + wi * NI) * kPairBytes;
+            // (one 16-sample k-step at a time, not unrolled: with both in flight the <2,8> tile spills, and a scratch
+            // reload inside this loop would make the compiler drain the prefetch DMA)
+#pragma unroll 1
+            for (int kk = 0; kk < 2; ++kk) {
+                Frag16 a[NO], bx[NI];
+                const unsigned a_kk = a_addr + kk * 512, b_kk = b_addr + kk * 512;
+#pragma unroll
+                for (int oo = 0; oo < NO; ++oo) {
+                    a[oo].d[0] = lds_read_tr16(a_kk, oo * kPairBytes);
+                    a[oo].d[1] = lds_read_tr16(a_kk, oo * kPairBytes + 128);
+                }
+#pragma unroll
+                for (int ii = 0; ii < NI; ++ii) {
+                    bx[ii].d[0] = lds_read_tr16(b_kk, ii * kPairBytes);
+                    bx[ii].d[1] = lds_read_tr16(b_kk, ii * kPairBytes + 128);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int oo = 0; oo < NO; ++oo) { after_lds_wait(a[oo].d[0]); after_lds_wait(a[oo].d[1]); }
+#pragma unroll
+                for (int ii = 0; ii < NI; ++ii) { after_lds_wait(bx[ii].d[0]); after_lds_wait(bx[ii].d[1]); }
+                f16x8 ah[NO];
+#pragma unroll
+                for (int oo = 0; oo < NO; ++oo) {
+                    // bf16 pairs -> fp32 (exact), bias sum in true units, x region scale -> fp16
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned word = a[oo].d[w >> 1][w & 1];
+                        const f32x2 v = {__uint_as_float(word << 16), __uint_as_float(word & 0xffff0000u)};
+                        bsum[oo] += v[0] + v[1];
+                        const f16x2 hcv = __builtin_convertvector(v * gk, f16x2);
+                        ah[oo][2 * w] = hcv[0]; ah[oo][2 * w + 1] = hcv[1];
+                    }
+                }
+#pragma unroll
+                for (int oo = 0; oo < NO; ++oo)
+#pragma unroll
+                    for (int ii = 0; ii < NI; ++ii)
+                        acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[oo], bx[ii].h, acc[oo][ii], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!active) return;
+    const int in_cols = job.in_tiles * 32;
+    float* out = partial + job.partial_off + (long long)chunk * rows_dy * in_cols;
+    float* bout = partial + job.bias_off + (long long)chunk * rows_dy;
+#pragma unroll
+    for (int oo = 0; oo < NO; ++oo) {
+        const int o = wo * NO + oo;
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii) {
+            const int i = wi * NI + ii;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                out[(long long)(o * 32 + row) * in_cols + i * 32 + (lane & 31)] = acc[oo][ii][r];
+            }
+        }
+        if (wi == 0) {
+            const float sum = bsum[oo] + __shfl_xor(bsum[oo], 32, 64);
+            if (half == 0) bout[o * 32 + lane] = sum;
+        }
+    }
+}
+
 // B3: fixed-order sum over chunks, scattered into the reference-layout gradient tensors.  A block owns 64 consecutive
 // output elements; its four waves each fold a quarter of the chunks (coalesced 256-byte rows, eight independent loads
 // in flight per lane -- the small head/encoding jobs have few outputs but up to 512 chunks, so a single serial loop
@@ -385,11 +562,11 @@ __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float
             if (idx < nw) {
                 o = (int)(idx / job.in_rows);
                 i = (int)(idx - (long long)o * job.in_rows);
-                p = partial + job.partial_off + (long long)o * in_cols + i;
+                p = partial + job.partial_off + (long long)(o + job.dy_skip) * in_cols + i;
                 stride = (long long)rows_dy * in_cols;
             } else {
                 o = (int)(idx - nw);
-                p = partial + job.bias_off + o;
+                p = partial + job.bias_off + o + job.dy_skip;
                 stride = rows_dy;
             }
             int c = c0;
@@ -406,8 +583,16 @@ __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float
         __syncthreads();
         if (wave == 0 && idx < total) {
             const float sum = ((quarter[0][lane] + quarter[1][lane]) + quarter[2][lane]) + quarter[3][lane];
-            if (idx < nw) grad_w[(long long)o * job.w_ld + job.w_col + i] = sum * unscale;
-            else grad_b[o] = sum;
+            if (idx < nw) {
+                int col = i;
+                if (job.x_kind != snerf::SEG_ACC) {   // 16-bit encoding tile: position -> encoding index (or padding)
+                    const int e = pe_position_feature(i, job.x_kind);
+                    col = (e >= job.feat_lo && e < job.feat_hi) ? e - job.feat_lo : -1;
+                }
+                if (col >= 0) grad_w[(long long)o * job.w_ld + job.w_col + col] = sum * unscale;
+            } else {
+                grad_b[o] = sum;
+            }
         }
         __syncthreads();
     }
@@ -426,28 +611,43 @@ struct Workspace {
     std::vector<WgradJob> jobs;
 };
 
-Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples) {
+// `f16`: SNERF_PRECISION_F16 -- dY and X are 16-bit operand pieces (same row numbers; encoding tiles in register order)
+Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool f16 = false) {
     Workspace w;
     const long long blocks = (total_samples + 127) / 128 * 4;
-    w.grads_floats = blocks * p.grad_rows() * 32;
+    w.grads_floats = blocks * p.grad_rows() * 32;   // (the 16-bit tiles use the first half)
     long long off = 192;  // [0, 64): zero page for padded rows; [64, 192): per-region max |dY| words (f16x3)
-    auto add = [&](int dy_row0, int out_rows, int x_row0, int in_rows, int w_param, int w_ld, int w_col, int b_param) {
+    auto add = [&](int dy_row0, int out_rows, int x_row0, int in_rows, int w_param, int w_ld, int w_col, int b_param,
+                   int x_kind = snerf::SEG_ACC) {
         WgradJob j;
-        j.dy_row0 = dy_row0; j.out_rows = out_rows; j.out_tiles = (out_rows + 31) / 32;
-        j.x_row0 = x_row0; j.in_rows = in_rows; j.in_tiles = (in_rows + 31) / 32;
-        j.grad_rows = p.grad_rows(); j.act_rows = p.act_rows();
+        j.dy_row0 = dy_row0; j.out_rows = out_rows; j.dy_skip = 0;
+        j.x_row0 = x_row0; j.in_rows = in_rows; j.x_kind = snerf::SEG_ACC; j.feat_lo = 0; j.feat_hi = 0;
+        if (f16) {
+            j.dy_skip = dy_row0 % 32;                 // the head tile's rgb rows
+            j.dy_row0 = dy_row0 - j.dy_skip;
+            if (x_kind != snerf::SEG_ACC) {           // the whole encoding tile; the reduction picks this job's indices
+                const int tile_row0 = x_kind == snerf::SEG_POINTS_PE ? p.act_pe() : p.act_pev();
+                j.x_kind = x_kind;
+                j.feat_lo = x_row0 - tile_row0; j.feat_hi = j.feat_lo + in_rows;
+                j.x_row0 = tile_row0;
+                j.in_rows = x_kind == snerf::SEG_POINTS_PE ? 64 : 32;
+            }
+        }
+        j.out_tiles = (j.dy_skip + out_rows + 31) / 32;
+        j.in_tiles = (j.in_rows + 31) / 32;
+        j.grad_rows = f16 ? p.grad16_rows() : p.grad_rows(); j.act_rows = f16 ? p.act16_rows() : p.act_rows();
         j.chunks = 1; j.blocks = blocks; j.partial_off = 0; j.bias_off = 0;
-        j.w_param = w_param; j.w_ld = w_ld; j.w_col = w_col; j.b_param = b_param; j.half = 0;
+        j.w_param = w_param; j.w_ld = w_ld; j.w_col = w_col; j.b_param = b_param; j.half = f16 ? 1 : 0;
         w.jobs.push_back(j);
     };
     const int d = p.depth, wd = p.width;
     // trunk layer l: dY_l x [encoding | h_l]
-    add(p.grad_y(0), wd, p.act_pe(), p.pts_in, 0, p.pts_in, 0, 1);
+    add(p.grad_y(0), wd, p.act_pe(), p.pts_in, 0, p.pts_in, 0, 1, snerf::SEG_POINTS_PE);
     for (int l = 1; l < d; ++l) {
         const bool skip_in = (l == 5);
         const int ld = wd + (skip_in ? p.pts_in : 0);
         add(p.grad_y(l), wd, p.act_h(l), wd, 2 * l, ld, skip_in ? p.pts_in : 0, 2 * l + 1);
-        if (skip_in) add(p.grad_y(l), wd, p.act_pe(), p.pts_in, 2 * l, ld, 0, -1);
+        if (skip_in) add(p.grad_y(l), wd, p.act_pe(), p.pts_in, 2 * l, ld, 0, -1, snerf::SEG_POINTS_PE);
     }
     // heads: rows of the head tile are [d sigma_raw, d rgb_pre(3)]
     if (p.view_dependent) {
@@ -455,8 +655,9 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples) {
         add(p.grad_feature(), wd, p.act_h(d), wd, 2 * d + 2, wd, 0, 2 * d + 3);               // feature_linear
         const int ldv = wd + p.extra + p.views_pe;
         add(p.grad_yv(), p.views_width, p.act_feature(), wd, 2 * d + 4, ldv, 0, 2 * d + 5);    // views_linears.0 | feature
-        if (p.sigma_pe) add(p.grad_yv(), p.views_width, p.act_pe() + p.pts_in, p.extra, 2 * d + 4, ldv, wd, -1);
-        add(p.grad_yv(), p.views_width, p.act_pev(), p.views_pe, 2 * d + 4, ldv, wd + p.extra, -1);
+        if (p.sigma_pe)
+            add(p.grad_yv(), p.views_width, p.act_pe() + p.pts_in, p.extra, 2 * d + 4, ldv, wd, -1, snerf::SEG_POINTS_PE);
+        add(p.grad_yv(), p.views_width, p.act_pev(), p.views_pe, 2 * d + 4, ldv, wd + p.extra, -1, snerf::SEG_VIEWS_PE);
         add(p.grad_head() + 1, 3, p.act_hv(), p.views_width, 2 * d + 6, p.views_width, 0, 2 * d + 7);  // views_output_linear
     } else {
         add(p.grad_head(), 4, p.act_h(d), wd, 2 * d, wd, 0, 2 * d + 1);                      // pts_output_linear (4 rows)
@@ -542,10 +743,30 @@ int launch_wgrad(const JobTable& table, const float* grads, const float* acts, f
 
 }  // namespace
 
+template <int NO, int NI>
+int launch_wgrad16(const JobTable& table, const float* grads, const float* acts, float* partial, hipStream_t stream) {
+    int max_tiles = 0;
+    for (int j = 0; j < table.count; ++j) max_tiles = std::max(max_tiles, table.jobs[j].out_tiles + table.jobs[j].in_tiles);
+    const size_t lds_bytes = (size_t)kWgrad16Buffers * max_tiles * kPairBytes;
+    auto kernel = wgrad16_kernel<NO, NI>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kWgrad16Buffers * 16 * kPairBytes);
+        if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)table.wg_start[table.count]), dim3(256), lds_bytes, stream, table,
+                       reinterpret_cast<const unsigned short*>(grads), reinterpret_cast<const unsigned short*>(acts), partial,
+                       partial);
+    return snerf::check_launch("mlp_backward(wgrad16)");
+}
+
 extern "C" size_t snerf_mlp_backward_workspace_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples) {
     snerf::MlpPlan plan;
     if (snerf::build_plan(desc, &plan) != SNERF_OK || num_rays < 0 || num_samples < 1) return 0;
-    return (size_t)plan_workspace(plan, num_rays * num_samples).total_floats;
+    return (size_t)std::max(plan_workspace(plan, num_rays * num_samples, false).total_floats,
+                            plan_workspace(plan, num_rays * num_samples, true).total_floats);
 }
 
 extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packed, const float* saved_acts,
@@ -561,12 +782,13 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
                   num_params);
     for (int i = 0; i < num_params; ++i) SNERF_REQUIRE(param_grads[i], "mlp_backward: gradient tensor %d is NULL", i);
     SNERF_REQUIRE(num_rays >= 1 && num_samples >= 1, "mlp_backward: bad sizes n=%lld S=%d", num_rays, num_samples);
-    if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3)
+    if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3 && precision != SNERF_PRECISION_F16)
         return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: precision %d not built", precision);
+    const bool f16 = precision == SNERF_PRECISION_F16;   // saved_acts must come from forward_train at the same precision
     const long long total = num_rays * num_samples;
     if ((total + 127) / 128 > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many samples");
     hipStream_t s = (hipStream_t)stream;
-    const Workspace ws = plan_workspace(plan, total);
+    const Workspace ws = plan_workspace(plan, total, f16);
     float* grads = workspace;
     float* partial = workspace + ws.grads_floats;
 
@@ -577,15 +799,16 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     a.act_rows = plan.act_rows(); a.act_h1 = plan.act_h(1); a.act_hv = plan.act_hv(); a.act_mask = plan.act_mask();
     a.grad_rows = plan.grad_rows(); a.grad_feature = plan.grad_feature(); a.grad_yv = plan.grad_yv();
     a.grad_head = plan.grad_head();
+    if (f16) { a.act_rows = plan.act16_rows(); a.grad_rows = plan.grad16_rows(); }
     // partial[0..64): zero page for padded staging rows; partial[64..192): per-region max |dY| (f16x3)
     hipError_t he = hipMemsetAsync(partial, 0, 192 * sizeof(float), s);
     if (he != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: memset: %s", hipGetErrorString(he));
     int rc;
-    const int key = precision == SNERF_PRECISION_F16X3 ? -1 : plan.wt * 10 + plan.vt;
+    const int key = precision != SNERF_PRECISION_FP32 ? -1 : plan.wt * 10 + plan.vt;
     a.dy_max = nullptr;
-    if (precision == SNERF_PRECISION_F16X3) {
+    if (precision != SNERF_PRECISION_FP32) {
         a.dy_max = reinterpret_cast<unsigned*>(partial) + 64;
-        rc = snerf::mlp_backward_chain_f16x3(plan, a, s);
+        rc = snerf::mlp_backward_chain_f16x3(plan, a, f16 ? 1 : 3, s);
         if (rc != SNERF_OK) return rc;
     }
     switch (key) {
@@ -605,7 +828,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     for (WgradJob& job : jobs) {
         int no, ni;
         wave_tile(job, &no, &ni);
-        job.half = (precision == SNERF_PRECISION_F16X3 && ni == 8) ? 1 : 0;
+        job.half = (f16 || (precision == SNERF_PRECISION_F16X3 && ni == 8)) ? 1 : 0;
     }
     // (the zero page and the gradient-max word were cleared before the chain kernel)
     JobTable table;  // all jobs, for the reduction
@@ -632,9 +855,18 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
             ++sub.count;
         }
         if (sub.count == 0) continue;
-        const bool f16 = precision == SNERF_PRECISION_F16X3;
-        if (cls[0] == 2 && cls[1] == 8 && f16) rc = launch_wgrad<2, 8, true>(sub, grads, saved_acts, partial, partial, s);
-        else if (cls[0] == 1 && cls[1] == 8 && f16) rc = launch_wgrad<1, 8, true>(sub, grads, saved_acts, partial, partial, s);
+        const bool x3 = precision == SNERF_PRECISION_F16X3;
+        if (f16) {
+            if (cls[0] == 2 && cls[1] == 8) rc = launch_wgrad16<2, 8>(sub, grads, saved_acts, partial, s);
+            else if (cls[0] == 2 && cls[1] == 2) rc = launch_wgrad16<2, 2>(sub, grads, saved_acts, partial, s);
+            else if (cls[0] == 2 && cls[1] == 1) rc = launch_wgrad16<2, 1>(sub, grads, saved_acts, partial, s);
+            else if (cls[0] == 1 && cls[1] == 8) rc = launch_wgrad16<1, 8>(sub, grads, saved_acts, partial, s);
+            else if (cls[0] == 1 && cls[1] == 4) rc = launch_wgrad16<1, 4>(sub, grads, saved_acts, partial, s);
+            else if (cls[0] == 1 && cls[1] == 2) rc = launch_wgrad16<1, 2>(sub, grads, saved_acts, partial, s);
+            else rc = launch_wgrad16<1, 1>(sub, grads, saved_acts, partial, s);
+        }
+        else if (cls[0] == 2 && cls[1] == 8 && x3) rc = launch_wgrad<2, 8, true>(sub, grads, saved_acts, partial, partial, s);
+        else if (cls[0] == 1 && cls[1] == 8 && x3) rc = launch_wgrad<1, 8, true>(sub, grads, saved_acts, partial, partial, s);
         else if (cls[0] == 2 && cls[1] == 8) rc = launch_wgrad<2, 8>(sub, grads, saved_acts, partial, partial, s);
         else if (cls[0] == 2 && cls[1] == 2) rc = launch_wgrad<2, 2>(sub, grads, saved_acts, partial, partial, s);
         else if (cls[0] == 2 && cls[1] == 1) rc = launch_wgrad<2, 1>(sub, grads, saved_acts, partial, partial, s);

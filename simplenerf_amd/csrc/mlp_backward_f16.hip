@@ -64,7 +64,36 @@ __device__ __forceinline__ void renormalise(f32x16 (&acc)[U], float& gscale, flo
     gback = 1.0f / gscale;
 }
 
-template <int WT, int VT, bool VIEWDEP>
+// dY tile(s) of this wave block -> the weight-gradient kernel's input.  P = 3: fp32 [feature][32-sample] rows, true scale.
+// P = 1 (SNERF_PRECISION_F16): bf16 operand pieces (store_pieces layout; bf16 because its exponent range needs no
+// per-region scale at this point -- the region maxima are only complete when the whole chain kernel has finished).
+template <int P, int U>
+__device__ __forceinline__ void store_dy(const f32x16 (&acc)[U], float* __restrict__ grads, int row0, int lane, float k) {
+    if constexpr (P == 3) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) store_tile_rows_scaled(acc[u], grads + (row0 + 32 * u) * 32, lane, k);
+    } else {
+        __bf16* rows = reinterpret_cast<__bf16*>(grads) + row0 * 32;
+        const int slot = 2 * (lane & 31) + (lane >> 5);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 f = f32x2{acc[u][8 * s + e], acc[u][8 * s + e + 1]} * k;
+                    const bf16x2 b = __builtin_convertvector(f, bf16x2);
+                    v[e] = b[0]; v[e + 1] = b[1];
+                }
+                *reinterpret_cast<bf16x8*>(rows + (2 * u + s) * 512 + slot * 8) = v;
+            }
+    }
+}
+template <int P>
+constexpr int dy_stores(int tiles) { return P == 3 ? 16 * tiles : 2 * tiles; }
+
+template <int WT, int VT, bool VIEWDEP, int P>
 __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfChainArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ChainArgs& a = args.c;
@@ -82,7 +111,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
         if (VIEWDEP && idx < WT) return VK;
         return HK;
     };
-    UnitStream st;
+    UnitStreamT<P> st;
     st.start(a.packed + args.half_dgrad_offset, lds, ks_of(0), ks_of(1), lane, wave);
     int unit_idx = 0;
     auto next_unit = [&]() {
@@ -90,13 +119,16 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
         ++unit_idx;
         return p + lane * 4;
     };
-    const NoSide none;
-
     const long long block = (long long)blockIdx.x * 4 + wave;
     const long long first = block * 32 + (lane & 31);
     const bool live = first < a.total;
-    const unsigned* masks = reinterpret_cast<const unsigned*>(a.acts + (block * a.act_rows + a.act_mask) * 32);
-    float* grads = a.grads + block * a.grad_rows * 32;
+    // (P = 1: both buffers hold 16-bit rows -- a.act_rows / a.grad_rows count rows of 64 bytes; `grads` is then only
+    // ever used through store_dy, with row numbers)
+    const unsigned* masks = P == 3
+        ? reinterpret_cast<const unsigned*>(a.acts + (block * a.act_rows + a.act_mask) * 32)
+        : reinterpret_cast<const unsigned*>(reinterpret_cast<const _Float16*>(a.acts) + (block * a.act_rows + a.act_mask) * 32);
+    float* grads = P == 3 ? a.grads + block * a.grad_rows * 32
+                          : reinterpret_cast<float*>(reinterpret_cast<_Float16*>(a.grads) + block * a.grad_rows * 32);
 
     // ---- head gradients (pre-activation) -------------------------------------------------------------------------
     float dhead[4];
@@ -106,13 +138,23 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
         const float col = live ? a.rgb[first * 3 + c] : 0.0f;
         dhead[c + 1] = live ? a.d_rgb[first * 3 + c] * (col * (1.0f - col)) : 0.0f;
     }
-    if (half == 0) {
+    if (P == 3) {
+        if (half == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) grads[(a.grad_head + c) * 32 + (lane & 31)] = dhead[c];
+            for (int c = 0; c < 4; ++c) grads[(a.grad_head + c) * 32 + (lane & 31)] = dhead[c];
+        }
+    } else {
+        // first piece of the head tile: features 0..3 = the four head gradients, the rest zero
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)((half == 0 && e < 4) ? dhead[e & 3] : 0.0f);
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(grads) + a.grad_head * 32 + (2 * (lane & 31) + half) * 8) = v;
     }
     // Per-sample power-of-two scaling (see renorm_factor): `gscale` is the factor currently applied to this sample's
     // gradients inside the chain, `gback` = 1/gscale is applied whenever one of its dY tiles is stored.
-    float gscale = renorm_factor(fmaxf(fmaxf(fabsf(dhead[0]), fabsf(dhead[1])), fmaxf(fabsf(dhead[2]), fabsf(dhead[3]))));
+    const float head_max = fmaxf(fmaxf(fabsf(dhead[0]), fabsf(dhead[1])), fmaxf(fabsf(dhead[2]), fabsf(dhead[3])));
+    if (a.dy_max) publish_max(a.dy_max + a.grad_head / 32, head_max, lane);   // region scale of the head-weight products
+    float gscale = renorm_factor(head_max);
     if (!(gscale < 1.0e30f)) gscale = 1.0e30f;
     float gback = 1.0f / gscale;
     const float dsig_raw = dhead[0];  // re-enters below, after the views/feature products have been renormalised
@@ -140,9 +182,8 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
             }
         }
         apply_relu_masks<VT>(dyvs, masks, a.depth * WT, lane);
-#pragma unroll
-        for (int u = 0; u < VT; ++u) store_tile_rows_scaled(dyvs[u], grads + (a.grad_yv + 32 * u) * 32, lane, gback);
-        st.note_vmem(16 * VT);
+        store_dy<P, VT>(dyvs, grads, a.grad_yv, lane, gback);
+        st.note_vmem(dy_stores<P>(VT));
         renormalise<VT>(dyvs, gscale, gback, a.dy_max ? a.dy_max + a.grad_yv / 32 : nullptr, lane);
 #pragma unroll
         for (int u = 0; u < VT; ++u) split_tile<false>(dyvs[u], vh[2 * u], vl[2 * u], vh[2 * u + 1], vl[2 * u + 1]);
@@ -152,9 +193,10 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
             const float* unit = next_unit();
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
-            seg_mfma<VK>(acc[u], unit, vh, vl, none, 8, st);
-            store_tile_rows_scaled(acc[u], grads + (a.grad_feature + 32 * u) * 32, lane, gback);
-            st.note_vmem(16);
+            seg_product<P, VK>(acc[u], unit, VK, vh, vl, st);
+            const f32x16(&one)[1] = reinterpret_cast<const f32x16(&)[1]>(acc[u]);
+            store_dy<P, 1>(one, grads, a.grad_feature + 32 * u, lane, gback);
+            st.note_vmem(dy_stores<P>(1));
         }
         renormalise<WT>(acc, gscale, gback, a.dy_max ? a.dy_max + a.grad_feature / 32 : nullptr, lane);
 #pragma unroll
@@ -165,7 +207,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
             const float* unit = next_unit();
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
-            seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
+            seg_product<P, HK>(acc[u], unit, HK, xh, xl, st);
         }
     } else {
         zero_tiles<WT>(acc);
@@ -195,12 +237,10 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
     load_relu_words<WT>(relu_words, masks, (a.depth - 1) * WT, lane);
 #pragma unroll 1
     for (int l = a.depth - 1; l >= 0; --l) {
-        float* dy_tile = grads + (l * a.width) * 32;
         mask_with_words<WT>(acc, relu_words);
         if (l > 0) load_relu_words<WT>(relu_words, masks, (l - 1) * WT, lane);   // in flight during this layer's products
-#pragma unroll
-        for (int u = 0; u < WT; ++u) store_tile_rows_scaled(acc[u], dy_tile + 32 * u * 32, lane, gback);
-        st.note_vmem(16 * WT);
+        store_dy<P, WT>(acc, grads, l * a.width, lane, gback);
+        st.note_vmem(dy_stores<P>(WT));
         unsigned* region = a.dy_max ? a.dy_max + (l * a.width) / 32 : nullptr;
         if (l == 0) {
             if (region) publish_max(region, tiles_max<WT>(acc) * gback, lane);
@@ -214,17 +254,17 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
             const float* unit = next_unit();
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
-            seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
+            seg_product<P, HK>(acc[u], unit, HK, xh, xl, st);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int WT, int VT, bool VIEWDEP>
+template <int WT, int VT, bool VIEWDEP, int P>
 int launch_chain_half(const HalfChainArgs& args, hipStream_t stream) {
     const long long blocks = (args.c.total + 127) / 128;
     const size_t lds_bytes = sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024);  // ring + DMA dump area
-    auto kernel = mlp_backward_chain_f16x3_kernel<WT, VT, VIEWDEP>;
+    auto kernel = mlp_backward_chain_f16x3_kernel<WT, VT, VIEWDEP, P>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -240,16 +280,18 @@ int launch_chain_half(const HalfChainArgs& args, hipStream_t stream) {
 
 namespace snerf {
 
-int mlp_backward_chain_f16x3(const MlpPlan& plan, const ChainArgs& a, hipStream_t stream) {
+// products = 3: SNERF_PRECISION_F16X3.  products = 1: SNERF_PRECISION_F16 (a.act_rows / a.grad_rows describe 16-bit rows).
+int mlp_backward_chain_f16x3(const MlpPlan& plan, const ChainArgs& a, int products, hipStream_t stream) {
     HalfChainArgs args;
     args.c = a;
     args.half_dgrad_offset = plan.half_dgrad_offset;
     const int key = plan.wt * 10 + plan.vt;
+#define SNERF_CHAIN(WT_, VT_, VD_) return products == 3 ? launch_chain_half<WT_, VT_, VD_, 3>(args, stream) : launch_chain_half<WT_, VT_, VD_, 1>(args, stream)
     switch (key) {
-        case 84: return launch_chain_half<8, 4, true>(args, stream);
-        case 80: return launch_chain_half<8, 4, false>(args, stream);
-        case 42: return launch_chain_half<4, 2, true>(args, stream);
-        case 40: return launch_chain_half<4, 2, false>(args, stream);
+        case 84: SNERF_CHAIN(8, 4, true);
+        case 80: SNERF_CHAIN(8, 4, false);
+        case 42: SNERF_CHAIN(4, 2, true);
+        case 40: SNERF_CHAIN(4, 2, false);
         default: return fail(SNERF_E_UNSUPPORTED, "mlp_backward(f16x3): width %d / views width %d not built", plan.width,
                              plan.views_width);
     }

@@ -6,6 +6,8 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kUnitBufFloats = 22 * 512;  // largest unit: 22 k-steps x 2 KiB (views layer of the points-aug MLP)
 constexpr int kUnitBuffers = 3;
@@ -36,7 +38,12 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform in [0,
 // run-ahead leaves the matrix pipe waiting.  A unit of k k-steps is 2k KiB-pieces (hi + lo fragment per k-step), k even,
 // so each of the 4 waves issues exactly k/2 DMA instructions per unit and can wait with a COUNTED vmcnt that leaves the
 // younger unit in flight (a plain __syncthreads() would drain it: its fence waits vmcnt(0) while LDS-DMA is pending).
-struct UnitStream {
+//
+// Unit layout (mlp_pack.hip): [hi fragment of every k-step, 1 KiB each][lo fragment of every k-step].  The single-product
+// kernels (P = 1, SNERF_PRECISION_F16) request only the hi half of each unit -- k KiB-pieces, rounded up to a multiple of
+// four (one DMA instruction per wave; the surplus pieces are the first lo fragments, which nobody reads).
+template <int P>
+struct UnitStreamT {
     const float* fetch_ptr;  // global address of the next unit to request
     const float* stream_base;
     float* lds;
@@ -82,7 +89,7 @@ struct UnitStream {
     __device__ __forceinline__ void begin_fetch(int ksteps, int into_slot) {
         pend_src = fetch_ptr + wave * 256 - 1024;   // fetch_piece pre-increments
         pend_dst = lds + into_slot * kUnitBufFloats + wave * 256 - 1024;
-        pend_left = ksteps >> 1;
+        pend_left = P == 3 ? ksteps >> 1 : (ksteps + 3) >> 2;
         issued = 0;
         fetch_ptr += ksteps * 512;
     }
@@ -122,6 +129,7 @@ struct UnitStream {
         return ready;
     }
 };
+using UnitStream = UnitStreamT<3>;
 
 // Converts accumulator registers (2i, 2i+1) of a finished tile -- ReLU optional -- into the fp16 hi/lo pair they form
 // in the next layer's operand: registers 8s..8s+7 are the 8 elements of k-step s.
@@ -171,19 +179,21 @@ __device__ __forceinline__ void lds_wait_all(f16x8& a, f16x8& b) {
 // the two fragment pairs into one and the wait-count pass puts lgkmcnt(0) right behind each pair of reads, so every
 // k-step paid the full LDS latency (~130 cycles) in front of 96 cycles of MFMAs -- the matrix pipe was 41-42 % busy
 // (PMC) and a third of all wave cycles were parked at s_waitcnt.
-template <int NKS, int NB, typename Side>
-__device__ __forceinline__ void seg_mfma(f32x16& acc, const float*& p, const f16x8 (&bh)[NB], const f16x8 (&bl)[NB],
-                                         const Side& side, int side_first, UnitStream& st) {
+// `unit_ks` = k-steps of the whole unit `p` points into: its lo fragments start unit_ks KiB after its hi fragments.
+template <int NKS, int NB, typename Side, typename Stream>
+__device__ __forceinline__ void seg_mfma(f32x16& acc, const float*& p, int unit_ks, const f16x8 (&bh)[NB],
+                                         const f16x8 (&bl)[NB], const Side& side, int side_first, Stream& st) {
     static_assert(NB >= NKS, "operand array too short");
     const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+    const unsigned base_lo = base + unit_ks * 1024;
     f16x8 ah = lds_read_f16x8(base, 0);
-    f16x8 al = lds_read_f16x8(base, 1024);
+    f16x8 al = lds_read_f16x8(base_lo, 0);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         f16x8 nah = ah, nal = al;
         if (ks + 1 < NKS) {
-            nah = lds_read_f16x8(base, (ks + 1) * 2048);
-            nal = lds_read_f16x8(base, (ks + 1) * 2048 + 1024);
+            nah = lds_read_f16x8(base, (ks + 1) * 1024);
+            nal = lds_read_f16x8(base_lo, (ks + 1) * 1024);
             lds_wait_all_but_two(ah, al);
         } else {
             lds_wait_all(ah, al);
@@ -195,12 +205,57 @@ __device__ __forceinline__ void seg_mfma(f32x16& acc, const float*& p, const f16
         if ((ks & 1) == 0) st.fetch_piece();
         ah = nah; al = nal;
     }
-    p += NKS * 512;
+    p += NKS * 256;
+}
+
+// Single-product variant (SNERF_PRECISION_F16): one fp16 MFMA per k-step (32 cycles), so a fragment has to be requested
+// FOUR k-steps before its use to cover the LDS latency from one wave per SIMD; counted waits as above.
+template <int N>
+__device__ __forceinline__ void lds_wait_all_but(f16x8& a) {
+    static_assert(N >= 0 && N <= 4, "wait count");
+    if (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory");
+    if (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a)::"memory");
+    if (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a)::"memory");
+    if (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a)::"memory");
+    if (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a)::"memory");
+}
+template <int NKS, int NB, typename Stream>
+__device__ __forceinline__ void seg_mfma1(f32x16& acc, const float*& p, const f16x8 (&bh)[NB], Stream& st) {
+    static_assert(NB >= NKS, "operand array too short");
+    constexpr int AHEAD = 4;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+    f16x8 a[AHEAD + 1];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (i < NKS) a[i] = lds_read_f16x8(base, i * 1024);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + AHEAD < NKS) a[(ks + AHEAD) % (AHEAD + 1)] = lds_read_f16x8(base, (ks + AHEAD) * 1024);
+        constexpr int kLast = NKS - 1;
+        const int newer = kLast - ks < AHEAD ? kLast - ks : AHEAD;   // reads issued after the one for k-step ks
+        f16x8& cur = a[ks % (AHEAD + 1)];
+        if (newer == 4) lds_wait_all_but<4>(cur);
+        else if (newer == 3) lds_wait_all_but<3>(cur);
+        else if (newer == 2) lds_wait_all_but<2>(cur);
+        else if (newer == 1) lds_wait_all_but<1>(cur);
+        else lds_wait_all_but<0>(cur);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bh[ks], acc, 0, 0, 0);
+        if ((ks & 3) == 0) st.fetch_piece();
+    }
+    p += NKS * 256;
 }
 
 struct NoSide {
     __device__ __forceinline__ void step(int) const {}
 };
+
+// P = 3: split-precision product (hi.hi + hi.lo + lo.hi); P = 1: hi.hi only.
+template <int P, int NKS, int NB, typename Stream>
+__device__ __forceinline__ void seg_product(f32x16& acc, const float*& p, int unit_ks, const f16x8 (&bh)[NB],
+                                            const f16x8 (&bl)[NB], Stream& st) {
+    if constexpr (P == 3) seg_mfma<NKS>(acc, p, unit_ks, bh, bl, NoSide(), 8, st);
+    else seg_mfma1<NKS>(acc, p, bh, st);
+}
 
 __device__ __forceinline__ void tile_bias(f32x16& acc, const float* __restrict__ bias, int half) {
 #pragma unroll
@@ -297,6 +352,18 @@ __device__ __forceinline__ void mask_with_words(f32x16* acc, const unsigned (&wo
     for (int u = 0; u < U; u += 2)
 #pragma unroll
         for (int r = 0; r < 32; ++r) acc[u + (r >> 4)][r & 15] = (words[u >> 1] >> r) & 1u ? acc[u + (r >> 4)][r & 15] : 0.0f;
+}
+
+// 16-bit saved tiles (SNERF_PRECISION_F16): NKS consecutive operand fragments -> NKS "pieces" of 1 KiB.  A piece is the
+// fragment image of one 16-feature k-step, [slot = 2 * sample + lane half][8 x 16 bit], i.e. for sample j the features
+// 16s + {0..3 | 4..7 | 8..11 | 12..15} in natural order within its 32 bytes -- sample-major rows that the weight-gradient
+// kernel reads back TRANSPOSED (ds_read_b64_tr_b16).  Every store instruction writes 1 KiB contiguous.
+template <int NKS, int NB>
+__device__ __forceinline__ void store_pieces(const f16x8 (&frag)[NB], _Float16* __restrict__ rows, int lane) {
+    static_assert(NB >= NKS, "fragment array too short");
+    const int slot = 2 * (lane & 31) + (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) *reinterpret_cast<f16x8*>(rows + s * 512 + slot * 8) = frag[s];
 }
 
 // One finished accumulator tile -> rows 32u .. 32u+31 of a [feature][32-sample] fp32 tile (training: saved activations).

@@ -25,7 +25,7 @@
 #include "mlp_device.h"
 
 namespace snerf {
-int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, hipStream_t stream);  // mlp_forward_f16.hip
+int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, int products, hipStream_t stream);  // mlp_forward_f16.hip
 }
 
 namespace {
@@ -179,7 +179,7 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     SNERF_REQUIRE(!plan.view_dependent || view_dirs, "mlp_forward: this MLP needs view_dirs");
     SNERF_REQUIRE(num_rays >= 0 && num_samples >= 1, "mlp_forward: bad sizes n=%lld S=%d", num_rays, num_samples);
     SNERF_REQUIRE(!train || saved_acts, "mlp_forward_train: saved_acts is NULL");
-    if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3)
+    if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3 && precision != SNERF_PRECISION_F16)
         return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: precision %d not built", precision);
     if (num_rays == 0) return SNERF_OK;
     MlpArgs a;
@@ -193,7 +193,11 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     a.acts = saved_acts; a.act_rows = plan.act_rows(); a.act_pev = plan.act_pev(); a.act_h1 = plan.act_h(1);
     a.act_feature = plan.act_feature(); a.act_hv = plan.act_hv(); a.act_mask = plan.act_mask();
     hipStream_t s = (hipStream_t)stream;
-    if (precision == SNERF_PRECISION_F16X3) return snerf::mlp_forward_f16x3(plan, a, train, s);
+    if (precision == SNERF_PRECISION_F16X3) return snerf::mlp_forward_f16x3(plan, a, train, 3, s);
+    if (precision == SNERF_PRECISION_F16) {
+        a.act_rows = plan.act16_rows();  // 16-bit pieces: same row numbers, rows of 64 bytes (mlp_plan.h)
+        return snerf::mlp_forward_f16x3(plan, a, train, 1, s);
+    }
     const int key = plan.wt * 100 + plan.vt * 10 + (plan.sigma_pe ? 1 : 0);
 #define SNERF_DISPATCH(WT_, VT_, VD_, SP_) return train ? launch<WT_, VT_, VD_, SP_, true>(a, s) : launch<WT_, VT_, VD_, SP_, false>(a, s)
     switch (key) {

@@ -26,7 +26,9 @@ struct HalfArgs {
     int const_floats;  // biases + head weights: packed[bias_offset, bias_offset + const_floats), kept in LDS
 };
 
-template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE>
+// P = 3: split precision (SNERF_PRECISION_F16X3).  P = 1: single fp16 product (SNERF_PRECISION_F16); its training variant
+// saves the activations as 16-bit operand fragments (store_piece) instead of fp32 rows.
+template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P>
 __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const MlpArgs& a = args.m;
@@ -47,7 +49,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
         const int v = idx - trunk_units;
         return v < WT ? HK : (v < WT + VT ? kViewsKs : 0);
     };
-    UnitStream st;
+    UnitStreamT<P> st;
     st.start(a.packed + args.half_offset, lds, ks_of(0), ks_of(1), lane, wave);
     int unit_idx = 0;
     auto next_unit = [&]() {
@@ -71,26 +73,34 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
 #pragma unroll
     for (int k = 0; k < 3; ++k) x[k] = a.origins[ray * 3 + k] + a.dirs[ray * 3 + k] * z;
 
+    constexpr bool STORE32 = STORE && P == 3, STORE16 = STORE && P == 1;
     float* tile = nullptr;  // training: this wave block's saved-activation tiles (fp32, same layout as the fp32 path)
+    _Float16* tile16 = nullptr;  // ... or 16-bit fragment pieces, rows of 32 x 16 bit (a.act_rows counts those)
     unsigned* masks = nullptr;
-    if (STORE) {
+    if (STORE32) {
         tile = a.acts + ((long long)blockIdx.x * 4 + wave) * a.act_rows * 32;
         masks = reinterpret_cast<unsigned*>(tile + a.act_mask * 32);
+    }
+    if (STORE16) {
+        tile16 = reinterpret_cast<_Float16*>(a.acts) + ((long long)blockIdx.x * 4 + wave) * a.act_rows * 32;
+        masks = reinterpret_cast<unsigned*>(tile16 + a.act_mask * 32);
     }
     f16x8 pe_h[4], pe_l[4], pev_h[2], pev_l[2];
     {
         float pe[snerf::kPointsKSteps];
         encode<snerf::kPointsPairs, snerf::kPointsKSteps>(x, half, pe);
-        if (STORE) store_pe_tile<snerf::kPointsPairs, snerf::kPointsKSteps>(pe, tile, lane);
+        if (STORE32) store_pe_tile<snerf::kPointsPairs, snerf::kPointsKSteps>(pe, tile, lane);
         split_encoding<32, 4>(pe, pe_h, pe_l);
+        if (STORE16) store_pieces<4>(pe_h, tile16, lane);
     }
     if (VIEWDEP) {
         float v[3], pev[snerf::kViewsKSteps];
 #pragma unroll
         for (int k = 0; k < 3; ++k) v[k] = a.view_dirs[ray * 3 + k];
         encode<snerf::kViewsPairs, snerf::kViewsKSteps>(v, half, pev);
-        if (STORE) store_pe_tile<snerf::kViewsPairs, snerf::kViewsKSteps>(pev, tile + a.act_pev * 32, lane);
+        if (STORE32) store_pe_tile<snerf::kViewsPairs, snerf::kViewsKSteps>(pev, tile + a.act_pev * 32, lane);
         split_encoding<16, 2>(pev, pev_h, pev_l);
+        if (STORE16) store_pieces<2>(pev_h, tile16 + a.act_pev * 32, lane);
     }
 
     const float* bias = consts;
@@ -106,7 +116,6 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
     // with the next tile's MFMAs through a second operand buffer; the extra 128 registers pushed the B operands into
     // AGPRs and every MFMA then paid v_accvgpr_read moves -- slower overall.)
     f32x16 acc[WT];
-    const NoSide none;
     auto heads_from = [&](const f32x16& t, int u) {
         head[0] += tile_dot_relu(t, wout + 32 * u, half);
         if (!VIEWDEP) {
@@ -120,13 +129,14 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
     for (int u = 0; u < WT; ++u) {
         const float* unit = next_unit();
         tile_bias(acc[u], bias + 32 * u, half);
-        seg_mfma<4>(acc[u], unit, pe_h, pe_l, none, 8, st);
+        seg_product<P, 4>(acc[u], unit, 4, pe_h, pe_l, st);
         if (single) heads_from(acc[u], u);
-        if (STORE) { store_tile_rows<true>(acc[u], tile + (a.act_h1 + 32 * u) * 32, lane); st.note_vmem(16); }
+        if (STORE32) { store_tile_rows<true>(acc[u], tile + (a.act_h1 + 32 * u) * 32, lane); st.note_vmem(16); }
     }
     if (STORE) store_relu_masks<WT>(acc, masks, 0, lane);
 #pragma unroll
     for (int u = 0; u < WT; ++u) split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
+    if (STORE16) { store_pieces<HK>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK); }
 
     // ---- trunk layers 1 .. depth-1 --------------------------------------------------------------------------------
 #pragma unroll 1
@@ -137,14 +147,16 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
         for (int u = 0; u < WT; ++u) {
             const float* unit = next_unit();
             tile_bias(acc[u], bl + 32 * u, half);
-            if (l == 5) seg_mfma<4>(acc[u], unit, pe_h, pe_l, none, 8, st);  // skip connection [encoding | h]
-            seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
+            const int unit_ks = l == 5 ? 4 + HK : HK;
+            if (l == 5) seg_product<P, 4>(acc[u], unit, unit_ks, pe_h, pe_l, st);  // skip connection [encoding | h]
+            seg_product<P, HK>(acc[u], unit, unit_ks, xh, xl, st);
             if (last) heads_from(acc[u], u);
-            if (STORE) { store_tile_rows<true>(acc[u], tile + (a.act_h1 + l * a.width + 32 * u) * 32, lane); st.note_vmem(16); }
+            if (STORE32) { store_tile_rows<true>(acc[u], tile + (a.act_h1 + l * a.width + 32 * u) * 32, lane); st.note_vmem(16); }
         }
         if (STORE) store_relu_masks<WT>(acc, masks, l * WT, lane);
 #pragma unroll
         for (int u = 0; u < WT; ++u) split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
+        if (STORE16) { store_pieces<HK>(xh, tile16 + (a.act_h1 + l * a.width) * 32, lane); st.note_vmem(HK); }
     }
 
     float sigma = (head[0] + __shfl_xor(head[0], 32, 64)) + bout[0];
@@ -161,11 +173,12 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
         for (int u = 0; u < WT; ++u) {
             const float* unit = next_unit();
             tile_bias(acc[u], bf + 32 * u, half);
-            seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
-            if (STORE) { store_tile_rows<false>(acc[u], tile + (a.act_feature + 32 * u) * 32, lane); st.note_vmem(16); }
+            seg_product<P, HK>(acc[u], unit, HK, xh, xl, st);
+            if (STORE32) { store_tile_rows<false>(acc[u], tile + (a.act_feature + 32 * u) * 32, lane); st.note_vmem(16); }
         }
 #pragma unroll
         for (int u = 0; u < WT; ++u) split_tile<false>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
+        if (STORE16) { store_pieces<HK>(xh, tile16 + a.act_feature * 32, lane); st.note_vmem(HK); }
         // views layer over [feature | rest of the point encoding (points-aug) | view encoding], then the colour head
         const float* bv = consts + (a.views_bias - a.bias_offset);
         const float* wv = consts + (a.views_out_w - a.bias_offset);
@@ -175,10 +188,16 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
         for (int u = 0; u < VT; ++u) {
             const float* unit = next_unit();
             tile_bias(acc[u], bv + 32 * u, half);
-            seg_mfma<HK>(acc[u], unit, xh, xl, none, 8, st);
-            if (SIGMA_PE) seg_mfma<4>(acc[u], unit, pe_h, pe_l, none, 8, st);
-            seg_mfma<2>(acc[u], unit, pev_h, pev_l, none, 8, st);
-            if (STORE) { store_tile_rows<true>(acc[u], tile + (a.act_hv + 32 * u) * 32, lane); st.note_vmem(16); }
+            seg_product<P, HK>(acc[u], unit, kViewsKs, xh, xl, st);
+            if (SIGMA_PE) seg_product<P, 4>(acc[u], unit, kViewsKs, pe_h, pe_l, st);
+            seg_product<P, 2>(acc[u], unit, kViewsKs, pev_h, pev_l, st);
+            if (STORE32) { store_tile_rows<true>(acc[u], tile + (a.act_hv + 32 * u) * 32, lane); st.note_vmem(16); }
+            if (STORE16) {
+                f16x8 vh[2], vl[2];
+                split_tile<true>(acc[u], vh[0], vl[0], vh[1], vl[1]);
+                store_pieces<2>(vh, tile16 + (a.act_hv + 32 * u) * 32, lane);
+                st.note_vmem(2);
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) col[c] += tile_dot_relu(acc[u], wv + c * VT * 32 + 32 * u, half);
         }
@@ -195,12 +214,12 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
     }
 }
 
-template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE>
+template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P>
 int launch_half(const HalfArgs& args, hipStream_t stream) {
     const long long blocks = (args.m.total + 127) / 128;
     if (blocks > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: too many samples in one call");
     const size_t lds_bytes = sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024 + (size_t)args.const_floats);
-    auto kernel = mlp_forward_f16x3_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE>;
+    auto kernel = mlp_forward_f16x3_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE, P>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -212,12 +231,20 @@ int launch_half(const HalfArgs& args, hipStream_t stream) {
     return snerf::check_launch("mlp_forward(f16x3)");
 }
 
+template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE>
+int launch_variant(const HalfArgs& args, bool train, int products, hipStream_t stream) {
+    if (products == 3)
+        return train ? launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, 3>(args, stream) : launch_half<WT, VT, VIEWDEP, SIGMA_PE, false, 3>(args, stream);
+    return train ? launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, 1>(args, stream) : launch_half<WT, VT, VIEWDEP, SIGMA_PE, false, 1>(args, stream);
+}
+
 }  // namespace
 
 namespace snerf {
 
-// Called by snerf_mlp_forward for SNERF_PRECISION_F16X3 (argument checks already done there).
-int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, hipStream_t stream) {
+// Called by snerf_mlp_forward for SNERF_PRECISION_F16X3 (products = 3) and SNERF_PRECISION_F16 (products = 1); argument
+// checks already done there.  For products = 1 in training mode m.act_* describe the 16-bit tile layout.
+int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, int products, hipStream_t stream) {
     HalfArgs args;
     args.m = m;
     args.half_offset = plan.half_offset;
@@ -228,12 +255,12 @@ int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, hipStre
             return fail(SNERF_E_UNSUPPORTED, "mlp_forward(f16x3): staging unit of %d KiB exceeds the LDS buffer", st.unit_floats / 256);
     const int key = plan.wt * 100 + plan.vt * 10 + (plan.sigma_pe ? 1 : 0);
     switch (key) {
-        case 840: return train ? launch_half<8, 4, true, false, true>(args, stream) : launch_half<8, 4, true, false, false>(args, stream);
-        case 841: return train ? launch_half<8, 4, true, true, true>(args, stream) : launch_half<8, 4, true, true, false>(args, stream);
-        case 800: return train ? launch_half<8, 4, false, false, true>(args, stream) : launch_half<8, 4, false, false, false>(args, stream);
-        case 420: return train ? launch_half<4, 2, true, false, true>(args, stream) : launch_half<4, 2, true, false, false>(args, stream);
-        case 421: return train ? launch_half<4, 2, true, true, true>(args, stream) : launch_half<4, 2, true, true, false>(args, stream);
-        case 400: return train ? launch_half<4, 2, false, false, true>(args, stream) : launch_half<4, 2, false, false, false>(args, stream);
+        case 840: return launch_variant<8, 4, true, false>(args, train, products, stream);
+        case 841: return launch_variant<8, 4, true, true>(args, train, products, stream);
+        case 800: return launch_variant<8, 4, false, false>(args, train, products, stream);
+        case 420: return launch_variant<4, 2, true, false>(args, train, products, stream);
+        case 421: return launch_variant<4, 2, true, true>(args, train, products, stream);
+        case 400: return launch_variant<4, 2, false, false>(args, train, products, stream);
         default:
             return fail(SNERF_E_UNSUPPORTED, "mlp_forward(f16x3): width %d / views width %d combination not built", plan.width,
                         plan.views_width);

@@ -58,16 +58,16 @@ __global__ void __launch_bounds__(256) pack_segment_kernel(SegmentTable table, f
     }
 }
 
-// f16x3 stream: for every (stage, out tile u, k-step): a hi fragment [64 lanes][8 fp16] then a lo fragment, where
+// f16x3 stream: for every (stage, out tile u): the hi fragments [64 lanes][8 fp16] of all k-steps, then the lo fragments, where
 // hi = fp16(w), lo = fp16(w - hi) (lo may be subnormal: the MFMA honours fp16 subnormals, measured).  Element j of lane
 // (i, h) multiplies input feature  16*ks + 8*(j>>2) + 4*h + (j&3)  of an accumulator-sourced segment (the order in which
 // a 32x32 accumulator tile turns into the next B operand), or encoding register n = 8*ks + j of the lane half.
-__device__ __forceinline__ _Float16* out_ptr(float* packed, const snerf::MlpPlan::HalfStage& st) {
-    return reinterpret_cast<_Float16*>(packed + st.dst);
-}
-__device__ __forceinline__ void out_store(_Float16* out, long long base, int lane, int j, _Float16 hi, _Float16 lo) {
-    out[base + lane * 8 + j] = hi;
-    out[base + 512 + lane * 8 + j] = lo;
+// unit layout (fp16 elements): [ks][hi: 64 lanes x 8] for every k-step of the unit, then [ks][lo: 64 lanes x 8]
+__device__ __forceinline__ void out_store(_Float16* out, long long unit, int unit_ks, int ks, int lane, int j, _Float16 hi,
+                                          _Float16 lo) {
+    const long long base = unit * unit_ks * 1024 + ks * 512 + lane * 8 + j;
+    out[base] = hi;
+    out[base + unit_ks * 512] = lo;
 }
 
 __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, float* __restrict__ packed) {
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
     const int unit_ks = st.unit_floats / 512;
     const long long total = (long long)st.tiles * unit_ks * 512;  // one thread per (u, ks, lane, j): 512 elements per k-step
     const long long stride = (long long)gridDim.x * blockDim.x;
-    _Float16* out = reinterpret_cast<_Float16*>(packed + st.dst);
+    _Float16* dst16 = reinterpret_cast<_Float16*>(packed + st.dst);
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
         const int j = (int)(idx & 7);
         const int lane = (int)((idx >> 3) & 63);
@@ -98,8 +98,7 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
             float tv = 0.0f;
             if (out < sg.out_dim && row < sg.feat_hi) tv = w[(long long)out * sg.ld + sg.col_offset + row];
             const _Float16 thi = (_Float16)tv;
-            const long long tbase = ((long long)u * unit_ks + ks_unit) * 1024;
-            out_store(out_ptr(packed, st), tbase, lane, j, thi, (_Float16)(tv - (float)thi));
+            out_store(dst16, u, unit_ks, ks_unit, lane, j, thi, (_Float16)(tv - (float)thi));
             continue;
         }
         if (sg.kind == snerf::SEG_ACC) {
@@ -115,9 +114,7 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
         if (row < sg.out_dim && col >= 0 && col < sg.ld) v = w[(long long)row * sg.ld + col];
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
-        // unit layout: [ks][hi: 64 lanes x 8][lo: 64 lanes x 8]  (fp16)
-        const long long base = ((long long)u * unit_ks + ks_unit) * 1024;
-        out_store(out, base, lane, j, hi, lo);
+        out_store(dst16, u, unit_ks, ks_unit, lane, j, hi, lo);
     }
 }
 

@@ -61,6 +61,11 @@ struct MlpPlan {
     int mask_tiles() const { return depth * (width / 32) + (view_dependent ? views_width / 32 : 0); }
     int act_mask() const { return 96 + (depth + 1) * width + (view_dependent ? views_width : 0); }
     int act_rows() const { return act_mask() + 2 * ((mask_tiles() + 1) / 2); }
+    // SNERF_PRECISION_F16 keeps the same tensors as 16-bit operand fragments ("pieces", mlp_device_f16.h store_pieces):
+    // the row numbers above then count rows of 32 x 16 bit (64 bytes), a 32-feature tile = two 1 KiB pieces = its 32
+    // rows, and a pair of mask words takes four such rows.  Block strides of the two 16-bit buffers, in those rows:
+    int act16_rows() const { return act_mask() + 4 * ((mask_tiles() + 1) / 2); }
+    int grad16_rows() const { return grad_rows(); }
     int grad_y(int l) const { return l * width; }             // l = 0 .. depth-1
     int grad_feature() const { return depth * width; }
     int grad_yv() const { return (depth + 1) * width; }

@@ -13,8 +13,9 @@ from ._lib import MlpDesc
 
 Tensor = torch.Tensor
 PRECISION_FP32 = 0   # fp32 MFMA
-PRECISION_F16X3 = 1  # fp16 hi/lo split, 3 MFMAs per product, fp32 accumulate (forward only)
-PRECISIONS = {'fp32': PRECISION_FP32, 'f16x3': PRECISION_F16X3}
+PRECISION_F16X3 = 1  # fp16 hi/lo split, 3 MFMAs per product, fp32 accumulate: fp32-grade results
+PRECISION_F16 = 2    # 16-bit mode: one fp16 MFMA per product, fp32 accumulate / master weights; 16-bit saved tensors
+PRECISIONS = {'fp32': PRECISION_FP32, 'f16x3': PRECISION_F16X3, 'f16': PRECISION_F16}
 
 
 def _stream() -> ctypes.c_void_p:
