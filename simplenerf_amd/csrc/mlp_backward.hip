@@ -684,7 +684,7 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
                 wave_tile(k, &ko, &ki);
                 peers += (ko == no && ki == ni && k.out_tiles * k.in_tiles >= 32);
             }
-            chunks = (256 + peers - 1) / peers;
+            chunks = 256 / peers;   // rounded DOWN: 7 jobs x 37 chunks = 259 workgroups ran as 256 + a second round of 3
             cap = blocks / 8;
         } else {
             chunks = 512;

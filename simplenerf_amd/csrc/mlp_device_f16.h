@@ -49,6 +49,7 @@ struct UnitStreamT {
     float* lds;
     int slot;                // ring slot of the unit about to be consumed
     int lane, wave;
+    int slot_floats;         // size of one ring slot (kUnitBufFloats, or less when the caller sized the ring to its units)
 
     const float* pend_src;   // unit being requested piecewise (one DMA instruction per call of fetch_piece)
     float* pend_dst;
@@ -82,13 +83,13 @@ struct UnitStreamT {
     // the stream into a per-wave dump area instead of touching a live buffer.
     __device__ __forceinline__ void issued_next_none() {
         pend_src = stream_base;
-        pend_dst = lds + kUnitBuffers * kUnitBufFloats + wave * 256;  // dump: 4 KiB right after the ring
+        pend_dst = lds + kUnitBuffers * slot_floats + wave * 256;  // dump: 4 KiB right after the ring
         pend_left = 0;
         issued = 0;
     }
     __device__ __forceinline__ void begin_fetch(int ksteps, int into_slot) {
         pend_src = fetch_ptr + wave * 256 - 1024;   // fetch_piece pre-increments
-        pend_dst = lds + into_slot * kUnitBufFloats + wave * 256 - 1024;
+        pend_dst = lds + into_slot * slot_floats + wave * 256 - 1024;
         pend_left = P == 3 ? ksteps >> 1 : (ksteps + 3) >> 2;
         issued = 0;
         fetch_ptr += ksteps * 512;
@@ -97,9 +98,10 @@ struct UnitStreamT {
         begin_fetch(ksteps, into_slot);
         finish_fetch();
     }
-    __device__ __forceinline__ void start(const float* first, float* lds_base, int ks0, int ks1, int lane_, int wave_) {
+    __device__ __forceinline__ void start(const float* first, float* lds_base, int ks0, int ks1, int lane_, int wave_,
+                                          int slot_floats_ = kUnitBufFloats) {
         fetch_ptr = first; stream_base = first; lds = lds_base; slot = 0; lane = lane_; wave = wave_; pend_left = 0; issued = 0;
-        younger = 0;
+        younger = 0; slot_floats = slot_floats_;
         fetch(ks0, 0);
         if (ks1 > 0) fetch(ks1, 1);
         if (ks1 <= 0) issued_next_none();
@@ -122,7 +124,7 @@ struct UnitStreamT {
 #ifndef SNERF_ABL_NOBARRIER
         __builtin_amdgcn_s_barrier();
 #endif
-        const float* ready = lds + slot * kUnitBufFloats;
+        const float* ready = lds + slot * slot_floats;
         const int vacated = slot == 0 ? kUnitBuffers - 1 : slot - 1;
         if (next2 > 0) begin_fetch(next2, vacated); else issued_next_none();
         slot = slot == kUnitBuffers - 1 ? 0 : slot + 1;
@@ -327,6 +329,20 @@ __device__ __forceinline__ void store_relu_masks(const f32x16* acc, unsigned* __
 #pragma unroll
         for (int r = 0; r < 32; ++r) word |= (acc[u + (r >> 4)][r & 15] > 0.0f ? 1u : 0u) << r;
         masks[((t0 + u) >> 1) * 64 + lane] = word;
+    }
+}
+// One tile at a time (the single-product forward calls this right behind each tile's MFMAs, so the compares run in the
+// shadow of the next tile's matrix work and no second pass over all accumulators is needed): the tile's 16 sign bits,
+// shifted to the half of its pair's word.  `bits` collects a pair; the word is stored when its second tile arrives.
+__device__ __forceinline__ void relu_mask_tile(const f32x16& acc, int u, unsigned& bits, unsigned* __restrict__ masks, int t0,
+                                               int lane) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= (acc[r] > 0.0f ? 1u : 0u) << r;
+    if ((u & 1) == 0) {
+        bits = m;
+    } else {
+        masks[((t0 + u) >> 1) * 64 + lane] = bits | (m << 16);
     }
 }
 template <int U>

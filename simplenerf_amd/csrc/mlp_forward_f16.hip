@@ -16,6 +16,8 @@
 //
 // Bound: MFMA fp16 (dense peak 2.5 PFLOP/s; 3 MFMA passes per algorithmic product -> 833 TFLOP/s algorithmic ceiling),
 // with the weight stream L2 -> LDS (2.3 MB per 128 samples) as the secondary limit.
+#include <algorithm>
+
 #include "mlp_device_f16.h"
 
 namespace {
@@ -24,12 +26,18 @@ struct HalfArgs {
     MlpArgs m;
     long long half_offset;
     int const_floats;  // biases + head weights: packed[bias_offset, bias_offset + const_floats), kept in LDS
+    int slot_floats;   // LDS ring slot size
 };
 
 // P = 3: split precision (SNERF_PRECISION_F16X3).  P = 1: single fp16 product (SNERF_PRECISION_F16); its training variant
 // saves the activations as 16-bit operand fragments (store_piece) instead of fp32 rows.
+// The single-product kernels size the ring to their (hi-only) units so that two workgroups fit a CU: at one wave per SIMD
+// every LDS latency, barrier and operand conversion sits in front of the 32-cycle MFMAs; a second wave fills those gaps
+// (inference: 1.47 -> 1.89 M rays/s on the headline step).  The training variant needs ~120 more registers for the
+// mask words and fragment stores and would spill at the 256-register budget of that occupancy (measured: slower), so
+// it keeps one workgroup per CU.
 template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P>
-__global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args) {
+__global__ void __launch_bounds__(256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(HalfArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const MlpArgs& a = args.m;
     const int lane = threadIdx.x & 63;
@@ -50,7 +58,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
         return v < WT ? HK : (v < WT + VT ? kViewsKs : 0);
     };
     UnitStreamT<P> st;
-    st.start(a.packed + args.half_offset, lds, ks_of(0), ks_of(1), lane, wave);
+    st.start(a.packed + args.half_offset, lds, ks_of(0), ks_of(1), lane, wave, args.slot_floats);
     int unit_idx = 0;
     auto next_unit = [&]() {
         const float* p = st.acquire(ks_of(unit_idx + 1), ks_of(unit_idx + 2));
@@ -59,7 +67,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
     };
     // Biases and head weights live in LDS for the whole kernel: an ordinary global load inside the tile loop would make
     // the compiler wait vmcnt(0), i.e. drain the weight prefetch (LDS-DMA) that is deliberately left in flight.
-    float* consts = lds + kUnitBuffers * kUnitBufFloats + 1024;  // after the ring and the 4-KiB DMA dump area
+    float* consts = lds + kUnitBuffers * args.slot_floats + 1024;  // after the ring and the 4-KiB DMA dump area
     for (int i = threadIdx.x * 4; i < args.const_floats; i += 256 * 4)
         *reinterpret_cast<f32x4*>(consts + i) = *reinterpret_cast<const f32x4*>(a.packed + a.bias_offset + i);
     __syncthreads();
@@ -116,6 +124,7 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
     // with the next tile's MFMAs through a second operand buffer; the extra 128 registers pushed the B operands into
     // AGPRs and every MFMA then paid v_accvgpr_read moves -- slower overall.)
     f32x16 acc[WT];
+    unsigned mask_bits = 0;
     auto heads_from = [&](const f32x16& t, int u) {
         head[0] += tile_dot_relu(t, wout + 32 * u, half);
         if (!VIEWDEP) {
@@ -132,8 +141,9 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
         seg_product<P, 4>(acc[u], unit, 4, pe_h, pe_l, st);
         if (single) heads_from(acc[u], u);
         if (STORE32) { store_tile_rows<true>(acc[u], tile + (a.act_h1 + 32 * u) * 32, lane); st.note_vmem(16); }
+        if (STORE16) { relu_mask_tile(acc[u], u, mask_bits, masks, 0, lane); st.note_vmem(u & 1); }
     }
-    if (STORE) store_relu_masks<WT>(acc, masks, 0, lane);
+    if (STORE32) store_relu_masks<WT>(acc, masks, 0, lane);
 #pragma unroll
     for (int u = 0; u < WT; ++u) split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
     if (STORE16) { store_pieces<HK>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK); }
@@ -152,8 +162,9 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
             seg_product<P, HK>(acc[u], unit, unit_ks, xh, xl, st);
             if (last) heads_from(acc[u], u);
             if (STORE32) { store_tile_rows<true>(acc[u], tile + (a.act_h1 + l * a.width + 32 * u) * 32, lane); st.note_vmem(16); }
+            if (STORE16) { relu_mask_tile(acc[u], u, mask_bits, masks, l * WT, lane); st.note_vmem(u & 1); }
         }
-        if (STORE) store_relu_masks<WT>(acc, masks, l * WT, lane);
+        if (STORE32) store_relu_masks<WT>(acc, masks, l * WT, lane);
 #pragma unroll
         for (int u = 0; u < WT; ++u) split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
         if (STORE16) { store_pieces<HK>(xh, tile16 + (a.act_h1 + l * a.width) * 32, lane); st.note_vmem(HK); }
@@ -196,12 +207,13 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_f16x3_kernel(HalfArgs args
                 f16x8 vh[2], vl[2];
                 split_tile<true>(acc[u], vh[0], vl[0], vh[1], vl[1]);
                 store_pieces<2>(vh, tile16 + (a.act_hv + 32 * u) * 32, lane);
-                st.note_vmem(2);
+                relu_mask_tile(acc[u], u, mask_bits, masks, a.depth * WT, lane);
+                st.note_vmem(2 + (u & 1));
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) col[c] += tile_dot_relu(acc[u], wv + c * VT * 32 + 32 * u, half);
         }
-        if (STORE) store_relu_masks<VT>(acc, masks, a.depth * WT, lane);
+        if (STORE32) store_relu_masks<VT>(acc, masks, a.depth * WT, lane);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoidf((col[c] + __shfl_xor(col[c], 32, 64)) + bo[c]);
     }
@@ -218,7 +230,7 @@ template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P>
 int launch_half(const HalfArgs& args, hipStream_t stream) {
     const long long blocks = (args.m.total + 127) / 128;
     if (blocks > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: too many samples in one call");
-    const size_t lds_bytes = sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024 + (size_t)args.const_floats);
+    const size_t lds_bytes = sizeof(float) * (kUnitBuffers * (size_t)args.slot_floats + 1024 + (size_t)args.const_floats);
     auto kernel = mlp_forward_f16x3_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE, P>;
     static bool configured = false;
     if (!configured) {
@@ -250,9 +262,14 @@ int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, int pro
     args.half_offset = plan.half_offset;
     args.const_floats = (int)((plan.dgrad_offset - plan.bias_offset + 3) / 4 * 4);  // biases + heads (+ alignment padding)
     if (args.const_floats > 5120) return fail(SNERF_E_UNSUPPORTED, "mlp_forward(f16x3): bias/head block of %d floats exceeds its LDS area", args.const_floats);
-    for (const MlpPlan::HalfStage& st : plan.half_stages)
+    int most_ks = 0;
+    for (const MlpPlan::HalfStage& st : plan.half_stages) {
         if (st.unit_floats > kUnitBufFloats)
             return fail(SNERF_E_UNSUPPORTED, "mlp_forward(f16x3): staging unit of %d KiB exceeds the LDS buffer", st.unit_floats / 256);
+        most_ks = std::max(most_ks, st.unit_floats / 512);
+    }
+    // products = 1 requests the hi half of each unit only: k KiB-pieces rounded up to four (one per wave)
+    args.slot_floats = products == 3 ? kUnitBufFloats : (most_ks + 3) / 4 * 4 * 256;
     const int key = plan.wt * 100 + plan.vt * 10 + (plan.sigma_pe ? 1 : 0);
     switch (key) {
         case 840: return launch_variant<8, 4, true, false>(args, train, products, stream);
