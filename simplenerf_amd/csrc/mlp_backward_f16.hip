@@ -5,6 +5,8 @@
 // Same arithmetic as mlp_forward_f16.hip: each operand is an fp16 hi/lo pair and each product is three MFMAs
 // (hi.hi + hi.lo + lo.hi) into an fp32 accumulator; W^T is pre-split at pack time (MlpPlan::half_dgrad_stages) and
 // streamed through the 3-slot LDS ring, one 32-row IN-feature tile (all of its k-steps over the OUT features) per unit.
+#include <algorithm>
+
 #include "mlp_device_f16.h"
 
 namespace {
@@ -12,6 +14,7 @@ namespace {
 struct HalfChainArgs {
     ChainArgs c;
     long long half_dgrad_offset;
+    int slot_floats;   // LDS ring slot size
 };
 
 template <int U>
@@ -94,6 +97,8 @@ template <int P>
 constexpr int dy_stores(int tiles) { return P == 3 ? 16 * tiles : 2 * tiles; }
 
 template <int WT, int VT, bool VIEWDEP, int P>
+// (one workgroup per CU also for P = 1: at the 256-register budget of two the kernel spills ~120 registers and the
+// training iteration measured 11.1 -> 14.4 ms)
 __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfChainArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ChainArgs& a = args.c;
@@ -112,7 +117,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
         return HK;
     };
     UnitStreamT<P> st;
-    st.start(a.packed + args.half_dgrad_offset, lds, ks_of(0), ks_of(1), lane, wave);
+    st.start(a.packed + args.half_dgrad_offset, lds, ks_of(0), ks_of(1), lane, wave, args.slot_floats);
     int unit_idx = 0;
     auto next_unit = [&]() {
         const float* p = st.acquire(ks_of(unit_idx + 1), ks_of(unit_idx + 2));
@@ -263,12 +268,12 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
 template <int WT, int VT, bool VIEWDEP, int P>
 int launch_chain_half(const HalfChainArgs& args, hipStream_t stream) {
     const long long blocks = (args.c.total + 127) / 128;
-    const size_t lds_bytes = sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024);  // ring + DMA dump area
+    const size_t lds_bytes = sizeof(float) * (kUnitBuffers * (size_t)args.slot_floats + 1024);  // ring + DMA dump area
     auto kernel = mlp_backward_chain_f16x3_kernel<WT, VT, VIEWDEP, P>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes);
+                                           (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024)));
         if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured = true;
     }
@@ -285,6 +290,9 @@ int mlp_backward_chain_f16x3(const MlpPlan& plan, const ChainArgs& a, int produc
     HalfChainArgs args;
     args.c = a;
     args.half_dgrad_offset = plan.half_dgrad_offset;
+    int most_ks = 0;
+    for (const MlpPlan::HalfStage& st : plan.half_dgrad_stages) most_ks = std::max(most_ks, st.unit_floats / 512);
+    args.slot_floats = products == 3 ? kUnitBufFloats : (most_ks + 3) / 4 * 4 * 256;   // hi halves only (see the forward)
     const int key = plan.wt * 10 + plan.vt;
 #define SNERF_CHAIN(WT_, VT_, VD_) return products == 3 ? launch_chain_half<WT_, VT_, VD_, 3>(args, stream) : launch_chain_half<WT_, VT_, VD_, 1>(args, stream)
     switch (key) {
