@@ -9,7 +9,9 @@ the parameters.  There is no eager/CPU fallback: CPU tensors or an unbuilt libra
 
 One extra, optional config key: ``configs['model']['hip_precision']`` = ``'fp32'`` (default; fp32 matrix cores) or
 ``'f16x3'`` (fp16 hi/lo split, three MFMAs per product, fp32 accumulate: fp32-grade results ~2.5x faster; covers the
-forward, the activation-keeping training forward and the backward dgrad chain -- weight-gradient products stay fp32).
+forward, the activation-keeping training forward, the backward dgrad chain and the large weight-gradient products), or
+``'f16'`` (16-bit mode: one fp16 MFMA per product, 16-bit saved activations / layer gradients, fp32 master weights and
+accumulation; ~4x faster training than fp32 at ~1e-3 agreement -- outside the fp32 parity bar, tests/test_gpu_f16.py).
 
 Differences from the reference that a caller can observe:
   * ``model.chunk`` / ``model.netchunk`` are accepted and ignored -- the kernels tile the work themselves and the
