@@ -371,9 +371,9 @@ __device__ __forceinline__ void mask_with_words(f32x16* acc, const unsigned (&wo
 }
 
 // 16-bit saved tiles (SNERF_PRECISION_F16): NKS consecutive operand fragments -> NKS "pieces" of 1 KiB.  A piece is the
-// fragment image of one 16-feature k-step, [slot = 2 * sample + lane half][8 x 16 bit], i.e. for sample j the features
-// 16s + {0..3 | 4..7 | 8..11 | 12..15} in natural order within its 32 bytes -- sample-major rows that the weight-gradient
-// kernel reads back TRANSPOSED (ds_read_b64_tr_b16).  Every store instruction writes 1 KiB contiguous.
+// fragment image of one 16-feature k-step, [slot = 2 * sample + lane half][8 x 16 bit]: sample j owns 32 consecutive
+// bytes holding features 16s + {0..3, 8..11, 4..7, 12..15} (feature 8g + 4h + q sits at byte 16h + 8g + 2q) -- sample-major
+// rows that the weight-gradient kernel reads back TRANSPOSED (ds_read_b64_tr_b16).  Every store writes 1 KiB contiguous.
 template <int NKS, int NB>
 __device__ __forceinline__ void store_pieces(const f16x8 (&frag)[NB], _Float16* __restrict__ rows, int lane) {
     static_assert(NB >= NKS, "fragment array too short");

@@ -172,3 +172,37 @@ def test_f16_training_run_tracks_fp32():
 
     ref, got = run('fp32'), run('f16')
     assert ref > 10.0 and abs(got - ref) < 1.0, (ref, got)
+
+
+@pytest.mark.parametrize('case', list(range(10)))
+def test_f16_random_shapes(case):
+    """Ragged shapes (single rays / samples, counts off the 32- and 128-sample tiles) and depths 1, 2, 4, 6, 8 in all three
+    weight layouts: forward against the oracle, gradients against the fp32 kernels on the same inputs."""
+    rng = numpy.random.RandomState(3000 + case)
+    layout = ['main', 'ptsaug', 'viewsaug'][case % 3]
+    depth, width, vwidth = [(8, 256, 128), (4, 128, 64), (2, 128, 64), (6, 256, 128), (1, 256, 128)][case % 5]
+    cfg = synth.mlp_config(64, depth=depth, width=width, views_width=vwidth, **LAYOUTS[layout])
+    sd = synth.synth_state_dict(util.mlp_param_shapes(cfg), 300 + case, float(rng.choice([1.0, 30.0])), float(rng.uniform(-2, 2)))
+    n, s = int(rng.randint(1, 90)), int(rng.choice([1, 2, 31, 33, 64, 127, 129, 192]))
+    o = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(numpy.float32))
+    d = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(numpy.float32))
+    v = d / d.norm(dim=1, keepdim=True)
+    z = torch.from_numpy(numpy.sort(rng.uniform(0, 1, (n, s)).astype(numpy.float32), axis=1))
+    params = {k: torch.from_numpy(a) for k, a in sd.items()}
+    ref = oracle.run_mlp(params, '', cfg, oracle.ray_points(o, d, z), v, None, None)
+    plist = abi_param_list({k: a.to(DEV) for k, a in params.items()})
+    mlp = ops.PackedMlp(cfg, DEV)
+    mlp.pack(plist)
+    dev = (o.to(DEV), d.to(DEV), v.to(DEV), z.to(DEV), None)
+    g_sigma = torch.from_numpy(rng.standard_normal((n, s, 1)).astype(numpy.float32)).to(DEV)
+    g_rgb = torch.from_numpy(rng.standard_normal((n, s, 3)).astype(numpy.float32)).to(DEV)
+    shapes = [tuple(p.shape) for p in plist]
+    sigma, rgb, saved = mlp.forward_train(*dev, F16)
+    scale = max(1.0, float(ref['sigma'].abs().max()))
+    assert util.linf(sigma, ref['sigma']) <= 5e-3 * scale and util.linf(rgb, ref['rgb']) <= 1e-3, (layout, depth, width, n, s)
+    got = mlp.backward(saved, sigma, rgb, g_sigma, g_rgb, shapes, F16)
+    sigma32, rgb32, saved32 = mlp.forward_train(*dev, ops.PRECISION_FP32)
+    want = mlp.backward(saved32, sigma32, rgb32, g_sigma, g_rgb, shapes, ops.PRECISION_FP32)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.isfinite(a).all()
+        assert rel_l2(a, b) < 0.2 or float(b.abs().max()) == 0.0, (i, layout, depth, width, n, s, rel_l2(a, b))

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Fold separate rocprofv3 --pmc passes of one command into a per-kernel table (duration, HBM bytes and rate, matrix-pipe
+and wave-state fractions).
+
+On the GPU box, one pass per counter set (--pmc never together with the trace domains gpurun refuses):
+    cd /tmp && export TMPDIR=/tmp
+    for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+        rocprofv3 --pmc $set --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/<tag>_${set%% *} -o p -- python3 <command>
+    done
+here:  python tools/collect_pmc_kernels.py gpurun_out/<tag> profiles/<name>.json "<command, for the record>" [kernel-name filter ...]
+
+HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of a wide streaming read, WRITE_SIZE is
+exact -- MI355X_MICROARCH.md, HBM).  Fractions: MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs);
+wave states relative to SQ_WAVE_CYCLES."""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    return re.sub(r'\(.*', '', name)
+
+
+def load(path):
+    values, times = defaultdict(lambda: defaultdict(list)), defaultdict(list)
+    with open(path) as f:
+        seen = set()
+        for r in csv.DictReader(f):
+            k = short(r['Kernel_Name'])
+            values[k][r['Counter_Name']].append(float(r['Counter_Value']))
+            if r['Dispatch_Id'] not in seen:
+                seen.add(r['Dispatch_Id'])
+                times[k].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    return values, times
+
+
+def main():
+    tag, dst, command = sys.argv[1], sys.argv[2], sys.argv[3]
+    filters = sys.argv[4:]
+    sq, sq_t = load(f'{tag}_SQ_VALU_MFMA_BUSY_CYCLES/p_counter_collection.csv')
+    fetch, _ = load(f'{tag}_FETCH_SIZE/p_counter_collection.csv')
+    write, _ = load(f'{tag}_WRITE_SIZE/p_counter_collection.csv')
+    mean = lambda xs: sum(xs) / len(xs)
+    rows = []
+    for k in sq:
+        if filters and not any(f in k for f in filters):
+            continue
+        c = {n: mean(v) for n, v in sq[k].items()}
+        us = mean(sq_t[k]) / 1e3
+        hbm = (2 * mean(fetch[k]['FETCH_SIZE']) + mean(write[k]['WRITE_SIZE'])) * 1024 if k in fetch and k in write else None
+        row = {'kernel': k, 'dispatches': len(sq_t[k]), 'duration_us': round(us, 1),
+               'mfma_busy_fraction': round(c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] / 8 * 1024), 3)}
+        if c.get('SQ_WAVE_CYCLES'):
+            w = c['SQ_WAVE_CYCLES']
+            row.update({'parked_at_waitcnt_or_barrier': round(c['SQ_WAIT_ANY'] / w, 3),
+                        'issue_stalled': round(c['SQ_WAIT_INST_ANY'] / w, 3), 'issuing': round(c['SQ_ACTIVE_INST_ANY'] / w, 3)})
+        if hbm is not None:
+            row.update({'hbm_bytes': hbm, 'hbm_tb_per_s': round(hbm / (us * 1e-6) / 1e12, 2)})
+        rows.append(row)
+    rows.sort(key=lambda r: -r['duration_us'] * r['dispatches'])
+    out = {'source': f'rocprofv3 --pmc <set> --kernel-trace -- python3 {command}  (three passes: SQ set | FETCH_SIZE | WRITE_SIZE; '
+                     'durations from the SQ pass, averages over the dispatches of each kernel); folded by tools/collect_pmc_kernels.py',
+           'correction': 'HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (see pmc_traffic.json)', 'kernels': rows}
+    with open(dst, 'w') as f:
+        json.dump(out, f, indent=1)
+    for r in rows:
+        print(r)
+
+
+if __name__ == '__main__':
+    main()
