@@ -120,8 +120,11 @@ int snerf_mlp_forward(const snerf_mlp_desc* desc, const float* packed, const flo
  *   workspace    device, snerf_mlp_backward_workspace_floats(...) floats of scratch
  *   param_grads  num_params device pointers, same order and shapes as snerf_mlp_pack's `params`; each tensor is
  *                OVERWRITTEN with dL/dparam (sums over samples are taken in a fixed order: bit-reproducible)
- *   precision    SNERF_PRECISION_FP32, or SNERF_PRECISION_F16X3 for the fp16-split forward_train / dgrad chain (the
- *                weight-gradient products stay on the fp32 matrix cores)
+ *   precision    SNERF_PRECISION_FP32; SNERF_PRECISION_F16X3 for the fp16-split forward_train / dgrad chain / large
+ *                weight-gradient products (the small head and encoding products stay on the fp32 matrix cores); or
+ *                SNERF_PRECISION_F16 (16-bit mode).  The layout of saved_acts depends on the precision: pass to
+ *                snerf_mlp_backward the precision that snerf_mlp_forward_train was called with (both buffer-size
+ *                queries are valid for every precision)
  * Inputs (rays, depths, view directions) receive no gradient -- the reference detaches the sample depths (:312).
  */
 size_t snerf_mlp_saved_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples);

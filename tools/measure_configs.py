@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the other BASELINE.json configurations on one MI355X (not bench lines; numbers quoted in DESIGN.md).
-    python tools/measure_configs.py > gpurun_out/configs.json        (SNERF_PREC=f16x3 for the split-precision kernels)"""
+    python tools/measure_configs.py > gpurun_out/configs.json        (SNERF_PREC=f16x3 for the split-precision kernels, f16 for the 16-bit mode)"""
 import json
 import os
 import sys

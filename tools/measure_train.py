@@ -2,7 +2,7 @@
 """Config 5 on one MI355X: the reference's training iteration (Trainer.train_one_iter, src/Trainer01.py:60-107, with the
 shipped LLFF settings: 2048 pixel rays + 2048 sparse-depth rays, sub-batches of 2048) with every stage on the device:
 batch assembly -> 4-MLP forward -> nine losses -> backward -> Adam with the decayed learning rate.
-    python tools/measure_train.py > gpurun_out/train.json          (SNERF_PREC=f16x3 for the split-precision kernels)
+    python tools/measure_train.py > gpurun_out/train.json          (SNERF_PREC=f16x3 for the split-precision kernels, f16 for the 16-bit mode)
 Also times the stages around the renderer separately and, for comparison, the same loss set and optimiser step done
 with stock torch ops on the GPU (what the reference's loss / optimiser code would launch)."""
 import json

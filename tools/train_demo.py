@@ -2,7 +2,7 @@
 """End-to-end training sanity run on one MI355X: the synthetic 3-view plane scene (synth.training_scene at 96x128),
 every stage on the device (BatchAssembler -> SimpleNeRFHip -> LossComputer -> optim.Adam with the NeRF decay), a few
 hundred iterations.  Prints the loss curve and the PSNR of a training view rendered before and after.
-    python tools/train_demo.py [iterations]            (SNERF_PREC=f16x3 for the split-precision kernels;
+    python tools/train_demo.py [iterations]            (SNERF_PREC=f16x3 for the split-precision kernels, f16 for the 16-bit mode;
                                                         SNERF_GRAPH=1 replays the pass from one HIP graph)"""
 import json
 import math
