@@ -157,7 +157,7 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 measurement')
+    ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 / f16 measurements')
     ap.add_argument('--precision', choices=('fp32', 'f16x3', 'f16'), default='fp32',
                     help="arithmetic of the fused MLP kernel: fp32 MFMA; fp16 hi/lo split with 3 MFMAs per product "
                          "(fp32-grade results, same parity tests); or f16 = one fp16 MFMA per product with 16-bit saved "
@@ -265,26 +265,37 @@ def main():
                          'kernel_share_of_step': kernel_ms / (elapsed * 1e3)},
         }
         if world == 1 and args.precision == 'fp32' and not args.no_alt:
-            # the same step with the fp16-split MLP kernel (same parity tests), as a secondary measurement
-            alt_model = synthetic_model(configs, 7, device, 'f16x3')
-            with torch.no_grad():
-                for _ in range(args.warmup):
-                    alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
-                torch.cuda.synchronize()
-                ops.PackedMlp.event_log = []
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
-                torch.cuda.synchronize()
-                alt_elapsed = time.perf_counter() - t0
-            alt_log, ops.PackedMlp.event_log = ops.PackedMlp.event_log, None
-            alt_ms = sum(a.elapsed_time(b) for a, b, _ in alt_log)
-            alt_tf = sum(n for _, _, n in alt_log) * FLOP_PER_SAMPLE / (alt_ms * 1e-3) / 1e12
+            # the same step with the other two arithmetic modes of the fused MLP kernel, as secondary measurements
+            def measure(precision):
+                alt_model = synthetic_model(configs, 7, device, precision)
+                with torch.no_grad():
+                    for _ in range(args.warmup):
+                        alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
+                    torch.cuda.synchronize()
+                    ops.PackedMlp.event_log = []
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
+                    torch.cuda.synchronize()
+                    alt_elapsed = time.perf_counter() - t0
+                alt_log, ops.PackedMlp.event_log = ops.PackedMlp.event_log, None
+                alt_ms = sum(a.elapsed_time(b) for a, b, _ in alt_log)
+                alt_tf = sum(n for _, _, n in alt_log) * FLOP_PER_SAMPLE / (alt_ms * 1e-3) / 1e12
+                return alt_elapsed, alt_tf
+
+            alt_elapsed, alt_tf = measure('f16x3')
             result['also_measured'] = {
                 'precision': 'f16x3 (fp16 hi/lo split, 3 MFMA passes per product, fp32 accumulate; same parity tests)',
                 'value': RAYS_PER_GPU * args.steps / alt_elapsed, 'unit': 'rays/s', 'ms_per_step': alt_elapsed / args.steps * 1e3,
                 'roofline': {'bound': 'mfma', 'achieved': alt_tf, 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                             'frac': alt_tf / PEAK_FP16_MFMA_TFLOPS, 'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false>'}}
+                             'frac': alt_tf / PEAK_FP16_MFMA_TFLOPS, 'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false,false,3>'}}
+            alt_elapsed, alt_tf = measure('f16')
+            result['also_measured_16bit'] = {
+                'precision': 'f16 (one fp16 MFMA pass per product, fp32 accumulate; OUTSIDE the fp32 parity bar -- colour ~1e-4, '
+                             'depth ~6e-4 from the fp32 path, tests/test_gpu_f16.py; BASELINE config 5 names this mode for training)',
+                'value': RAYS_PER_GPU * args.steps / alt_elapsed, 'unit': 'rays/s', 'ms_per_step': alt_elapsed / args.steps * 1e3,
+                'roofline': {'bound': 'mfma', 'achieved': alt_tf, 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                             'frac': alt_tf / PEAK_FP16_MFMA_TFLOPS, 'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false,false,1>'}}
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(configs, camera, first)
         print(json.dumps(result), flush=True)

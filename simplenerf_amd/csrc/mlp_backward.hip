@@ -223,6 +223,14 @@ __device__ __forceinline__ void lds_dma_16(const float* src, const float* lds_ds
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(src) : "memory", "m0");
 }
 
+// The same with the global address split into a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: the
+// per-piece address arithmetic then runs on the scalar unit, a 64-bit add per piece and block.
+__device__ __forceinline__ void lds_dma_16_base(const void* uniform_base, unsigned lane_byte_offset, unsigned lds_byte_address) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_address), "v"(lane_byte_offset),
+                 "s"(uniform_base)
+                 : "memory", "m0");
+}
+
 constexpr int kMaxJobs = 16;
 struct JobTable {
     int count;
@@ -434,18 +442,44 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     const int per_wave = (pieces + 3) >> 2;
     const int dy_pieces_real = (job.dy_skip + job.out_rows + 15) >> 4, x_pieces_real = (job.in_rows + 15) >> 4;
     const int buf_floats = (job.out_tiles + job.in_tiles) * (kPairBytes / 4);
-    auto stage = [&](long long b, float* dst) {
-        for (int k = 0; k < per_wave; ++k) {
-            int q = wave + 4 * k;
-            if (q >= pieces) q = pieces - 1;
-            const float* src = zeros + (lane & 15) * 4;   // zero page: 256 bytes
-            if (q < pieces_dy) {
-                if (q < dy_pieces_real)
-                    src = reinterpret_cast<const float*>(grads + ((b * job.grad_rows + job.dy_row0) * 32 + q * 512)) + lane * 4;
-            } else if (q - pieces_dy < x_pieces_real) {
-                src = reinterpret_cast<const float*>(acts + ((b * job.act_rows + job.x_row0) * 32 + (q - pieces_dy) * 512)) + lane * 4;
+    // Source base, LDS offset and per-block stride of each of this wave's (at most 8) pieces, worked out once: per block
+    // the staging then costs one scalar 64-bit add and one DMA instruction per piece.  (Recomputing the addresses from
+    // the block index took ~75 scalar instructions per piece, 600 per block and wave -- more issue time than the
+    // block's 32 MFMAs run; the kernel sat at 19 % MFMA-busy and 3.7 TB/s whatever the layout or the ring depth.)
+    constexpr int kMaxPerWave = 8;                       // (8 + 8 tiles) * 2 pieces / 4 waves
+    const char* piece_src[kMaxPerWave];
+    unsigned piece_dst[kMaxPerWave];
+    long long piece_stride[kMaxPerWave];
+    const unsigned lane16 = lane * 16;
+#pragma unroll
+    for (int k = 0; k < kMaxPerWave; ++k) {
+        int q = wave + 4 * k;
+        if (q >= pieces) q = pieces - 1;
+        const char* src = reinterpret_cast<const char*>(zeros + 192);   // 1 KiB zero page
+        long long stride = 0;
+        if (q < pieces_dy) {
+            if (q < dy_pieces_real) {
+                src = reinterpret_cast<const char*>(grads + ((b0 * job.grad_rows + job.dy_row0) * 32 + q * 512));
+                stride = (long long)job.grad_rows * 64;
             }
-            lds_dma_16(src, dst + (q >> 1) * (kPairBytes / 4) + (q & 1) * (kPieceGap / 4));
+        } else if (q - pieces_dy < x_pieces_real) {
+            src = reinterpret_cast<const char*>(acts + ((b0 * job.act_rows + job.x_row0) * 32 + (q - pieces_dy) * 512));
+            stride = (long long)job.act_rows * 64;
+        }
+        piece_src[k] = src;
+        piece_stride[k] = stride;
+        piece_dst[k] = (q >> 1) * kPairBytes + (q & 1) * kPieceGap;
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds;
+    // requests the NEXT block in line (blocks are staged strictly in order) into ring slot `slot`
+    auto stage_next = [&](int slot) {
+        const unsigned dst = lds_base + (unsigned)slot * (unsigned)(buf_floats * 4);
+#pragma unroll
+        for (int k = 0; k < kMaxPerWave; ++k) {
+            if (k < per_wave) {
+                lds_dma_16_base(piece_src[k], lane16, dst + piece_dst[k]);
+                piece_src[k] += piece_stride[k];
+            }
         }
     };
 
@@ -455,60 +489,86 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     const unsigned lane_off = (grp & 1) * kPieceGap + 32 * (8 * (grp >> 1) + q4) + 16 * (p4 & 1) + 8 * (p4 >> 1);
     const float gk = wgrad_scale(__uint_as_float(reinterpret_cast<const unsigned*>(zeros)[64 + job.dy_row0 / 32]));
 
-    const long long nblocks = b1 - b0;
-    for (int k = 0; k < kWgrad16Buffers - 1; ++k)
-        if (k < nblocks) stage(b0 + k, lds + k * buf_floats);
-    for (long long n = 0; n < nblocks; ++n) {
-        // block n must have landed; blocks n+1 (and the stores of nobody: this kernel stores only at the end) may fly
-        const long long ahead = nblocks - 1 - n < kWgrad16Buffers - 2 ? nblocks - 1 - n : kWgrad16Buffers - 2;
-        wait_vmcnt((int)ahead * per_wave);
-        __builtin_amdgcn_s_barrier();   // every wave's pieces of block n are in; everyone finished reading block n-1
-        if (n + kWgrad16Buffers - 1 < nblocks)
-            stage(b0 + n + kWgrad16Buffers - 1, lds + ((n + kWgrad16Buffers - 1) % kWgrad16Buffers) * buf_floats);
-        if (active) {
-            const unsigned cur = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(lds + (n % kWgrad16Buffers) * buf_floats) + lane_off;
-            const unsigned a_addr = cur + wo * NO * kPairBytes;
-            const unsigned b_addr = cur + (job.out_tiles + wi * NI) * kPairBytes;
-            // (one 16-sample k-step at a time, not unrolled: with both in flight the <2,8> tile spills, and a scratch
-            // reload inside this loop would make the compiler drain the prefetch DMA)
-#pragma unroll 1
-            for (int kk = 0; kk < 2; ++kk) {
-                Frag16 a[NO], bx[NI];
-                const unsigned a_kk = a_addr + kk * 512, b_kk = b_addr + kk * 512;
+    // Software pipeline over the 16-sample k-steps (two per block): the transposed reads of step t+1 are issued before the
+    // MFMAs of step t, into the other fragment set, so the LDS latency and the bf16->fp16 conversion of the next step run
+    // in the shadow of the current step's matrix work (issued one after the other, a block took ~4800 cycles for 1024
+    // cycles of MFMAs: 19 % busy, PMC).  Block n+1 must therefore have landed -- for every wave -- in the MIDDLE of block
+    // n: that is where the vmcnt wait and the barrier sit; the barrier also tells that everyone finished reading block
+    // n-1 (those reads were waited for during k-step 1 of block n-1), whose buffer then receives block n+2.
+    struct FragSet {
+        Frag16 a[NO], bx[NI];
+    };
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds + lane_off;
+    const unsigned a_off = wo * NO * kPairBytes, b_off = (job.out_tiles + wi * NI) * kPairBytes;
+    auto issue_reads = [&](FragSet& f, int slot, int kk) {
+        const unsigned buf = lds0 + (unsigned)slot * (unsigned)(buf_floats * 4) + kk * 512;
+        const unsigned a_kk = buf + a_off, b_kk = buf + b_off;
 #pragma unroll
-                for (int oo = 0; oo < NO; ++oo) {
-                    a[oo].d[0] = lds_read_tr16(a_kk, oo * kPairBytes);
-                    a[oo].d[1] = lds_read_tr16(a_kk, oo * kPairBytes + 128);
-                }
+        for (int oo = 0; oo < NO; ++oo) {
+            f.a[oo].d[0] = lds_read_tr16(a_kk, oo * kPairBytes);
+            f.a[oo].d[1] = lds_read_tr16(a_kk, oo * kPairBytes + 128);
+        }
 #pragma unroll
-                for (int ii = 0; ii < NI; ++ii) {
-                    bx[ii].d[0] = lds_read_tr16(b_kk, ii * kPairBytes);
-                    bx[ii].d[1] = lds_read_tr16(b_kk, ii * kPairBytes + 128);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int ii = 0; ii < NI; ++ii) {
+            f.bx[ii].d[0] = lds_read_tr16(b_kk, ii * kPairBytes);
+            f.bx[ii].d[1] = lds_read_tr16(b_kk, ii * kPairBytes + 128);
+        }
+    };
+    auto wait_reads = [&](FragSet& f, f16x8 (&ah)[NO]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int oo = 0; oo < NO; ++oo) { after_lds_wait(a[oo].d[0]); after_lds_wait(a[oo].d[1]); }
+        for (int oo = 0; oo < NO; ++oo) { after_lds_wait(f.a[oo].d[0]); after_lds_wait(f.a[oo].d[1]); }
 #pragma unroll
-                for (int ii = 0; ii < NI; ++ii) { after_lds_wait(bx[ii].d[0]); after_lds_wait(bx[ii].d[1]); }
-                f16x8 ah[NO];
+        for (int ii = 0; ii < NI; ++ii) { after_lds_wait(f.bx[ii].d[0]); after_lds_wait(f.bx[ii].d[1]); }
 #pragma unroll
-                for (int oo = 0; oo < NO; ++oo) {
-                    // bf16 pairs -> fp32 (exact), bias sum in true units, x region scale -> fp16
+        for (int oo = 0; oo < NO; ++oo) {
+            // bf16 pairs -> fp32 (exact), bias sum in true units, x region scale -> fp16
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const unsigned word = a[oo].d[w >> 1][w & 1];
-                        const f32x2 v = {__uint_as_float(word << 16), __uint_as_float(word & 0xffff0000u)};
-                        bsum[oo] += v[0] + v[1];
-                        const f16x2 hcv = __builtin_convertvector(v * gk, f16x2);
-                        ah[oo][2 * w] = hcv[0]; ah[oo][2 * w + 1] = hcv[1];
-                    }
-                }
-#pragma unroll
-                for (int oo = 0; oo < NO; ++oo)
-#pragma unroll
-                    for (int ii = 0; ii < NI; ++ii)
-                        acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[oo], bx[ii].h, acc[oo][ii], 0, 0, 0);
+            for (int w = 0; w < 4; ++w) {
+                const unsigned word = f.a[oo].d[w >> 1][w & 1];
+                const f32x2 v = {__uint_as_float(word << 16), __uint_as_float(word & 0xffff0000u)};
+                bsum[oo] += v[0] + v[1];
+                const f16x2 hcv = __builtin_convertvector(v * gk, f16x2);
+                ah[oo][2 * w] = hcv[0]; ah[oo][2 * w + 1] = hcv[1];
             }
+        }
+    };
+    auto products = [&](const FragSet& f, const f16x8 (&ah)[NO]) {
+#pragma unroll
+        for (int oo = 0; oo < NO; ++oo)
+#pragma unroll
+            for (int ii = 0; ii < NI; ++ii)
+                acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[oo], f.bx[ii].h, acc[oo][ii], 0, 0, 0);
+    };
+
+    const int nblocks = (int)(b1 - b0);
+    FragSet even, odd;
+    f16x8 ah[NO];
+    int stage_slot = 0, read_slot = 0;                       // ring positions of the next block to request / to read
+    auto advance = [](int& slot) { slot = slot == kWgrad16Buffers - 1 ? 0 : slot + 1; };
+    if (nblocks > 0) {
+        stage_next(stage_slot); advance(stage_slot);
+        if (nblocks > 1) { stage_next(stage_slot); advance(stage_slot); }
+        wait_vmcnt(nblocks > 1 ? per_wave : 0);
+        __builtin_amdgcn_s_barrier();                       // block 0 is in for every wave
+        if (active) issue_reads(even, read_slot, 0);
+    }
+    for (int n = 0; n < nblocks; ++n) {
+        if (active) {
+            wait_reads(even, ah);
+            issue_reads(odd, read_slot, 1);
+            products(even, ah);
+        }
+        advance(read_slot);
+        if (n + 1 < nblocks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // block n+1 (requested half a block ago or earlier)
+            __builtin_amdgcn_s_barrier();
+            if (n + 2 < nblocks) { stage_next(stage_slot); advance(stage_slot); }
+        }
+        if (active) {
+            wait_reads(odd, ah);
+            if (n + 1 < nblocks) issue_reads(even, read_slot, 0);
+            products(odd, ah);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -616,7 +676,8 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
     Workspace w;
     const long long blocks = (total_samples + 127) / 128 * 4;
     w.grads_floats = blocks * p.grad_rows() * 32;   // (the 16-bit tiles use the first half)
-    long long off = 192;  // [0, 64): zero page for padded rows; [64, 192): per-region max |dY| words (f16x3)
+    long long off = 448;  // [0, 64): zero page for padded rows; [64, 192): per-region max |dY| words (f16x3);
+                          // [192, 448): 1 KiB zero page of the 16-bit weight-gradient kernel
     auto add = [&](int dy_row0, int out_rows, int x_row0, int in_rows, int w_param, int w_ld, int w_col, int b_param,
                    int x_kind = snerf::SEG_ACC) {
         WgradJob j;
@@ -801,7 +862,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     a.grad_head = plan.grad_head();
     if (f16) { a.act_rows = plan.act16_rows(); a.grad_rows = plan.grad16_rows(); }
     // partial[0..64): zero page for padded staging rows; partial[64..192): per-region max |dY| (f16x3)
-    hipError_t he = hipMemsetAsync(partial, 0, 192 * sizeof(float), s);
+    hipError_t he = hipMemsetAsync(partial, 0, 448 * sizeof(float), s);
     if (he != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: memset: %s", hipGetErrorString(he));
     int rc;
     const int key = precision != SNERF_PRECISION_FP32 ? -1 : plan.wt * 10 + plan.vt;
