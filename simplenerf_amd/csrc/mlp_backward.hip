@@ -279,18 +279,51 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
     // to the read address below -- so that the 16 lanes of a ds_read_b128 group (16 rows, same logical chunk) hit 16
     // different bank quads.  Rows beyond the job's out_rows / in_rows are filled from a zero page.
     const int buf_floats = rows * 32;
-    auto stage = [&](long long b, float* dst) {
-        const int pieces = rows >> 3;
-        for (int q = wave; q < pieces; q += 4) {
-            const int r = q * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            const float* src = zeros + c * 4;
-            if (r < rows_dy) {
-                if (r < job.out_rows) src = grads + (b * job.grad_rows + job.dy_row0 + r) * 32 + c * 4;
-            } else if (r - rows_dy < job.in_rows) {
-                src = acts + (b * job.act_rows + job.x_row0 + (r - rows_dy)) * 32 + c * 4;
+    // Per piece of this wave (q = wave + 4k): source address of its first block, worked out ONCE -- per block the staging
+    // is then a scalar 64-bit add and one DMA instruction per piece.  (Recomputing the per-lane addresses from the block
+    // index inside the loop cost ~50 instructions, two divergent branches and several scalar loads of job fields per
+    // piece: more issue time per block than its MFMAs take.)  The swizzle term (4q + lane/16) & 7 has 4q & 7 = 4(wave & 1)
+    // for every piece of a wave, so one per-lane offset serves them all.  A piece whose 8 rows straddle the end of the
+    // job's rows (head and encoding products) mixes real rows and zero-page lanes: per-lane pointers, rebuilt per block.
+    constexpr int kMaxSlots = 16;                           // (8 + 8 tiles) * 4 pieces / 4 waves
+    const int per_wave = rows >> 5;                         // pieces / 4 (rows is a multiple of 32)
+    const char* slot_src[kMaxSlots];
+    int slot_rows[kMaxSlots];                               // real rows in the piece: 8 all, 0 none (zero page), else ragged
+    const char* zero_page = reinterpret_cast<const char*>(zeros + 192);      // 1 KiB
+    const long long dy_stride = (long long)job.grad_rows * 128, x_stride = (long long)job.act_rows * 128;
+#pragma unroll
+    for (int k = 0; k < kMaxSlots; ++k) {
+        const int r0 = (wave + 4 * k) * 8;
+        int real;
+        const char* src;
+        if (r0 < rows_dy) {
+            real = job.out_rows - r0;
+            src = reinterpret_cast<const char*>(grads) + (b0 * job.grad_rows + job.dy_row0 + r0) * 128;
+        } else {
+            real = job.in_rows - (r0 - rows_dy);
+            src = reinterpret_cast<const char*>(acts) + (b0 * job.act_rows + job.x_row0 + (r0 - rows_dy)) * 128;
+        }
+        real = real < 0 ? 0 : (real > 8 ? 8 : real);
+        slot_rows[k] = real;
+        slot_src[k] = real > 0 ? src : zero_page;
+    }
+    const unsigned lane_off = (lane >> 3) * 128 + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) << 4);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds;
+    // requests the NEXT block in line (blocks are staged strictly in order) into the buffer at `buffer_floats`
+    auto stage_next = [&](int buffer_floats) {
+#pragma unroll
+        for (int k = 0; k < kMaxSlots; ++k) {
+            if (k < per_wave) {
+                const unsigned dst = lds_base + (unsigned)buffer_floats * 4 + (wave + 4 * k) * 1024;
+                const int real = slot_rows[k];
+                if (real == 8 || real == 0) {
+                    lds_dma_16_base(slot_src[k], real ? lane_off : lane * 16, dst);
+                } else {
+                    const char* p = (lane >> 3) < real ? slot_src[k] + lane_off : zero_page + lane * 16;
+                    lds_dma_16(reinterpret_cast<const float*>(p), reinterpret_cast<const float*>(lds) + buffer_floats + (wave + 4 * k) * 256);
+                }
+                if (real) slot_src[k] += (wave + 4 * k) * 8 < rows_dy ? dy_stride : x_stride;
             }
-            lds_dma_16(src, dst + q * 256);
         }
     };
 
@@ -302,12 +335,12 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
     // (read once, before any DMA is in flight: a global load inside the loop makes the compiler wait for vmcnt(0),
     // i.e. for the prefetch of the next block as well)
     const float gk = F16 ? wgrad_scale(__uint_as_float(reinterpret_cast<const unsigned*>(zeros)[64 + job.dy_row0 / 32])) : 1.0f;
-    if (b0 < b1) stage(b0, lds);
+    if (b0 < b1) stage_next(0);
     for (long long b = b0; b < b1; ++b) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // block b has landed for every wave, and every wave is done reading the other buffer
         const float* cur = lds + ((b - b0) & 1) * buf_floats;
-        if (b + 1 < b1) stage(b + 1, lds + ((b - b0 + 1) & 1) * buf_floats);
+        if (b + 1 < b1) stage_next((int)((b - b0 + 1) & 1) * buf_floats);
         if (active && F16) {
             // fp16-split product: two k-steps of 16 samples; dY scaled by one power of two per region (wgrad_scale)
 #pragma unroll 1
