@@ -118,7 +118,12 @@ struct UnitStreamT {
         // them made the wait stricter than needed: it drained the run-ahead DMA and the stores at every unit of the
         // training forward (MFMA pipe 34 % busy against 48 % without the stores).  The counter saturates at 63.
         const int in_flight = issued + younger;
-        wait_vmcnt(next > 0 ? (in_flight < 63 ? in_flight : 63) : 0);
+        const int allowed = next > 0 ? (in_flight < 63 ? in_flight : 63) : 0;
+        // (the generic 64-way dispatch compiles to a compare-and-branch tree of ~30 scalar instructions, and with one wave
+        // per SIMD every instruction is an issue slot: the steady-state counts of the 256-wide trunk -- the successor's
+        // k/2 resp. k/4 DMA instructions and nothing else -- are tested first)
+        if (allowed == (P == 3 ? 8 : 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P == 3 ? 8 : 4) : "memory");
+        else wait_vmcnt(allowed);
         younger = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my LDS reads of unit i-1 are complete
 #ifndef SNERF_ABL_NOBARRIER
