@@ -99,6 +99,10 @@ enum snerf_precision {
                                   layer gradients as bf16 (half the HBM traffic).  NOT within the fp32 parity bar: results
                                   agree with the fp32 path to ~1e-3 (tests/test_gpu_f16.py states the tolerances) */
 };
+/* Range: both fp16 modes hold hidden activations and weights as fp16 numbers (pairs), so their magnitudes must stay
+ * below 65504 -- far above what a NeRF MLP on encoded inputs produces (trained hidden units are O(1..100)); beyond it
+ * the affected samples come out non-finite.  Gradients have no such limit (renormalised by powers of two).  The fp32
+ * mode has the full fp32 range. */
 
 /*   origins, dirs   device (num_rays,3): the rays the depths are measured along (NDC rays when ndc)
  *   view_dirs       device (num_rays,3) or NULL when !use_view_dirs
