@@ -1,6 +1,7 @@
 // A torch-free consumer of the C ABI: plain HIP runtime + include/*.h, linked against libsimplenerf_hip.so.
 // Generates the rays of a small frame, their coarse depths, a shuffled epoch of pixel indices, Philox draws, one Adam
-// step and a display conversion, and checks invariants on the host.  Built and run by tests/test_gpu_native.py.
+// step and a display conversion, runs a 4x128 MLP forward in the three arithmetic modes and its training forward +
+// backward, and checks invariants on the host.  Built and run by tests/test_gpu_native.py.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -115,6 +116,73 @@ int main() {
     auto hdep = host(ddep_out, 2);
     CHECK(himg[0] == 0 && himg[1] == 2 && himg[2] == 255 && himg[3] == 0 && himg[4] == 64 && himg[5] == 255);
     CHECK(hdep[0] == 0.f && hdep[1] == 7.f);
+
+    // K3 / K7: a 4x128 view-dependent MLP on those rays -- the three arithmetic modes agree, gradients are finite
+    {
+        snerf_mlp_desc desc = {4, 128, 1, 64, 10, 4, -1, 1, 1};
+        const int np = snerf_mlp_num_params(&desc);
+        CHECK(np == 16);
+        const int shape[16][2] = {{128, 63}, {128, 1}, {128, 128}, {128, 1}, {128, 128}, {128, 1}, {128, 128}, {128, 1},
+                                  {1, 128},  {1, 1},   {128, 128}, {128, 1}, {64, 155},  {64, 1},  {3, 64},    {3, 1}};
+        std::vector<float*> params(np), g32(np), g16(np);
+        unsigned state = 12345u;
+        for (int i = 0; i < np; ++i) {
+            const size_t count = (size_t)shape[i][0] * shape[i][1];
+            std::vector<float> hostw(count);
+            const float scale = (i & 1) ? 0.05f : 1.5f / std::sqrt((float)shape[i][1]);
+            for (float& v : hostw) {
+                state = state * 1664525u + 1013904223u;
+                v = scale * ((float)(state >> 8) / 8388608.f - 1.f);
+            }
+            params[i] = dev<float>(count); g32[i] = dev<float>(count); g16[i] = dev<float>(count);
+            HIP_OK(hipMemcpy(params[i], hostw.data(), count * 4, hipMemcpyHostToDevice));
+        }
+        float* packed = dev<float>(snerf_mlp_packed_floats(&desc));
+        SNERF_OK_(snerf_mlp_pack(&desc, params.data(), np, packed, nullptr));
+        const int S = 16;
+        float *sig[3], *col[3];
+        for (int m = 0; m < 3; ++m) {
+            sig[m] = dev<float>(n * S); col[m] = dev<float>(3 * n * S);
+            SNERF_OK_(snerf_mlp_forward(&desc, packed, o_ndc, d_ndc, dirs, depths, n, S, nullptr, sig[m], col[m], m, nullptr));
+        }
+        HIP_OK(hipDeviceSynchronize());
+        auto c0 = host(col[0], 3 * n * S), c1 = host(col[1], 3 * n * S), c2 = host(col[2], 3 * n * S);
+        float e1 = 0.f, e2 = 0.f, lo = 1.f, hi = 0.f;
+        for (size_t i = 0; i < c0.size(); ++i) {
+            e1 = std::fmax(e1, std::fabs(c1[i] - c0[i])); e2 = std::fmax(e2, std::fabs(c2[i] - c0[i]));
+            lo = std::fmin(lo, c0[i]); hi = std::fmax(hi, c0[i]);
+        }
+        CHECK(hi - lo > 0.05f);                 // not a constant field
+        CHECK(e1 < 1e-5f && e2 < 5e-3f);        // f16x3: fp32-grade; f16: its stated tolerance
+        // training forward + backward, fp32 and the 16-bit mode, with d(sigma) = d(rgb) = 1
+        float* saved = dev<float>(snerf_mlp_saved_floats(&desc, n, S));
+        float* work = dev<float>(snerf_mlp_backward_workspace_floats(&desc, n, S));
+        float *dsig = dev<float>(n * S), *dcol = dev<float>(3 * n * S);
+        std::vector<float> one(3 * n * S, 1.f);
+        HIP_OK(hipMemcpy(dsig, one.data(), n * S * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dcol, one.data(), 3 * n * S * 4, hipMemcpyHostToDevice));
+        const int modes[2] = {SNERF_PRECISION_FP32, SNERF_PRECISION_F16};
+        for (int k = 0; k < 2; ++k) {
+            std::vector<float*>& g = k == 0 ? g32 : g16;
+            SNERF_OK_(snerf_mlp_forward_train(&desc, packed, o_ndc, d_ndc, dirs, depths, n, S, nullptr, sig[0], col[0], saved,
+                                              modes[k], nullptr));
+            SNERF_OK_(snerf_mlp_backward(&desc, packed, saved, sig[0], col[0], dsig, dcol, n, S, work, g.data(), np, modes[k],
+                                         nullptr));
+        }
+        HIP_OK(hipDeviceSynchronize());
+        for (int i = 0; i < np; ++i) {
+            const size_t count = (size_t)shape[i][0] * shape[i][1];
+            auto a = host(g32[i], count), b = host(g16[i], count);
+            double num = 0.0, den = 0.0;
+            for (size_t j = 0; j < count; ++j) {
+                CHECK(std::isfinite(a[j]) && std::isfinite(b[j]));
+                num += ((double)a[j] - b[j]) * ((double)a[j] - b[j]); den += (double)a[j] * a[j];
+            }
+            CHECK(den > 0.0 && std::sqrt(num / den) < 0.1);
+        }
+        CHECK(snerf_mlp_forward(&desc, packed, o_ndc, d_ndc, dirs, depths, n, S, nullptr, sig[0], col[0], 7, nullptr) ==
+              SNERF_E_UNSUPPORTED);
+    }
 
     // errors are status codes with a message, not crashes
     CHECK(snerf_coarse_depths(nullptr, nullptr, 4, 8, 0, nullptr, nullptr, nullptr) == SNERF_E_INVALID);
