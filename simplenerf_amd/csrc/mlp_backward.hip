@@ -51,7 +51,7 @@ __device__ __forceinline__ void relu_backward(const f32x16 (&acc)[U], const unsi
 #pragma unroll
     for (int u = 0; u < U; u += 2)
 #pragma unroll
-        for (int r = 0; r < 32; ++r) dy[16 * u + r] = (words[u >> 1] >> r) & 1u ? acc[u + (r >> 4)][r & 15] : 0.0f;
+        for (int r = 0; r < 32; ++r) dy[16 * u + r] = keep_if_bit(acc[u + (r >> 4)][r & 15], words[u >> 1], r);
 }
 
 template <int WT, int VT, bool VIEWDEP>

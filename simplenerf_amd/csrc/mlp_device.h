@@ -79,6 +79,11 @@ __device__ __forceinline__ void load_acc_tile(float (&h)[N], const float* __rest
         h[n] = tile[f * 32 + j];
     }
 }
+// v if bit `bit` of `word` is set, else +0: the bit becomes 0 / -1 by a signed one-bit field extract and masks the value's
+// bits -- two VALU instructions, against three for test + compare + select (128 values per layer and lane in the chains).
+__device__ __forceinline__ float keep_if_bit(float v, unsigned word, int bit) {
+    return __uint_as_float(__float_as_uint(v) & (unsigned)__builtin_amdgcn_sbfe((int)word, bit, 1));
+}
 // ReLU sign bits (see MlpPlan::act_mask): bit r of a tile's 16-bit field = accumulator register r of this lane > 0.
 __device__ __forceinline__ unsigned relu_bits(const float* __restrict__ h) {
     unsigned m = 0;

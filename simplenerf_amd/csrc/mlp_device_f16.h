@@ -356,7 +356,7 @@ __device__ __forceinline__ void apply_relu_masks(f32x16* acc, const unsigned* __
     for (int u = 0; u < U; u += 2) {
         const unsigned word = masks[((t0 + u) >> 1) * 64 + lane];
 #pragma unroll
-        for (int r = 0; r < 32; ++r) acc[u + (r >> 4)][r & 15] = (word >> r) & 1u ? acc[u + (r >> 4)][r & 15] : 0.0f;
+        for (int r = 0; r < 32; ++r) acc[u + (r >> 4)][r & 15] = keep_if_bit(acc[u + (r >> 4)][r & 15], word, r);
     }
 }
 
@@ -372,7 +372,7 @@ __device__ __forceinline__ void mask_with_words(f32x16* acc, const unsigned (&wo
 #pragma unroll
     for (int u = 0; u < U; u += 2)
 #pragma unroll
-        for (int r = 0; r < 32; ++r) acc[u + (r >> 4)][r & 15] = (words[u >> 1] >> r) & 1u ? acc[u + (r >> 4)][r & 15] : 0.0f;
+        for (int r = 0; r < 32; ++r) acc[u + (r >> 4)][r & 15] = keep_if_bit(acc[u + (r >> 4)][r & 15], words[u >> 1], r);
 }
 
 // 16-bit saved tiles (SNERF_PRECISION_F16): NKS consecutive operand fragments -> NKS "pieces" of 1 KiB.  A piece is the
