@@ -176,8 +176,10 @@ class GraphedTrainStep:
     and, after the replay, the optimiser step.  ~150 launches and their Python glue become one graph launch: the host
     cost of an iteration drops from ~5.4 ms to well under 1 ms, which is what bounds small per-rank batches.
 
-    One pass over the whole batch (no sub-batching: with 288 GB the reference's 2048-row sub-batches are not needed, and
-    the loss means are over mask counts, so the gradients are the same).  ``p.grad`` of every parameter is a static
+    One pass over the whole batch (no sub-batching: with 288 GB the reference's 2048-row sub-batches are not needed).
+    The MSE, sparse-depth and augmentation-depth terms average over their mask counts and come out the same as with
+    sub-batches; the coarse-fine consistency term's patch statistics see the whole batch at once and differ by ~10 %
+    (tools/probes/sub_batch_terms.py) -- use ``train_one_iter`` with ``sub_batch_size`` for the reference's exact iteration.  ``p.grad`` of every parameter is a static
     buffer the graph overwrites each replay: do not call ``zero_grad(set_to_none=True)`` between iterations.  The loss
     weights of the iteration are baked into the graph; it is re-captured when ``LossComputer.get_loss_weight`` changes
     them (the shipped schedule: once, at iteration 10000).

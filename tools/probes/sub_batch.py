@@ -7,7 +7,7 @@ from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
 from simplenerf_amd.models.ModelFactory import get_model
 DEV = torch.device('cuda', 0)
 for sub in (2048, 4096):
-    cfg = synth.training_configs('f16x3'); cfg['sub_batch_size'] = sub
+    cfg = synth.training_configs(os.environ.get('SNERF_PREC', 'f16x3')); cfg['sub_batch_size'] = sub
     model = get_model(cfg, None)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
