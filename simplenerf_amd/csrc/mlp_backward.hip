@@ -309,8 +309,25 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
     }
     const unsigned lane_off = (lane >> 3) * 128 + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) << 4);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds;
+    // Jobs without partial tiles (every 256 x 256 product): piece k of this wave lies k * 4 KiB behind the wave's first
+    // piece of its region, so two running bases replace the per-slot state -- which does not fit the scalar registers
+    // (the general path below keeps 48 values per wave and pays ~12 v_readlane per piece for it).
+    const bool all_full = job.out_rows == rows_dy && job.in_rows == rows_x;
+    const int dy_slots = (rows_dy / 8 - wave + 3) >> 2;     // pieces of this wave inside the dY rows
+    const char* dy_run = reinterpret_cast<const char*>(grads) + (b0 * job.grad_rows + job.dy_row0 + wave * 8) * 128;
+    const char* x_run = reinterpret_cast<const char*>(acts) + (b0 * job.act_rows + job.x_row0 + wave * 8 - rows_dy) * 128;
     // requests the NEXT block in line (blocks are staged strictly in order) into the buffer at `buffer_floats`
     auto stage_next = [&](int buffer_floats) {
+        if (all_full) {
+#pragma unroll
+            for (int k = 0; k < kMaxSlots; ++k)
+                if (k < per_wave)
+                    lds_dma_16_base(k < dy_slots ? dy_run : x_run, lane_off + k * 4096,
+                                    lds_base + (unsigned)buffer_floats * 4 + (wave + 4 * k) * 1024);
+            dy_run += dy_stride;
+            x_run += x_stride;
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < kMaxSlots; ++k) {
             if (k < per_wave) {
@@ -335,34 +352,75 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
     // (read once, before any DMA is in flight: a global load inside the loop makes the compiler wait for vmcnt(0),
     // i.e. for the prefetch of the next block as well)
     const float gk = F16 ? wgrad_scale(__uint_as_float(reinterpret_cast<const unsigned*>(zeros)[64 + job.dy_row0 / 32])) : 1.0f;
+    if constexpr (F16) {
+        // fp16-split product, software-pipelined over the 16-sample k-steps (two per block): the LDS reads and the hi/lo
+        // split of step t+1 (~260 VALU instructions) are issued together with the 48 MFMAs of step t, into the other
+        // fragment set, so they run in the shadow of the matrix work instead of in front of it (the two used to add up:
+        // ~2700 issue cycles per step for 1536 cycles of MFMAs).  Consequences for the staging: every LDS read of block
+        // n is done after its FIRST half (the second step's fragments are converted there), so the barrier in the
+        // middle of block n both releases its buffer for block n+2 and confirms that block n+1 has landed.
+        struct SplitSet {
+            f16x8 ah[NO], al[NO], bh[NI], bl[NI];
+        };
+        // (`counted` = 0 for the look-ahead past the last block, which re-converts valid memory and is never multiplied:
+        // keeping the call unconditional keeps it in the MFMAs' basic block, where the scheduler interleaves the two)
+        auto convert = [&](SplitSet& f, const float* buf, int kk, float counted) {
+            const int c0 = 4 * kk + 2 * half;
+            float unused = 0.0f;
+#pragma unroll
+            for (int oo = 0; oo < NO; ++oo) {
+                float part = 0.0f;
+                split_fragment(buf + a_base + oo * 1024 + row_off, c0, swz, gk, f.ah[oo], f.al[oo], part);
+                bsum[oo] += part * counted;
+            }
+#pragma unroll
+            for (int ii = 0; ii < NI; ++ii) split_fragment(buf + b_base + ii * 1024 + row_off, c0, swz, 1.0f, f.bh[ii], f.bl[ii], unused);
+        };
+        auto products = [&](const SplitSet& f) {
+#pragma unroll
+            for (int oo = 0; oo < NO; ++oo)
+#pragma unroll
+                for (int ii = 0; ii < NI; ++ii) {
+                    acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[oo], f.bh[ii], acc[oo][ii], 0, 0, 0);
+                    acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[oo], f.bl[ii], acc[oo][ii], 0, 0, 0);
+                    acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[oo], f.bh[ii], acc[oo][ii], 0, 0, 0);
+                }
+        };
+        const int nblocks = (int)(b1 - b0);
+        SplitSet even, odd;
+        if (nblocks > 0) {
+            stage_next(0);
+            if (nblocks > 1) stage_next(buf_floats);
+            // block 0 must be in: everything but the second block's requests (per_wave DMA instructions per wave)
+            if (nblocks > 1) wait_vmcnt(per_wave < 63 ? per_wave : 63); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (active) convert(even, lds, 0, 1.0f);
+        }
+        for (int n = 0; n < nblocks; ++n) {
+            const float* cur = lds + (n & 1) * buf_floats;
+            const float* nxt = lds + ((n + 1) & 1) * buf_floats;
+            if (active) {
+                products(even);
+                convert(odd, cur, 1, 1.0f);
+            }
+            // all of this wave's reads of block n are complete once `odd` is converted (the compiler waits for the LDS
+            // data before using it); block n+1 was requested at least half a block ago
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (n + 2 < nblocks) stage_next((n & 1) * buf_floats);
+            if (active) {
+                products(odd);
+                convert(even, n + 1 < nblocks ? nxt : cur, 0, n + 1 < nblocks ? 1.0f : 0.0f);
+            }
+        }
+    } else {
     if (b0 < b1) stage_next(0);
     for (long long b = b0; b < b1; ++b) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // block b has landed for every wave, and every wave is done reading the other buffer
         const float* cur = lds + ((b - b0) & 1) * buf_floats;
         if (b + 1 < b1) stage_next((int)((b - b0 + 1) & 1) * buf_floats);
-        if (active && F16) {
-            // fp16-split product: two k-steps of 16 samples; dY scaled by one power of two per region (wgrad_scale)
-#pragma unroll 1
-            for (int kk = 0; kk < 2; ++kk) {
-                const int c0 = 4 * kk + 2 * half;
-                f16x8 ah[NO], al[NO], bh[NI], bl[NI];
-                float unused = 0.0f;
-#pragma unroll
-                for (int oo = 0; oo < NO; ++oo) split_fragment(cur + a_base + oo * 1024 + row_off, c0, swz, gk, ah[oo], al[oo], bsum[oo]);
-#pragma unroll
-                for (int ii = 0; ii < NI; ++ii) split_fragment(cur + b_base + ii * 1024 + row_off, c0, swz, 1.0f, bh[ii], bl[ii], unused);
-#pragma unroll
-                for (int oo = 0; oo < NO; ++oo)
-#pragma unroll
-                    for (int ii = 0; ii < NI; ++ii) {
-                        acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[oo], bh[ii], acc[oo][ii], 0, 0, 0);
-                        acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[oo], bl[ii], acc[oo][ii], 0, 0, 0);
-                        acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[oo], bh[ii], acc[oo][ii], 0, 0, 0);
-                    }
-            }
-        }
-        if (active && !F16) {
+        if (active) {
             // one 8-sample group at a time (not unrolled): keeps the live fragment registers at 4*(NO+NI) so that nothing
             // spills -- a scratch reload inside this loop would force vmcnt(0) and drain the prefetch DMA issued above
 #pragma unroll 1
@@ -384,6 +442,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
                 }
             }
         }
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!active) return;
