@@ -340,3 +340,17 @@ def training_configs(precision: str = 'fp32', num_rays: int = 2048, num_sparse: 
                         'beta1': 0.9, 'beta2': 0.999}
     cfg.update(sub_batch_size=2048, num_iterations=100000, seed=seed)
     return cfg
+
+
+def abi_param_list(params: dict, prefix: str = ''):
+    """Parameter tensors of one MLP in the C ABI's order (include/simplenerf_hip.h, snerf_mlp_pack) out of a state dict."""
+    names = []
+    i = 0
+    while f'{prefix}pts_linears.{i}.weight' in params:
+        names += [f'pts_linears.{i}.weight', f'pts_linears.{i}.bias']
+        i += 1
+    names += ['pts_output_linear.weight', 'pts_output_linear.bias']
+    if f'{prefix}feature_linear.weight' in params:
+        names += ['feature_linear.weight', 'feature_linear.bias', 'views_linears.0.weight', 'views_linears.0.bias',
+                  'views_output_linear.weight', 'views_output_linear.bias']
+    return [params[prefix + n] for n in names]

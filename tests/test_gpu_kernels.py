@@ -82,17 +82,7 @@ def test_coarse_depths_ragged_sizes_match_oracle(steps):
 LAYOUTS = {'main': {}, 'ptsaug': dict(sigma_pe_degree=3), 'viewsaug': dict(use_view_dirs=False, view_dependent_rgb=False)}
 
 
-def abi_param_list(params: dict, prefix: str = ''):
-    names = []
-    i = 0
-    while f'{prefix}pts_linears.{i}.weight' in params:
-        names += [f'pts_linears.{i}.weight', f'pts_linears.{i}.bias']
-        i += 1
-    names += ['pts_output_linear.weight', 'pts_output_linear.bias']
-    if f'{prefix}feature_linear.weight' in params:
-        names += ['feature_linear.weight', 'feature_linear.bias', 'views_linears.0.weight', 'views_linears.0.bias',
-                  'views_output_linear.weight', 'views_output_linear.bias']
-    return [params[prefix + n] for n in names]
+abi_param_list = synth.abi_param_list
 
 
 @pytest.mark.parametrize('layout', ['main', 'ptsaug', 'viewsaug'])

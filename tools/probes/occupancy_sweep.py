@@ -5,7 +5,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from simplenerf_amd import ops, synth
 from tests import util
-from tests.test_gpu_kernels import abi_param_list
+from simplenerf_amd.synth import abi_param_list
 prec = int(sys.argv[1])
 cfg = synth.mlp_config(128)
 sd = synth.synth_state_dict(util.mlp_param_shapes(cfg), 1)

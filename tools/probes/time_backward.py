@@ -7,7 +7,7 @@ from simplenerf_amd import _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from simplenerf_amd import ops, synth
 from tests import util
-from tests.test_gpu_kernels import abi_param_list
+from simplenerf_amd.synth import abi_param_list
 prec = int(sys.argv[2])
 cfg = synth.mlp_config(128)
 sd = synth.synth_state_dict(util.mlp_param_shapes(cfg), 1)
