@@ -28,7 +28,8 @@ enum snerf_status {
     SNERF_E_HIP = -3          /* HIP runtime error (message carries hipGetErrorString) */
 };
 
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature change (new enum values such as SNERF_PRECISION_F16 extend a
+ * version without changing it: older callers never pass them). */
 #define SNERF_ABI_VERSION 4
 int snerf_abi_version(void);
 const char* snerf_last_error(void);
