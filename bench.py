@@ -116,7 +116,8 @@ def train_bench(args, rank, world, device, dist):
         state['iter'] += 1
         for group in opt.param_groups:
             group['lr'] = decayer.get_updated_learning_rate(it)
-        return harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it), cfg['sub_batch_size'], world)
+        return harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it), cfg['sub_batch_size'], world,
+                                      single_pass=args.single_pass)
 
     def fence():
         if world > 1:
@@ -145,7 +146,7 @@ def train_bench(args, rank, world, device, dist):
             'vs_baseline': None, 'dtype': {'fp32': 'f32', 'f16x3': 'f16x3', 'f16': 'f16 (bf16 layer gradients)'}[args.precision], 'data': 'synthetic',
             'config': {'workload': 'config 5: 2048 pixel + 2048 sparse-depth rows per GPU in two sub-batches, main coarse+fine '
                                    '+ points-aug + views-aug MLPs (64 + 192 samples), nine shipped losses, Adam, NeRF LR decay',
-                       'rows_per_gpu': per_gpu, 'parallelism': f'row-shard x{world}' + (' + 1 gradient all-reduce/step' if world > 1 else '')},
+                       'rows_per_gpu': per_gpu, 'single_pass': bool(args.single_pass), 'parallelism': f'row-shard x{world}' + (' + 1 gradient all-reduce/step' if world > 1 else '')},
             'algorithmic_tflops': flop * world * args.steps / elapsed / 1e12}), flush=True)
 
 
@@ -153,6 +154,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--train', action='store_true',
                     help='measure BASELINE config 5 (training iteration) instead of the headline render metric')
+    ap.add_argument('--single-pass', action='store_true',
+                    help='--train: one model forward/backward over the whole batch, losses still normalised per sub-batch '
+                         '(harness.train_one_iter single_pass)')
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)

@@ -52,14 +52,16 @@ def main():
         lr = decayer.get_updated_learning_rate(it)
         for group in opt.param_groups:
             group['lr'] = lr
-        return harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it), cfg['sub_batch_size'])
+        return harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it), cfg['sub_batch_size'],
+                                      single_pass=os.environ.get('SNERF_SINGLE_PASS') == '1')
 
     n = cfg['data_loader']['num_rays'] + cfg['data_loader']['sparse_depth']['num_rays']
     res = {}
     dt = timed(step, 5)
     fwd_flop = n * (64 * (FLOP['main'] + FLOP['ptsaug'] + FLOP['viewsaug']) + 192 * FLOP['main'])
     res['train_iteration'] = {'ms': dt * 1e3, 'rays_per_s': n / dt, 'algorithmic_tflops': 3 * fwd_flop / dt / 1e12,
-                              'precision': os.environ.get('SNERF_PREC', 'fp32'), 'rows': n}
+                              'precision': os.environ.get('SNERF_PREC', 'fp32'), 'rows': n,
+                              'single_pass': os.environ.get('SNERF_SINGLE_PASS') == '1'}
     totals = step()
     res['loss_values'] = {k: float(v) for k, v in totals.items()}
 
