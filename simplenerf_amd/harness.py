@@ -156,8 +156,12 @@ def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch
         whole = dict(input_batch)
         whole['row_offset'] = base
         output = model(whole)
+        # one split per output tensor: its backward is a single concatenation of the sub-batch gradients (slicing per
+        # sub-batch would zero-fill and add a full-size gradient per slice)
+        pieces = {k: (v.split(sub) if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n else None)
+                  for k, v in output.items()}
         objective = None
-        for start in range(0, n, sub):
+        for index, start in enumerate(range(0, n, sub)):
             piece = {}
             for key, value in input_batch.items():
                 if isinstance(value, torch.Tensor):
@@ -167,8 +171,7 @@ def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch
                 else:
                     piece[key] = value
             piece['row_offset'] = base + start
-            out_piece = {k: (v[start:start + sub] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n else v)
-                         for k, v in output.items()}
+            out_piece = {k: (pieces[k][index] if pieces[k] is not None else v) for k, v in output.items()}
             losses = loss_computer.compute_losses(piece, out_piece)
             objective = losses['TotalLoss'] if objective is None else objective + losses['TotalLoss']
             for name, entry in losses.items():
