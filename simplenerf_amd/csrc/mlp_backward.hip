@@ -177,6 +177,19 @@ __host__ __device__ inline int pe_position_feature(int p, int kind) {
     return snerf::pe_feature(n, h, kind == snerf::SEG_POINTS_PE ? snerf::kPointsPairs : snerf::kViewsPairs, 16);
 }
 
+// Per-region max |dY| words, written by the chain kernels with atomicMax.  kMaxSlots copies of the table, 512 bytes apart,
+// indexed by workgroup: with a single copy every wave of the launch hit the same few cache lines of one L2 channel and the
+// atomics alone cost 5.6 % of the chain kernel.  Readers take the maximum over the copies (one word per lane).
+constexpr int kRegionSlots = 64, kRegionWords = 128;      // 64 x 128 words at workspace floats [448, 448 + 8192)
+constexpr int kRegionTableFloat0 = 448;
+__device__ __forceinline__ float region_max(const float* workspace, int region) {
+    const unsigned w = reinterpret_cast<const unsigned*>(workspace)[kRegionTableFloat0 + (threadIdx.x & (kRegionSlots - 1)) * kRegionWords + region];
+    float v = __uint_as_float(w);     // non-negative floats order like their bits
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 // One power-of-two scale per dY region for the f16x3 weight-gradient product (the contraction runs over the samples, so a
 // per-sample factor cannot be pulled out): max |dY| -> [2^9, 2^10).  Samples whose gradients are < 6e-11 of the largest
 // one underflow the fp16 pair; their contribution is below fp32 rounding of the sum anyway.
@@ -351,7 +364,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
 
     // (read once, before any DMA is in flight: a global load inside the loop makes the compiler wait for vmcnt(0),
     // i.e. for the prefetch of the next block as well)
-    const float gk = F16 ? wgrad_scale(__uint_as_float(reinterpret_cast<const unsigned*>(zeros)[64 + job.dy_row0 / 32])) : 1.0f;
+    const float gk = F16 ? wgrad_scale(region_max(zeros, job.dy_row0 / 32)) : 1.0f;
     if constexpr (F16) {
         // fp16-split product, software-pipelined over the 16-sample k-steps (two per block): the LDS reads and the hi/lo
         // split of step t+1 (~260 VALU instructions) are issued together with the 48 MFMAs of step t, into the other
@@ -579,7 +592,7 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     // 4q+p of the group points at sample row q, feature columns 4p..4p+3 of the piece
     const int grp = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
     const unsigned lane_off = (grp & 1) * kPieceGap + 32 * (8 * (grp >> 1) + q4) + 16 * (p4 & 1) + 8 * (p4 >> 1);
-    const float gk = wgrad_scale(__uint_as_float(reinterpret_cast<const unsigned*>(zeros)[64 + job.dy_row0 / 32]));
+    const float gk = wgrad_scale(region_max(zeros, job.dy_row0 / 32));
 
     // Software pipeline over the 16-sample k-steps (two per block): the transposed reads of step t+1 are issued before the
     // MFMAs of step t, into the other fragment set, so the LDS latency and the bf16->fp16 conversion of the next step run
@@ -696,7 +709,7 @@ __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float
     __shared__ float quarter[4][64];
     const WgradJob& job = table.jobs[blockIdx.y];
     const float unscale =
-        job.half ? 1.0f / wgrad_scale(__uint_as_float(reinterpret_cast<const unsigned*>(partial)[64 + job.dy_row0 / 32])) : 1.0f;
+        job.half ? 1.0f / wgrad_scale(region_max(partial, job.dy_row0 / 32)) : 1.0f;
     float* __restrict__ grad_w = ptrs.p[job.w_param];
     float* __restrict__ grad_b = job.b_param >= 0 ? ptrs.p[job.b_param] : nullptr;
     const int in_cols = job.in_tiles * 32, rows_dy = job.out_tiles * 32;
@@ -768,8 +781,8 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
     Workspace w;
     const long long blocks = (total_samples + 127) / 128 * 4;
     w.grads_floats = blocks * p.grad_rows() * 32;   // (the 16-bit tiles use the first half)
-    long long off = 448;  // [0, 64): zero page for padded rows; [64, 192): per-region max |dY| words (f16x3);
-                          // [192, 448): 1 KiB zero page of the 16-bit weight-gradient kernel
+    long long off = kRegionTableFloat0 + kRegionSlots * kRegionWords;
+    // [0, 64): zero page for padded rows; [192, 448): 1 KiB zero page; [448, 8640): per-region max |dY| words (region_max)
     auto add = [&](int dy_row0, int out_rows, int x_row0, int in_rows, int w_param, int w_ld, int w_col, int b_param,
                    int x_kind = snerf::SEG_ACC) {
         WgradJob j;
@@ -954,13 +967,13 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     a.grad_head = plan.grad_head();
     if (f16) { a.act_rows = plan.act16_rows(); a.grad_rows = plan.grad16_rows(); }
     // partial[0..64): zero page for padded staging rows; partial[64..192): per-region max |dY| (f16x3)
-    hipError_t he = hipMemsetAsync(partial, 0, 448 * sizeof(float), s);
+    hipError_t he = hipMemsetAsync(partial, 0, (kRegionTableFloat0 + kRegionSlots * kRegionWords) * sizeof(float), s);
     if (he != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: memset: %s", hipGetErrorString(he));
     int rc;
     const int key = precision != SNERF_PRECISION_FP32 ? -1 : plan.wt * 10 + plan.vt;
     a.dy_max = nullptr;
     if (precision != SNERF_PRECISION_FP32) {
-        a.dy_max = reinterpret_cast<unsigned*>(partial) + 64;
+        a.dy_max = reinterpret_cast<unsigned*>(partial) + kRegionTableFloat0;
         rc = snerf::mlp_backward_chain_f16x3(plan, a, f16 ? 1 : 3, s);
         if (rc != SNERF_OK) return rc;
     }

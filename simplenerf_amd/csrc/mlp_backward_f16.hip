@@ -127,6 +127,8 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
     const long long block = (long long)blockIdx.x * 4 + wave;
     const long long first = block * 32 + (lane & 31);
     const bool live = first < a.total;
+    // this workgroup's copy of the region-maximum table (64 copies of 128 words, see region_max in mlp_backward.hip)
+    unsigned* const dy_max = a.dy_max ? a.dy_max + (blockIdx.x & 63) * 128 : nullptr;
     // (P = 1: both buffers hold 16-bit rows -- a.act_rows / a.grad_rows count rows of 64 bytes; `grads` is then only
     // ever used through store_dy, with row numbers)
     const unsigned* masks = P == 3
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
     // Per-sample power-of-two scaling (see renorm_factor): `gscale` is the factor currently applied to this sample's
     // gradients inside the chain, `gback` = 1/gscale is applied whenever one of its dY tiles is stored.
     const float head_max = fmaxf(fmaxf(fabsf(dhead[0]), fabsf(dhead[1])), fmaxf(fabsf(dhead[2]), fabsf(dhead[3])));
-    if (a.dy_max) publish_max(a.dy_max + a.grad_head / 32, head_max, lane);   // region scale of the head-weight products
+    if (dy_max) publish_max(dy_max + a.grad_head / 32, head_max, lane);   // region scale of the head-weight products
     float gscale = renorm_factor(head_max);
     if (!(gscale < 1.0e30f)) gscale = 1.0e30f;
     float gback = 1.0f / gscale;
@@ -189,7 +191,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
         apply_relu_masks<VT>(dyvs, masks, a.depth * WT, lane);
         store_dy<P, VT>(dyvs, grads, a.grad_yv, lane, gback);
         st.note_vmem(dy_stores<P>(VT));
-        renormalise<VT>(dyvs, gscale, gback, a.dy_max ? a.dy_max + a.grad_yv / 32 : nullptr, lane);
+        renormalise<VT>(dyvs, gscale, gback, dy_max ? dy_max + a.grad_yv / 32 : nullptr, lane);
 #pragma unroll
         for (int u = 0; u < VT; ++u) split_tile<false>(dyvs[u], vh[2 * u], vl[2 * u], vh[2 * u + 1], vl[2 * u + 1]);
         // d feature = Wv[:, :width]^T dYv
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
             store_dy<P, 1>(one, grads, a.grad_feature + 32 * u, lane, gback);
             st.note_vmem(dy_stores<P>(1));
         }
-        renormalise<WT>(acc, gscale, gback, a.dy_max ? a.dy_max + a.grad_feature / 32 : nullptr, lane);
+        renormalise<WT>(acc, gscale, gback, dy_max ? dy_max + a.grad_feature / 32 : nullptr, lane);
 #pragma unroll
         for (int u = 0; u < WT; ++u) split_tile<false>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
         // d h_depth = W_feature^T dfeature
@@ -246,7 +248,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
         if (l > 0) load_relu_words<WT>(relu_words, masks, (l - 1) * WT, lane);   // in flight during this layer's products
         store_dy<P, WT>(acc, grads, l * a.width, lane, gback);
         st.note_vmem(dy_stores<P>(WT));
-        unsigned* region = a.dy_max ? a.dy_max + (l * a.width) / 32 : nullptr;
+        unsigned* region = dy_max ? dy_max + (l * a.width) / 32 : nullptr;
         if (l == 0) {
             if (region) publish_max(region, tiles_max<WT>(acc) * gback, lane);
             break;
