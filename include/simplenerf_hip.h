@@ -181,6 +181,9 @@ int snerf_resample_depths(const float* depths_coarse, const float* weights_coars
  * Output post-processing (next-row f3).  Replaces post_process_image / post_process_depth
  * (src/data_preprocessors/DataPreprocessor01.py:1106-1114) on the device, so a rendered frame crosses PCIe as uint8.
  *   rgb (n,3) device; depth (n) device or NULL;  image (n,3) uint8 device;  depth_out (n) device or NULL
+ *   image (and rgb) may be NULL to convert a depth column alone (retrieve_inference_outputs :906-918 converts four).
+ * Pinned edge cases (tests/golden/display.npz, made by the reference's functions): colour NaN -> 0, +inf -> 255,
+ * exact .5 ties round to even; depth NaN stays NaN, -0.0 stays -0.0, -inf -> 0.
  */
 int snerf_to_display(const float* rgb, const float* depth, long long num_rays, unsigned char* image, float* depth_out,
                      snerf_stream_t stream);

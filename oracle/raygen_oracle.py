@@ -85,7 +85,20 @@ def full_frame_batch(resolution, intrinsic, pose, near, far, ndc: bool, near_ndc
 
 
 def to_display(rgb: numpy.ndarray, depth: numpy.ndarray):
-    """post_process_image / post_process_depth :1106-1114: clip to [0,1], round(255x) -> uint8; depth clip >= 0."""
-    img = numpy.round(numpy.clip(rgb, 0, 1) * 255).astype('uint8')
+    """post_process_image / post_process_depth :1106-1114: clip to [0,1], round(255x) -> uint8; depth clip >= 0.
+    Pinned by tests/golden/display.npz (the reference's two functions on ties, out-of-range values, infinities, NaN)."""
+    with numpy.errstate(invalid='ignore'):
+        img = numpy.round(numpy.clip(rgb, 0, 1) * 255).astype('uint8')
     dep = numpy.clip(depth, 0, numpy.inf).astype('float32')
     return img, dep
+
+
+def retrieve_inference_outputs(configs: dict, resolution, network_outputs: dict) -> dict:
+    """DataPreprocessor.retrieve_inference_outputs :897-925: of all network outputs keep rgb / depth / depth_var
+    (+ depth_ndc / depth_var_ndc when ndc) of the finest level present, as a display image and clipped depth maps."""
+    h, w = resolution
+    suffix = '_fine' if 'fine_mlp' in configs['model'] else '_coarse'
+    out = {'image': to_display(numpy.asarray(network_outputs[f'rgb{suffix}']).reshape(h, w, 3), numpy.zeros(1))[0]}
+    for name in ['depth', 'depth_var'] + (['depth_ndc', 'depth_var_ndc'] if configs['data_loader']['ndc'] else []):
+        out[name] = to_display(numpy.zeros(3), numpy.asarray(network_outputs[f'{name}{suffix}']).reshape(h, w))[1]
+    return out

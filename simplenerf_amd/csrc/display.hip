@@ -13,12 +13,19 @@ __global__ void __launch_bounds__(256) to_display_kernel(const float* __restrict
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < 3 && image; ++c) {
             float v = rgb[3 * i + c];
-            v = fminf(fmaxf(v, 0.0f), 1.0f);     // numpy.clip; NaN propagates to 0 through the integer cast below
+            // numpy.clip, then round-half-to-even, then the uint8 cast.  NaN: numpy keeps it through clip and round and
+            // its float->uint8 cast yields 0 on x86-64 (pinned by tests/golden/display.npz); fmaxf(NaN, 0) = 0 gives the
+            // same byte here
+            v = fminf(fmaxf(v, 0.0f), 1.0f);
             image[3 * i + c] = (unsigned char)rintf(v * 255.0f);
         }
-        if (depth_out) depth_out[i] = fmaxf(depth[i], 0.0f);
+        if (depth_out) {
+            // numpy.clip(depth, 0, inf): comparisons, not fmaxf -- NaN stays NaN and -0.0 stays -0.0 as in the reference
+            const float d = depth[i];
+            depth_out[i] = d < 0.0f ? 0.0f : d;
+        }
     }
 }
 
@@ -26,7 +33,7 @@ __global__ void __launch_bounds__(256) to_display_kernel(const float* __restrict
 
 extern "C" int snerf_to_display(const float* rgb, const float* depth, long long num_rays, unsigned char* image,
                                 float* depth_out, snerf_stream_t stream) {
-    SNERF_REQUIRE(rgb && image, "to_display: NULL pointer");
+    SNERF_REQUIRE((rgb && image) || (!image && depth_out), "to_display: NULL pointer");
     SNERF_REQUIRE(!depth_out || depth, "to_display: depth_out requested without depth");
     SNERF_REQUIRE(num_rays >= 0, "to_display: negative ray count");
     if (num_rays == 0) return SNERF_OK;

@@ -112,6 +112,46 @@ def to_display(rgb: Tensor, depth: Tensor):
     return ops.to_display(rgb, depth)
 
 
+def retrieve_inference_outputs(configs: dict, resolution, network_outputs: Dict[str, Tensor]) -> dict:
+    """What leaves the device after a frame and in what form: DataPreprocessor.retrieve_inference_outputs
+    (src/data_preprocessors/DataPreprocessor01.py:897-925).  The reference copies EVERY network output to the host
+    (post_process_output, incl. ~1 KB/ray of alpha) and then keeps five of them; here only those five are converted on the
+    device (K: snerf_to_display -- uint8 colour, depths clipped at 0) and copied: 3 + 16 B per pixel.
+
+    Returns numpy arrays under the reference's keys, in its order: ``image`` (h,w,3) uint8, ``depth``, ``depth_var``
+    (h,w) float32 and, for NDC scenes, ``depth_ndc``, ``depth_var_ndc``; the suffix is ``_fine`` when the model has a
+    fine MLP, else ``_coarse`` (:900-905).  (``visibility2`` belongs to predict_visibility, which is not built.)"""
+    h, w = int(resolution[0]), int(resolution[1])
+    if 'fine_mlp' in configs['model']:
+        suffix = '_fine'
+    elif 'coarse_mlp' in configs['model']:
+        suffix = '_coarse'
+    else:
+        raise RuntimeError('retrieve_inference_outputs: the model has neither a fine nor a coarse MLP')
+    image, depth = ops.to_display(network_outputs[f'rgb{suffix}'].reshape(h * w, 3), network_outputs[f'depth{suffix}'].reshape(h * w))
+    out = {'image': image.reshape(h, w, 3), 'depth': depth.reshape(h, w)}
+    names = ['depth_var'] + (['depth_ndc', 'depth_var_ndc'] if configs['data_loader']['ndc'] else [])
+    for name in names:
+        out[name] = ops.to_display(network_outputs[f'rgb{suffix}'].reshape(h * w, 3),
+                                   network_outputs[f'{name}{suffix}'].reshape(h * w), colour=False)[1].reshape(h, w)
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@torch.no_grad()
+def predict_frame(model, configs: dict, camera: dict, device, rank: int = 0, world_size: int = 1,
+                  ray_block: int = 65536) -> Optional[dict]:
+    """NerfTester.predict_frame (src/Tester01.py:57-66): full-frame batch -> model under no_grad -> the five display
+    outputs.  Rays are generated on the device per block; with world_size > 1 each rank renders its block of the frame
+    and rank 0 receives it through one gather (None on the other ranks)."""
+    ndc = bool(configs['data_loader']['ndc'])
+    suffix = '_fine' if 'fine_mlp' in configs['model'] else '_coarse'
+    keys = [f'rgb{suffix}', f'depth{suffix}', f'depth_var{suffix}'] + ([f'depth_ndc{suffix}', f'depth_var_ndc{suffix}'] if ndc else [])
+    frame = render_frame(model, camera, ndc, device, keys, rank, world_size, ray_block)
+    if frame is None:
+        return None
+    return retrieve_inference_outputs(configs, camera['resolution'], frame)
+
+
 def allreduce_gradients(parameters, world_size: int, group=None) -> None:
     """Training with rays sharded over ranks: average every parameter gradient across ranks with ONE collective
     (all gradients flattened into a single buffer: 2 265 488 floats = 9.06 MB for the 4-MLP model).

@@ -305,18 +305,21 @@ def resample_depths(depths_coarse: Tensor, weights_coarse: Tensor, num_fine: int
 
 
 # ---------------------------------------------------------------------------------------------- f3
-def to_display(rgb: Tensor, depth: Optional[Tensor] = None):
-    """-> uint8 image (n,3) [clip to [0,1], round(255 x) half-to-even] and depth clipped at 0 (or None)."""
+def to_display(rgb: Optional[Tensor], depth: Optional[Tensor] = None, colour: bool = True):
+    """-> uint8 image (n,3) [clip to [0,1], round(255 x) half-to-even] and depth clipped at 0 (or None).
+    ``colour=False`` converts only the depth column (image is None)."""
     lib = _lib.load()
-    n = rgb.shape[0]
-    rgb = _dev(rgb, 'rgb', (n, 3))
+    n = rgb.shape[0] if colour else depth.shape[0]
+    rgb = _dev(rgb, 'rgb', (n, 3)) if colour else None
     depth = _dev(depth, 'depth', (n,))
-    image = torch.empty((n, 3), dtype=torch.uint8, device=rgb.device)
-    depth_out = None if depth is None else torch.empty((n,), dtype=torch.float32, device=rgb.device)
+    dev = rgb.device if colour else depth.device
+    image = torch.empty((n, 3), dtype=torch.uint8, device=dev) if colour else None
+    depth_out = None if depth is None else torch.empty((n,), dtype=torch.float32, device=dev)
     if n == 0:
         return image, depth_out
-    with torch.cuda.device(rgb.device):
-        st = lib.snerf_to_display(_ptr(rgb), _ptr(depth), n, ctypes.c_void_p(image.data_ptr()), _ptr(depth_out), _stream())
+    with torch.cuda.device(dev):
+        st = lib.snerf_to_display(_ptr(rgb), _ptr(depth), n, ctypes.c_void_p(0 if image is None else image.data_ptr()),
+                                  _ptr(depth_out), _stream())
     _lib.check(st, 'snerf_to_display')
     return image, depth_out
 

@@ -53,6 +53,7 @@ def make_configs(kind: str, model_name: str = 'SimpleNeRFHip01') -> dict:
     kind:
       'config1'   1024 random rays, 64 coarse samples, 4x128 MLP, non-NDC, no fine MLP
       'config2'   LLFF fern, 64+128, 8x256 coarse+fine, NDC
+      'config4'   the same renderer for the RealEstate-10K full-frame render (camera('re10k'))
       'headline'  128+128, 8x256 coarse+fine, NDC (the metric configuration)
       'config3'   config2 + points-augmentation + views-augmentation coarse MLPs
       'headline_world'  headline but non-NDC (world-space rays)
@@ -71,7 +72,7 @@ def make_configs(kind: str, model_name: str = 'SimpleNeRFHip01') -> dict:
     if kind == 'config1':
         ndc = False
         model['coarse_mlp'] = mlp_config(64, depth=4, width=128, views_width=64)
-    elif kind == 'config2':
+    elif kind in ('config2', 'config4'):      # config 4 = the config-2 renderer on the RealEstate-10K camera
         model['coarse_mlp'] = mlp_config(64)
         model['fine_mlp'] = mlp_config(128)
     elif kind == 'headline':
@@ -161,11 +162,14 @@ def load_cameras() -> dict:
         return json.load(f)
 
 
-def camera(scene: str = 'fern', pose_index: int = 0, downscale: int = 1) -> dict:
+def camera(scene: str = 'fern', pose_index: int = 0, downscale: int = 1, resolution: Optional[tuple] = None) -> dict:
     """Camera metadata for a full-frame render: resolution, intrinsic (3x3), processed pose (4x4), near, far.
 
     Values originate from the reference's saved run metadata (see tests/golden/cameras.json header);
-    ``downscale=2`` halves resolution and intrinsics (BASELINE config 2 names fern at 504x378).
+    ``downscale=2`` halves resolution and intrinsics (BASELINE config 2 names fern at 504x378);
+    ``resolution=(h, w)`` re-targets the camera to another frame size: focal lengths scaled by w / w0, principal point
+    at the new centre (BASELINE config 4 names the RE10K render at 1008x756; the scene's own frames are 1024x576,
+    SURVEY 8d).
     """
     cams = load_cameras()[scene]
     h, w = cams['resolution']
@@ -174,6 +178,13 @@ def camera(scene: str = 'fern', pose_index: int = 0, downscale: int = 1) -> dict
         h, w = h // downscale, w // downscale
         k = k.copy()
         k[:2] /= downscale
+    if resolution is not None:
+        scale = resolution[1] / w
+        h, w = int(resolution[0]), int(resolution[1])
+        k = k.copy()
+        k[0, 0] *= scale
+        k[1, 1] *= scale
+        k[0, 2], k[1, 2] = w / 2, h / 2
     return {
         'resolution': (h, w),
         'intrinsic': k.astype(numpy.float32),

@@ -223,11 +223,13 @@ def test_losses_on_outputs_without_gradient_path_fail_loudly():
         out['depth_var_coarse'].sum().backward()
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3', 'f16'])
 def test_full_size_training_batch_properties(precision):
     """BASELINE config 5 at full size (4096 rays, four MLPs, 64 + 192 samples) through size-independent properties:
     the gradient of a sum-type loss over the whole batch equals the accumulated gradients of its two 2048-ray halves
-    (the reference's sub-batching), doubles when the loss doubles, and is bit-reproducible run to run."""
+    (the reference's sub-batching), doubles when the loss doubles, and is bit-reproducible run to run.  The 16-bit mode
+    ('f16', the mode BASELINE config 5 names) quantises layer gradients with one power-of-two scale per region of the
+    launch, so halves and whole agree to its own tolerance (2 %) instead of 1e-4; doubling is exact in every mode."""
     from simplenerf_amd import harness
     cfg = synth.with_overrides(synth.make_configs('config3'), perturb=False, raw_noise_std=0.0, hip_precision=precision)
     model = get_model(cfg, None)
@@ -254,4 +256,4 @@ def test_full_size_training_batch_properties(precision):
     assert all(torch.isfinite(g).all() and float(g.abs().max()) > 0 for g in whole)
     for a, b, c, d in zip(whole, again, halves, double):
         assert torch.equal(a, b)                                              # fixed-order reductions
-        assert rel_to_max(c, a) < 1e-4 and rel_to_max(d, 2 * a) < 1e-5
+        assert rel_to_max(c, a) < (2e-2 if precision == 'f16' else 1e-4) and rel_to_max(d, 2 * a) < 1e-5

@@ -103,7 +103,7 @@ def check_outputs(out, ref, strict_fine, tag=''):
 
 
 EVAL_CASES = [(k, p) for k in ('config1', 'config2', 'headline', 'headline_world') for p in ('plain', 'dense', 'consistent')
-              if not (k == 'config1' and p == 'consistent')]
+              if not (k == 'config1' and p == 'consistent')] + [('config4', 'dense'), ('config4', 'consistent')]
 
 
 @pytest.mark.parametrize('kind,profile', EVAL_CASES)
@@ -162,7 +162,7 @@ def test_train_forward_with_fine_augmentation_mlps_matches_reference(precision):
 
 
 @pytest.mark.parametrize('kind,profile', [('config2', 'dense'), ('headline', 'dense'), ('headline_world', 'dense'),
-                                          ('config2', 'plain')])
+                                          ('config2', 'plain'), ('config4', 'dense')])
 def test_fine_pass_on_reference_samples(kind, profile):
     """Intervention: give the fine MLP + compositing kernels the REFERENCE's fine depths (skipping only the
     rounding-sensitive resampling) -- every ray must then match at the full tolerance, for independent fields too."""
@@ -348,3 +348,58 @@ def test_full_size_frame_properties_and_eight_way_shards():
     other = harness.render_frame(fast, cam, True, DEV, keys=('rgb_fine',))['rgb_fine']
     off = ((other - whole).abs().max(1)[0] > 1e-4).float().mean()
     assert float(off) < 0.01, float(off)
+
+
+@pytest.mark.parametrize('resolution', [None, (756, 1008)], ids=['native1024x576', 'named1008x756'])
+def test_config4_re10k_full_frame_properties_and_eight_way_shards(resolution):
+    """BASELINE config 4 at full size: the RealEstate-10K camera (runs/training/train0011/00000/ModelConfigs.json: f = 493.9,
+    near 1, far 133.3) at its own 1024 x 576 = 589 824 rays and at the 1008 x 756 = 762 048 rays BASELINE names, 64+128
+    samples, 8x256 coarse+fine, with the weights of the config-4 golden.  Size-independent properties on every block;
+    the golden's own pixels re-rendered inside the full frame reproduce the fixture (native size: same camera); the
+    union of the eight per-rank ray ranges is bit-identical to the unsharded frame, and so is the display conversion
+    of the gathered frame (harness.predict_frame's single-rank path)."""
+    from simplenerf_amd import harness
+    cfg = synth.make_configs('config4')
+    g = util.load('e2e_config4_consistent.npz')
+    model = build(cfg, g).eval()
+    cam = synth.camera('re10k', 0, resolution=resolution)
+    h, w = cam['resolution']
+    n = h * w
+    assert n == (589824 if resolution is None else 762048)
+    keys = ('rgb_fine', 'depth_fine', 'depth_var_fine', 'depth_ndc_fine', 'depth_var_ndc_fine')
+    blocks = {k: [] for k in keys}
+    with torch.no_grad():
+        for start in range(0, n, 65536):
+            count = min(65536, n - start)
+            out = model(harness.frame_batch(cam, True, DEV, start, count), retraw=True)
+            zc, zf, wf, acc, rgb = out['z_vals_coarse'], out['z_vals_fine'], out['weights_fine'], out['acc_fine'], out['rgb_fine']
+            assert zc.shape == (count, 64) and zf.shape == (count, 192)
+            assert bool((zf[:, 1:] >= zf[:, :-1]).all()) and float(zf.min()) >= 0.0 and float(zf.max()) <= 1.0
+            pos = torch.searchsorted(zf, zc.contiguous()).clamp(max=191)
+            assert torch.equal(torch.gather(zf, 1, pos), zc)
+            assert float(wf.min()) >= 0.0 and float((wf.sum(1) - acc).abs().max()) <= 1e-5 and float(acc.max()) <= 1.0 + 1e-5
+            assert float(rgb.min()) >= 0.0 and bool((rgb <= acc[:, None] + 1e-5).all())
+            assert float(out['depth_ndc_fine'].min()) >= 0.0 and float(out['depth_ndc_fine'].max()) <= 1.0 + 1e-5
+            assert float(out['depth_fine'][acc > 0.5].min()) > 0.0           # world depth: in front of the camera
+            assert all(torch.isfinite(v).all() for v in out.values())
+            for k in keys:
+                blocks[k].append(out[k])
+    whole = {k: torch.cat(v) for k, v in blocks.items()}
+    if resolution is None:
+        pix = torch.from_numpy(g['pixel_indices']).to(DEV)
+        assert util.linf(whole['rgb_fine'][pix], g['out_rgb_fine']) <= RGB_TOL
+        assert util.linf(whole['depth_ndc_fine'][pix], g['out_depth_ndc_fine']) <= DEPTH_TOL
+    shards = [harness.render_rays_blockwise(model, cam, True, DEV, *harness.shard_range(n, r, 8), keys=keys) for r in range(8)]
+    assert [s['rgb_fine'].shape[0] for s in shards] == [n // 8] * 8
+    for k in keys:
+        assert torch.equal(torch.cat([s[k] for s in shards]), whole[k]), k
+    frame = harness.predict_frame(model, cfg, cam, DEV)
+    assert list(frame) == ['image', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc']
+    assert frame['image'].shape == (h, w, 3) and frame['image'].dtype == numpy.uint8
+    ref_img, ref_depth = oracle_display(whole['rgb_fine'].cpu().numpy(), whole['depth_fine'].cpu().numpy())
+    assert numpy.array_equal(frame['image'].reshape(-1, 3), ref_img) and numpy.array_equal(frame['depth'].reshape(-1), ref_depth)
+
+
+def oracle_display(rgb, depth):
+    from oracle import raygen_oracle
+    return raygen_oracle.to_display(rgb, depth)

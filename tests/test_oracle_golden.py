@@ -315,3 +315,42 @@ def test_draw_statistics():
     assert 0.0 <= u.min() and u.max() < 1.0
     assert stats.kstest(u, 'uniform').pvalue > 1e-3 and stats.kstest(z, 'norm').pvalue > 1e-3
     assert numpy.array_equal(batch_oracle.random_uniform(9, 4, 100, 50, 63), u.reshape(4096, 63)[100:150])   # row-keyed
+
+
+# ---------------------------------------------------------------- config 4 (RealEstate-10K camera) end to end
+@pytest.mark.parametrize('profile', ['dense', 'consistent'])
+def test_render_config4_re10k_matches_reference(profile):
+    """BASELINE config 4: the RE10K camera (1024x576, f = 493.9, near 1, far 133.3) through the 64+128 NDC renderer."""
+    g = util.load(f'e2e_config4_{profile}.npz')
+    cfg = synth.make_configs('config4')
+    out = oracle.render(util.golden_params(cfg, g), cfg, util.golden_batch(g), training=False, retraw=True)
+    ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
+    assert sorted(out.keys()) == sorted(ref.keys())
+    for k, v in ref.items():
+        assert util.rel_linf(out[k], v) < 2e-5, k
+    assert float(ref['depth_fine'].max()) > 20.0        # the far RE10K geometry is in the fixture
+
+
+# ---------------------------------------------------------------- f3 display conversion + which outputs leave the device
+def same_bits(a, b):
+    a, b = numpy.ascontiguousarray(a), numpy.ascontiguousarray(b)
+    return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def test_display_oracle_matches_reference_post_processing():
+    g = util.load('display.npz')
+    image, depth = raygen_oracle.to_display(g['rgb'], g['depth'])
+    assert same_bits(image, g['image']) and same_bits(depth, g['depth_out'])      # incl. NaN payloads and the sign of -0.0
+    assert g['image'][520].tolist() == [255, 0, 0] and numpy.isnan(g['depth_out'][4]) and numpy.signbit(g['depth_out'][1])
+
+
+@pytest.mark.parametrize('case,kind,ndc', [('fine_ndc', 'config2', True), ('coarse_world', 'config1', False)])
+def test_inference_outputs_oracle_matches_reference(case, kind, ndc):
+    g = util.load('inference_outputs.npz')
+    cfg = synth.make_configs(kind)
+    assert cfg['data_loader']['ndc'] == ndc
+    net = {k[len(case) + 5:]: v for k, v in g.items() if k.startswith(f'{case}_net_')}
+    out = raygen_oracle.retrieve_inference_outputs(cfg, (12, 20), net)
+    assert list(out.keys()) == g[f'{case}_keys'].tolist()
+    for k, v in out.items():
+        assert same_bits(v, g[f'{case}_out_{k}']), k

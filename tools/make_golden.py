@@ -117,6 +117,12 @@ def make_cameras():
     return cams
 
 
+def cams_from_disk():
+    """cameras.json as make_cameras() wrote it (for generators that add fixtures without re-making the others)."""
+    with open(os.path.join(OUT, 'cameras.json')) as f:
+        return json.load(f)
+
+
 def make_raygen(cams):
     for scene in ('fern', 're10k'):
         mc = {k: cams[scene][k] for k in ('resolution', 'intrinsic', 'near', 'far', 'near_ndc', 'far_ndc',

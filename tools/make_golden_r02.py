@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Round-2 golden vectors, made by RUNNING THE REFERENCE in the build container (same rules as tools/make_golden.py:
+the reference is imported read-only from /root/reference/src, inputs/weights come from simplenerf_amd/synth.py).
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tools/make_golden_r02.py
+
+Fixtures written:
+    e2e_config4_<profile>.npz   G6 for BASELINE config 4: the RealEstate-10K camera of
+                                runs/training/train0011/00000/ModelConfigs.json (1024x576, f = 493.9, near 1, far 133.3)
+                                through SimpleNeRF.forward (eval, NDC, 64+128, 8x256 coarse+fine), 128 rays
+    display.npz                 f3: DataPreprocessor.post_process_image / post_process_depth
+                                (src/data_preprocessors/DataPreprocessor01.py:1106-1114) on seeded arrays with exact .5
+                                ties, negatives, values > 1, +-inf and NaN
+    inference_outputs.npz       f3: DataPreprocessor.retrieve_inference_outputs (:897-925) on a seeded network-output
+                                dictionary of a small frame: which outputs leave the device and in what form
+"""
+import os
+import sys
+import warnings
+
+import numpy
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_golden as base  # noqa: E402  (imports the reference, stubs skimage)
+from make_golden import DataPreprocessor, cams_from_disk, save, synth  # noqa: E402
+
+
+def re10k_batch(pixel_seed, n, cams, pose_index=0):
+    mc = {k: cams['re10k'][k] for k in ('resolution', 'intrinsic', 'near', 'far', 'near_ndc', 'far_ndc',
+                                        'average_pose', 'translation_scale')}
+    pp = base.preprocessor(mc)
+    batch = pp.create_test_data(numpy.array(cams['re10k']['raw_poses'][pose_index]), preprocess_pose=True)
+    h, w = mc['resolution']
+    pix = numpy.sort(numpy.random.RandomState(pixel_seed).choice(h * w, n, replace=False))
+    pix[0], pix[-1] = 0, h * w - 1          # the two frame corners: largest |x|, |y| of the NDC warp
+    return {k: v[pix].contiguous() for k, v in batch.items()}, pix
+
+
+def make_config4(cams):
+    n = 128
+    for profile in ('dense', 'consistent'):
+        cfg = synth.make_configs('config2')
+        model = base.ref_model(cfg, 107, training=False)
+        batch, pix = re10k_batch(53, n, cams)
+        overrides = base.calibrate_density(model, batch, train_mode=False)
+        if profile == 'consistent':
+            overrides = {k: v for k, v in overrides.items() if not k.startswith('ovr_fine_model')}
+            overrides.update(base.tie_fine_to_coarse(model))
+        with torch.no_grad():
+            out = model(batch, retraw=True)
+            out_plain = model(batch)
+        assert all(torch.equal(out[k], out_plain[k]) for k in out_plain)
+        arrays = {'seed': 107, 'pixel_indices': pix, 'eval_keys': numpy.array(sorted(out_plain.keys()))}
+        arrays.update(overrides)
+        arrays.update({f'in_{k}': v for k, v in batch.items()})
+        arrays.update({f'out_{k}': v for k, v in out.items()})
+        save(f'e2e_config4_{profile}.npz', **arrays)
+        print('   acc_coarse mean %.3f  acc_fine mean %.3f  depth_fine max %.1f' % (
+            out['acc_coarse'].mean(), out['acc_fine'].mean(), out['depth_fine'].max()))
+
+
+def display_inputs():
+    rng = numpy.random.RandomState(4)
+    n = 4096
+    rgb = rng.uniform(-0.2, 1.2, (n, 3)).astype(numpy.float32)
+    rgb[:512] = (numpy.arange(512 * 3).reshape(512, 3) % 511 + 0.5).astype(numpy.float32) / 255   # x*255 lands on k + 0.5
+    rgb[512:520] = numpy.array([0.0, -0.0, 1.0, 1.0000001, -1e-30, 0.5, 0.0019607844, 0.99803925], dtype=numpy.float32)[:, None]
+    rgb[520] = [numpy.inf, -numpy.inf, numpy.nan]
+    rgb[521] = [numpy.nan, 0.25, 2.0]
+    depth = rng.uniform(-1, 6, n).astype(numpy.float32)
+    depth[:6] = [0.0, -0.0, numpy.inf, -numpy.inf, numpy.nan, -1e-38]
+    return rgb, depth
+
+
+def make_display():
+    rgb, depth = display_inputs()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')         # NaN -> uint8 cast warns; the value numpy produces is what we record
+        image = DataPreprocessor.post_process_image(rgb)
+    depth_out = DataPreprocessor.post_process_depth(depth)
+    save('display.npz', rgb=rgb, depth=depth, image=image, depth_out=depth_out)
+    print('   NaN colour ->', image[520, 2], image[521, 0], ' NaN depth ->', depth_out[4], ' -inf depth ->', depth_out[3])
+
+
+def make_inference_outputs(cams):
+    """retrieve_inference_outputs on seeded per-ray outputs of a 12 x 20 frame, for a coarse+fine NDC config, a
+    coarse-only world config, and the fine NDC config again with extra per-sample keys present (they must be dropped)."""
+    arrays = {}
+    for case, kind, ndc in (('fine_ndc', 'config2', True), ('coarse_world', 'config1', False)):
+        h, w = 12, 20
+        mc = {k: cams['fern'][k] for k in ('intrinsic', 'near', 'far', 'near_ndc', 'far_ndc', 'average_pose', 'translation_scale')}
+        mc['resolution'] = [h, w]
+        pp = base.preprocessor(mc, ndc=ndc)
+        pp.configs['model'] = synth.make_configs(kind)['model']
+        rng = numpy.random.RandomState(17)
+        net = {}
+        for level in (('coarse', 'fine') if kind == 'config2' else ('coarse',)):
+            net[f'rgb_{level}'] = rng.uniform(-0.1, 1.1, (h * w, 3)).astype(numpy.float32)
+            for k in ('depth', 'depth_var') + (('depth_ndc', 'depth_var_ndc') if ndc else ()):
+                net[f'{k}_{level}'] = rng.uniform(-0.5, 5.0, h * w).astype(numpy.float32)
+            net[f'acc_{level}'] = rng.uniform(0, 1, h * w).astype(numpy.float32)
+            net[f'alpha_{level}'] = rng.uniform(0, 1, (h * w, 8)).astype(numpy.float32)
+        out = pp.retrieve_inference_outputs({k: torch.from_numpy(v) for k, v in net.items()})
+        arrays[f'{case}_keys'] = numpy.array(list(out.keys()))
+        for k, v in net.items():
+            arrays[f'{case}_net_{k}'] = v
+        for k, v in out.items():
+            arrays[f'{case}_out_{k}'] = v
+    save('inference_outputs.npz', **arrays)
+
+
+if __name__ == '__main__':
+    cams = cams_from_disk()
+    make_config4(cams)
+    make_display()
+    make_inference_outputs(cams)
