@@ -2,8 +2,12 @@
 """Headline benchmark: rays/sec of the ray-marching hot path (coarse+fine, 128+128 samples, 8x256 MLPs).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]            (--train: BASELINE config 5 instead, see train_bench)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-        bench.py --gpus N --steps K --warmup W
+
+``--gpus N`` with N > 1 needs no wrapper: when no launcher has set WORLD_SIZE, bench.py starts N fresh rank processes
+itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment) BEFORE anything in
+this process touches the GPU, relays rank 0's JSON line and exits with the ranks' status.  Under
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N``
+the launcher's environment is used as it is.  One rank per GPU, RCCL (torch.distributed backend "nccl") between them.
 
 One "step" = one pass of the whole hot path over one batch of 1024 rays per GPU: on-device ray generation for the
 rank's pixel block of a fern frame, coarse depths, coarse MLP, compositing, inverse-CDF resampling + merge, fine MLP,
@@ -16,11 +20,19 @@ Printed JSON (rank 0, one line) also carries
                 inside the timed region / their HIP-event durations, against 157.3 TFLOP/s (MI355X_MICROARCH.md)
   cpu_baseline  the oracle (torch CPU fp32 restatement of the reference path, reference chunking) timed on this
                 host on the same 1024-ray batch, best of 5 after one warm-up
+  collective    (N > 1) backend and number of ranks torch.distributed reports
+  also_measured*        the same step in the other two arithmetic modes (N = 1)
+  also_measured_train   BASELINE config 5 (the reference's training iteration, 4096 rows per GPU) in fp32 and in the
+                        16-bit mode: ms per iteration, algorithmic TFLOP/s, fraction of the matching MFMA peak
+  sustained     the headline step repeated for ~1 s of device time (the K timed steps alone are ~65 ms)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy
@@ -29,18 +41,73 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from simplenerf_amd import harness, ops, synth  # noqa: E402
-from simplenerf_amd.models.ModelFactory import get_model  # noqa: E402
+# (simplenerf_amd is imported inside the rank-side functions: the self-launching parent must not load the HIP library)
 
 RAYS_PER_GPU = 1024
 FLOP_PER_SAMPLE = 2 * 593408          # main 8x256 MLP, Linear layers only
+TRAIN_FLOP_PER_RAY = (64 * 2 * (593408 + 577280 + 492032) + 192 * 2 * 593408) * 3   # config 5: forward x3 (dgrad + wgrad)
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_FP16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
 WORKLOAD = ('headline: 1024 rays/GPU x (128 coarse + 128 fine -> 256 merged) samples, 8x256 coarse+fine MLPs, '
             'LLFF fern NDC rays, eval')
 
 
+def launch_ranks(num_ranks: int) -> int:
+    """Self-launch for ``--gpus N`` without a launcher: N child processes, one per GPU, each a fresh interpreter running
+    this file with the rank environment set.  The parent never initialises the GPU (no HIP call, no library load) and
+    never exec()s: it waits, forwards rank 0's output and returns the worst exit status.  If a rank dies the others are
+    stopped (they would wait in the rendezvous forever)."""
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs, logs = [], []
+    for rank in range(num_ranks):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(num_ranks), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        log = tempfile.TemporaryFile(mode='w+')
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=log,
+                                      stderr=None if rank == 0 else subprocess.STDOUT))
+    codes = [None] * num_ranks
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()          # our own children, by handle
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+            break
+        time.sleep(0.05)
+    failed = [i for i, c in enumerate(codes) if c != 0]
+    for i, log in enumerate(logs):
+        log.seek(0)
+        text = log.read()
+        if i == 0:
+            sys.stdout.write(text)
+        elif i in failed and text.strip():
+            sys.stderr.write(f'[rank {i}] ' + text[-4000:] + '\n')
+        log.close()
+    sys.stdout.flush()
+    return 0 if not failed else next(c for c in codes if c != 0)
+
+
+def _pkg():
+    from simplenerf_amd import harness, ops, synth
+    from simplenerf_amd.models.ModelFactory import get_model
+    return harness, ops, synth, get_model
+
+
 def synthetic_model(configs, seed, device, precision='fp32'):
+    _, _, synth, get_model = _pkg()
     configs = synth.with_overrides(configs, hip_precision=precision)
     model = get_model(configs, None)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -57,9 +124,11 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(configs, camera, first_ray):
-    """Oracle on the host CPU, same rays and weights as the GPU step; bounded: 1 warm-up + 5 runs of 1024 rays."""
+def cpu_baseline(configs, camera, first_ray, runs=9):
+    """Oracle on the host CPU, same rays and weights as the GPU step; bounded: 1 warm-up + ``runs`` passes over the 1024
+    rays (~10 s of CPU work on 16 cores)."""
     from oracle import nerf_oracle, raygen_oracle
+    _, _, synth, get_model = _pkg()
     cores = host_cores()
     torch.set_num_threads(cores)
     shapes = {k: tuple(v.shape) for k, v in get_model(configs, None).state_dict().items()}
@@ -67,17 +136,18 @@ def cpu_baseline(configs, camera, first_ray):
     full = raygen_oracle.full_frame_batch(camera['resolution'], camera['intrinsic'], camera['pose'], camera['near'],
                                           camera['far'], True, camera['near_ndc'], camera['far_ndc'])
     batch = {k: torch.from_numpy(numpy.ascontiguousarray(v[first_ray:first_ray + RAYS_PER_GPU])) for k, v in full.items()}
-    best = float('inf')
+    times = []
     with torch.no_grad():
-        for i in range(6):
+        for i in range(runs + 1):
             t0 = time.perf_counter()
             nerf_oracle.render(params, configs, batch, training=False)
-            dt = time.perf_counter() - t0
             if i > 0:
-                best = min(best, dt)
+                times.append(time.perf_counter() - t0)
+    best = min(times)
     return {'value': RAYS_PER_GPU / best, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{RAYS_PER_GPU} rays of the same workload, best of 5 after 1 warm-up ({best:.3f} s each), '
-                      f'torch {torch.__version__} CPU fp32, chunk 4096 / netchunk 16384'}
+            'sample': f'{RAYS_PER_GPU} rays of the same workload, best of {runs} after 1 warm-up ({best:.3f} s best, '
+                      f'{sum(times) / len(times):.3f} s mean; {sum(times):.1f} s of CPU work), torch {torch.__version__} CPU fp32, '
+                      f'chunk 4096 / netchunk 16384'}
 
 
 def pmc_traffic(precision):
@@ -89,17 +159,19 @@ def pmc_traffic(precision):
     return None
 
 
-def train_bench(args, rank, world, device, dist):
-    """--train: BASELINE config 5 instead of the headline metric.  One step = the reference's training iteration
-    (Trainer.train_one_iter) with every stage on the device: batch assembly (2048 pixel + 2048 sparse-depth rows per GPU,
+# ---------------------------------------------------------------------------------------------- config 5 (training)
+def training_step(precision, rank, world, device, single_pass=False):
+    """BASELINE config 5: a callable running ONE iteration of the reference's training loop (Trainer.train_one_iter,
+    src/Trainer01.py:60-107) with every stage on the device: batch assembly (2048 pixel + 2048 sparse-depth rows per GPU,
     each rank a slice of one global index stream), four MLPs forward, nine losses, backward, ONE all-reduce of the
     flattened gradients (RCCL) for N > 1, Adam with the decayed rate.  Weak scaling: 4096 rows per GPU."""
+    harness, _, synth, get_model = _pkg()
     from simplenerf_amd import optim
     from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
     from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
     from simplenerf_amd.lr_decayers.LearningRateDecayerFactory import get_lr_decayer
     rows = 2048
-    cfg = synth.training_configs(args.precision, num_rays=rows * world, num_sparse=rows * world)
+    cfg = synth.training_configs(precision, num_rays=rows * world, num_sparse=rows * world)
     model = get_model(cfg, None)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
@@ -117,7 +189,55 @@ def train_bench(args, rank, world, device, dist):
         for group in opt.param_groups:
             group['lr'] = decayer.get_updated_learning_rate(it)
         return harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it), cfg['sub_batch_size'], world,
-                                      single_pass=args.single_pass)
+                                      single_pass=single_pass)
+
+    return step, 2 * rows
+
+
+TRAIN_WORKLOAD = ('config 5: 2048 pixel + 2048 sparse-depth rows per GPU in two sub-batches, main coarse+fine + points-aug + '
+                  'views-aug MLPs (64 + 192 samples), nine shipped losses, Adam, NeRF LR decay')
+TRAIN_DTYPE = {'fp32': 'f32', 'f16x3': 'f16x3', 'f16': 'f16 (bf16 layer gradients)'}
+
+
+def time_training(precision, device, steps, warmup, single_pass=False):
+    """Config 5 on one GPU: (ms per iteration, ms of MLP forward launches, ms of MLP backward calls) from ``steps`` timed
+    iterations after ``warmup``."""
+    _, ops, _, _ = _pkg()
+    step, rows = training_step(precision, 0, 1, device, single_pass)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ops.PackedMlp.event_log, ops.PackedMlp.backward_event_log = [], []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fwd, ops.PackedMlp.event_log = ops.PackedMlp.event_log, None
+    bwd, ops.PackedMlp.backward_event_log = ops.PackedMlp.backward_event_log, None
+    return elapsed / steps * 1e3, sum(a.elapsed_time(b) for a, b, _ in fwd) / steps, sum(a.elapsed_time(b) for a, b, _ in bwd) / steps, rows
+
+
+def training_record(device, steps=10, warmup=3):
+    """The ``also_measured_train`` object of the default bench line: config 5 at 4096 rows on this GPU in the fp32 mode
+    (the reference's arithmetic) and the 16-bit mode BASELINE config 5 names, each against its own MFMA peak."""
+    dominant = {'fp32': 'wgrad_kernel<2,8,false> (weight gradients); forward mlp_forward_kernel<8,4,true,false,true>',
+                'f16': 'wgrad16_kernel<2,8> (weight gradients, HBM-bound); chain mlp_backward_chain_f16x3_kernel<8,4,true,1>'}
+    out = {'workload': TRAIN_WORKLOAD, 'rows_per_gpu': 4096, 'steps': steps, 'warmup': warmup, 'modes': {}}
+    for precision, peak in (('fp32', PEAK_FP32_MFMA_TFLOPS), ('f16', PEAK_FP16_MFMA_TFLOPS)):
+        ms, fwd_ms, bwd_ms, rows = time_training(precision, device, steps, warmup)
+        tflops = rows * TRAIN_FLOP_PER_RAY / (ms * 1e-3) / 1e12
+        out['modes'][precision] = {
+            'dtype': TRAIN_DTYPE[precision], 'ms_per_step': ms, 'value': rows / (ms * 1e-3), 'unit': 'rays/s',
+            'algorithmic_tflops': tflops, 'peak_tflops': peak, 'frac_of_peak': tflops / peak,
+            'mlp_forward_ms_per_step': fwd_ms, 'mlp_backward_ms_per_step': bwd_ms,
+            'mlp_share_of_step': (fwd_ms + bwd_ms) / ms, 'dominant_kernels': dominant[precision]}
+    return out
+
+
+def train_bench(args, rank, world, device, dist):
+    """--train: BASELINE config 5 instead of the headline metric (see training_step)."""
+    step, per_gpu = training_step(args.precision, rank, world, device, args.single_pass)
 
     def fence():
         if world > 1:
@@ -137,19 +257,59 @@ def train_bench(args, rank, world, device, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        per_gpu = 2 * rows
-        flop = per_gpu * (64 * 2 * (593408 + 577280 + 492032) + 192 * 2 * 593408) * 3      # forward x3 (dgrad + wgrad)
-        print(json.dumps({
+        line = {
             'metric': 'training rays/sec (config 5: forward + backward + optimiser, 4 MLPs, 9 losses)',
             'value': per_gpu * world * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': {'fp32': 'f32', 'f16x3': 'f16x3', 'f16': 'f16 (bf16 layer gradients)'}[args.precision], 'data': 'synthetic',
-            'config': {'workload': 'config 5: 2048 pixel + 2048 sparse-depth rows per GPU in two sub-batches, main coarse+fine '
-                                   '+ points-aug + views-aug MLPs (64 + 192 samples), nine shipped losses, Adam, NeRF LR decay',
-                       'rows_per_gpu': per_gpu, 'single_pass': bool(args.single_pass), 'parallelism': f'row-shard x{world}' + (' + 1 gradient all-reduce/step' if world > 1 else '')},
-            'algorithmic_tflops': flop * world * args.steps / elapsed / 1e12}), flush=True)
+            'vs_baseline': None, 'dtype': TRAIN_DTYPE[args.precision], 'data': 'synthetic',
+            'config': {'workload': TRAIN_WORKLOAD, 'rows_per_gpu': per_gpu, 'single_pass': bool(args.single_pass),
+                       'parallelism': f'row-shard x{world}' + (' + 1 gradient all-reduce/step' if world > 1 else '')},
+            'algorithmic_tflops': per_gpu * TRAIN_FLOP_PER_RAY * world * args.steps / elapsed / 1e12}
+        if world > 1:
+            line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size()}
+        print(json.dumps(line), flush=True)
 
 
+# ---------------------------------------------------------------------------------------------- stand-in (tests only)
+def standin_bench(args, rank, world, dist):
+    """SNERF_BENCH_STANDIN=1 (tests/test_dist_gloo.py only): the launcher, rendezvous, per-rank block, gather, barrier,
+    max-over-ranks timing and JSON line of the render bench with the renderer replaced by a CPU stand-in, so that the
+    N > 1 path is exercised without GPUs.  The line says so (``"data": "stand-in"``); it is not a measurement."""
+    from simplenerf_amd import harness
+    first = rank * RAYS_PER_GPU
+
+    def step():
+        idx = torch.arange(first, first + RAYS_PER_GPU, dtype=torch.float32)
+        local = {'rgb_fine': torch.stack([idx, 2 * idx, 3 * idx], 1), 'depth_fine': idx + 0.5}
+        return harness.gather_rays(local, world * RAYS_PER_GPU, rank, world) if world > 1 else local
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ref = torch.arange(world * RAYS_PER_GPU, dtype=torch.float32)
+        assert torch.equal(full['depth_fine'], ref + 0.5) and torch.equal(full['rgb_fine'][:, 2], 3 * ref)
+        line = {'metric': 'rays/sec (coarse+fine, 128+128 samples)', 'value': world * RAYS_PER_GPU * args.steps / elapsed,
+                'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                'dtype': 'none', 'data': 'stand-in', 'config': {'workload': 'launcher rehearsal, no renderer'}}
+        if world > 1:
+            line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size()}
+        print(json.dumps(line), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------- headline
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--train', action='store_true',
@@ -161,42 +321,56 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-alt', action='store_true', help='skip the secondary f16x3 / f16 measurements')
+    ap.add_argument('--no-alt', action='store_true', help='skip the secondary measurements (other precisions, training, sustained)')
     ap.add_argument('--precision', choices=('fp32', 'f16x3', 'f16'), default='fp32',
                     help="arithmetic of the fused MLP kernel: fp32 MFMA; fp16 hi/lo split with 3 MFMAs per product "
                          "(fp32-grade results, same parity tests); or f16 = one fp16 MFMA per product with 16-bit saved "
                          "tensors (BASELINE config 5's 16-bit training mode, own tolerances: tests/test_gpu_f16.py)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))       # nothing above this line touches the GPU
+
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the HIP renderer has no CPU path')
-    local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+        raise SystemExit(f'--gpus {args.gpus} but the launcher set WORLD_SIZE={world}')
+    standin = os.environ.get('SNERF_BENCH_STANDIN') == '1'
     dist = None
+    device = None
+    if not standin:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X: the HIP renderer has no CPU path')
+        local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # RCCL ('nccl') on a multi-GPU node; SNERF_DIST_BACKEND=gloo lets the same code path be rehearsed with several
-        # ranks sharing one GPU (RCCL refuses two ranks on one device)
+        # ranks sharing one GPU (RCCL refuses two ranks on one device) or, with the stand-in step, on the CPU
         backend = os.environ.get('SNERF_DIST_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    if args.train:
-        train_bench(args, rank, world, device, dist)
+    try:
+        if standin:
+            standin_bench(args, rank, world, dist)
+        elif args.train:
+            train_bench(args, rank, world, device, dist)
+        else:
+            render_bench(args, rank, world, device, dist)
+    finally:
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
-        return
 
+
+def render_bench(args, rank, world, device, dist):
+    harness, ops, synth, _ = _pkg()
     configs = synth.make_configs('headline')
     camera = synth.camera('fern', 0)
     h, w = camera['resolution']
@@ -234,78 +408,88 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if rank != 0:
+        return
 
-    if rank == 0:
-        kernel_ms = sum(a.elapsed_time(b) for a, b, _ in log)
-        kernel_flop = sum(n for _, _, n in log) * FLOP_PER_SAMPLE
-        achieved = kernel_flop / (kernel_ms * 1e-3) / 1e12
-        if args.precision == 'fp32':
-            peak, dtype, kernel_name = PEAK_FP32_MFMA_TFLOPS, 'f32', 'mlp_forward_kernel<8,4,true,false,false>'
-            note = 'fp32 MFMA: one pass per algorithmic FLOP'
-        elif args.precision == 'f16x3':
-            peak, dtype, kernel_name = PEAK_FP16_MFMA_TFLOPS, 'f16x3 (fp16 hi/lo split, fp32 accumulate)', \
-                'mlp_forward_f16x3_kernel<8,4,true,false,false,3>'
-            note = ('achieved counts ALGORITHMIC FLOPs; the kernel issues 3 fp16 MFMA passes per product, so its ceiling is '
-                    'peak/3 = 833 TFLOP/s and MFMA-pipe utilisation = 3 x frac')
-        else:
-            peak, dtype, kernel_name = PEAK_FP16_MFMA_TFLOPS, 'f16 (fp16 MFMA, fp32 accumulate)', \
-                'mlp_forward_f16x3_kernel<8,4,true,false,false,1>'
-            note = 'one fp16 MFMA pass per product; NOT within the fp32 parity bar (sigma ~1e-3 relative)'
+    kernel_ms = sum(a.elapsed_time(b) for a, b, _ in log)
+    kernel_flop = sum(n for _, _, n in log) * FLOP_PER_SAMPLE
+    achieved = kernel_flop / (kernel_ms * 1e-3) / 1e12
+    if args.precision == 'fp32':
+        peak, dtype, kernel_name = PEAK_FP32_MFMA_TFLOPS, 'f32', 'mlp_forward_kernel<8,4,true,false,false>'
+        note = 'fp32 MFMA: one pass per algorithmic FLOP'
+    elif args.precision == 'f16x3':
+        peak, dtype, kernel_name = PEAK_FP16_MFMA_TFLOPS, 'f16x3 (fp16 hi/lo split, fp32 accumulate)', \
+            'mlp_forward_f16x3_kernel<8,4,true,false,false,3>'
+        note = ('achieved counts ALGORITHMIC FLOPs; the kernel issues 3 fp16 MFMA passes per product, so its ceiling is '
+                'peak/3 = 833 TFLOP/s and MFMA-pipe utilisation = 3 x frac')
+    else:
+        peak, dtype, kernel_name = PEAK_FP16_MFMA_TFLOPS, 'f16 (fp16 MFMA, fp32 accumulate)', \
+            'mlp_forward_f16x3_kernel<8,4,true,false,false,1>'
+        note = 'one fp16 MFMA pass per product; NOT within the fp32 parity bar (sigma ~1e-3 relative)'
 
-        result = {
-            'metric': 'rays/sec (coarse+fine, 128+128 samples)',
-            'value': world * RAYS_PER_GPU * args.steps / elapsed,
-            'unit': 'rays/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': dtype, 'data': 'synthetic',
-            'config': {'workload': WORKLOAD, 'rays_per_gpu': RAYS_PER_GPU, 'samples': '128+128',
-                       'parallelism': f'ray-shard x{world}' + (' + 1 gather/step' if world > 1 else '')},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': pmc_traffic(args.precision),
-                         'kernel': kernel_name, 'note': note, 'launches': len(log),
-                         'avg_launch_ms': kernel_ms / max(1, len(log)),
-                         'kernel_share_of_step': kernel_ms / (elapsed * 1e3)},
-        }
-        if world == 1 and args.precision == 'fp32' and not args.no_alt:
-            # the same step with the other two arithmetic modes of the fused MLP kernel, as secondary measurements
-            def measure(precision):
-                alt_model = synthetic_model(configs, 7, device, precision)
-                with torch.no_grad():
-                    for _ in range(args.warmup):
-                        alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
-                    torch.cuda.synchronize()
-                    ops.PackedMlp.event_log = []
-                    t0 = time.perf_counter()
-                    for _ in range(args.steps):
-                        alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
-                    torch.cuda.synchronize()
-                    alt_elapsed = time.perf_counter() - t0
-                alt_log, ops.PackedMlp.event_log = ops.PackedMlp.event_log, None
-                alt_ms = sum(a.elapsed_time(b) for a, b, _ in alt_log)
-                alt_tf = sum(n for _, _, n in alt_log) * FLOP_PER_SAMPLE / (alt_ms * 1e-3) / 1e12
-                return alt_elapsed, alt_tf
-
-            alt_elapsed, alt_tf = measure('f16x3')
-            result['also_measured'] = {
-                'precision': 'f16x3 (fp16 hi/lo split, 3 MFMA passes per product, fp32 accumulate; same parity tests)',
-                'value': RAYS_PER_GPU * args.steps / alt_elapsed, 'unit': 'rays/s', 'ms_per_step': alt_elapsed / args.steps * 1e3,
-                'roofline': {'bound': 'mfma', 'achieved': alt_tf, 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                             'frac': alt_tf / PEAK_FP16_MFMA_TFLOPS, 'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false,false,3>'}}
-            alt_elapsed, alt_tf = measure('f16')
-            result['also_measured_16bit'] = {
-                'precision': 'f16 (one fp16 MFMA pass per product, fp32 accumulate; OUTSIDE the fp32 parity bar -- colour ~1e-4, '
-                             'depth ~6e-4 from the fp32 path, tests/test_gpu_f16.py; BASELINE config 5 names this mode for training)',
-                'value': RAYS_PER_GPU * args.steps / alt_elapsed, 'unit': 'rays/s', 'ms_per_step': alt_elapsed / args.steps * 1e3,
-                'roofline': {'bound': 'mfma', 'achieved': alt_tf, 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                             'frac': alt_tf / PEAK_FP16_MFMA_TFLOPS, 'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false,false,1>'}}
-        if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(configs, camera, first)
-        print(json.dumps(result), flush=True)
+    result = {
+        'metric': 'rays/sec (coarse+fine, 128+128 samples)',
+        'value': world * RAYS_PER_GPU * args.steps / elapsed,
+        'unit': 'rays/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': dtype, 'data': 'synthetic',
+        'config': {'workload': WORKLOAD, 'rays_per_gpu': RAYS_PER_GPU, 'samples': '128+128',
+                   'parallelism': f'ray-shard x{world}' + (' + 1 gather/step' if world > 1 else '')},
+        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                     'frac': achieved / peak, 'traffic': pmc_traffic(args.precision),
+                     'kernel': kernel_name, 'note': note, 'launches': len(log),
+                     'avg_launch_ms': kernel_ms / max(1, len(log)),
+                     'kernel_share_of_step': kernel_ms / (elapsed * 1e3)},
+    }
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        result['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
+                                'pattern': 'one gather of (rgb, depth) = 16 B/ray to rank 0 per step'}
+    if world == 1 and args.precision == 'fp32' and not args.no_alt:
+        # the same step with the other two arithmetic modes of the fused MLP kernel, as secondary measurements
+        def measure(precision, steps):
+            alt_model = model if precision == 'fp32' else synthetic_model(configs, 7, device, precision)
+            with torch.no_grad():
+                for _ in range(args.warmup):
+                    alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
+                torch.cuda.synchronize()
+                ops.PackedMlp.event_log = []
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
+                torch.cuda.synchronize()
+                alt_elapsed = time.perf_counter() - t0
+            alt_log, ops.PackedMlp.event_log = ops.PackedMlp.event_log, None
+            alt_ms = sum(a.elapsed_time(b) for a, b, _ in alt_log)
+            alt_tf = sum(n for _, _, n in alt_log) * FLOP_PER_SAMPLE / (alt_ms * 1e-3) / 1e12
+            return alt_elapsed, alt_tf
+
+        sustained_steps = 300       # ~1 s of device time: long enough for the clocks to settle under the load
+        s_elapsed, s_tf = measure('fp32', sustained_steps)
+        result['sustained'] = {'steps': sustained_steps, 'value': RAYS_PER_GPU * sustained_steps / s_elapsed, 'unit': 'rays/s',
+                               'ms_per_step': s_elapsed / sustained_steps * 1e3, 'achieved': s_tf,
+                               'frac': s_tf / PEAK_FP32_MFMA_TFLOPS, 'timed_region_s': s_elapsed}
+        alt_elapsed, alt_tf = measure('f16x3', args.steps)
+        result['also_measured'] = {
+            'precision': 'f16x3 (fp16 hi/lo split, 3 MFMA passes per product, fp32 accumulate; same parity tests)',
+            'value': RAYS_PER_GPU * args.steps / alt_elapsed, 'unit': 'rays/s', 'ms_per_step': alt_elapsed / args.steps * 1e3,
+            'roofline': {'bound': 'mfma', 'achieved': alt_tf, 'peak': PEAK_FP16_MFMA_TFLOPS / 3, 'unit': 'TFLOP/s',
+                         'frac': alt_tf / (PEAK_FP16_MFMA_TFLOPS / 3), 'frac_of_fp16_peak': alt_tf / PEAK_FP16_MFMA_TFLOPS,
+                         'note': 'peak = fp16 dense MFMA peak / 3: the kernel issues three fp16 MFMA passes per algorithmic '
+                                 'product, achieved counts algorithmic FLOPs',
+                         'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false,false,3>'}}
+        alt_elapsed, alt_tf = measure('f16', args.steps)
+        result['also_measured_16bit'] = {
+            'precision': 'f16 (one fp16 MFMA pass per product, fp32 accumulate; OUTSIDE the fp32 parity bar -- colour ~1e-4, '
+                         'depth ~6e-4 from the fp32 path, tests/test_gpu_f16.py; BASELINE config 5 names this mode for training)',
+            'value': RAYS_PER_GPU * args.steps / alt_elapsed, 'unit': 'rays/s', 'ms_per_step': alt_elapsed / args.steps * 1e3,
+            'roofline': {'bound': 'mfma', 'achieved': alt_tf, 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': alt_tf / PEAK_FP16_MFMA_TFLOPS, 'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false,false,1>'}}
+        result['also_measured_train'] = training_record(device)
+    if world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(configs, camera, first)
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == '__main__':

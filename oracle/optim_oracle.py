@@ -53,8 +53,9 @@ def mipnerf_learning_rate(lr_initial: float, lr_final: float, num_iterations: in
                           lr_decay_mult: float, iter_num: int) -> float:
     """MipNeRFLearningRateDecayer.get_updated_learning_rate (src/lr_decayers/MipNeRFLearningRateDecayer01.py:26-35):
     log-linear interpolation from lr_initial to lr_final with a sine warm-up factor."""
+    # numpy's exp / sin / log, as the reference: they differ from libm's by 1 ulp on ~4 % of iterations
     warm = 1.0
     if lr_decay_steps > 0:
-        warm = lr_decay_mult + (1 - lr_decay_mult) * math.sin(0.5 * math.pi * min(max(iter_num / lr_decay_steps, 0), 1))
-    t = min(max(iter_num / num_iterations, 0), 1)
-    return warm * math.exp(math.log(lr_initial) * (1 - t) + math.log(lr_final) * t)
+        warm = lr_decay_mult + (1 - lr_decay_mult) * numpy.sin(0.5 * numpy.pi * numpy.clip(iter_num / lr_decay_steps, 0, 1))
+    t = numpy.clip(iter_num / num_iterations, 0, 1)
+    return float(warm * numpy.exp(numpy.log(lr_initial) * (1 - t) + numpy.log(lr_final) * t))

@@ -874,13 +874,9 @@ int launch_chain(const ChainArgs& a, hipStream_t stream) {
     const long long blocks = (a.total + 127) / 128;
     const size_t lds_bytes = 2 * sizeof(float) * SlabStream<WT>::kBufFloats;
     auto kernel = mlp_backward_chain_kernel<WT, VT, VIEWDEP>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes);
-        if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
-    }
+    static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
+    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)lds_bytes, "mlp_backward");
+    if (attr != SNERF_OK) return attr;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a);
     return snerf::check_launch("mlp_backward(chain)");
 }
@@ -895,13 +891,9 @@ int launch_wgrad(const JobTable& table, const float* grads, const float* acts, f
     }
     const size_t lds_bytes = 2 * sizeof(float) * 32 * (size_t)max_rows;  // double-buffered [rows][32 samples]
     auto kernel = wgrad_kernel<NO, NI, F16>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           2 * 4 * 32 * 512);
-        if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
-    }
+    static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
+    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), 2 * 4 * 32 * 512, "mlp_backward");
+    if (attr != SNERF_OK) return attr;
     hipLaunchKernelGGL(kernel, dim3((unsigned)table.wg_start[table.count]), dim3(256), lds_bytes, stream, table, grads, acts,
                        partial, zeros);
     return snerf::check_launch("mlp_backward(wgrad)");
@@ -915,13 +907,9 @@ int launch_wgrad16(const JobTable& table, const float* grads, const float* acts,
     for (int j = 0; j < table.count; ++j) max_tiles = std::max(max_tiles, table.jobs[j].out_tiles + table.jobs[j].in_tiles);
     const size_t lds_bytes = (size_t)kWgrad16Buffers * max_tiles * kPairBytes;
     auto kernel = wgrad16_kernel<NO, NI>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           kWgrad16Buffers * 16 * kPairBytes);
-        if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
-    }
+    static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
+    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), kWgrad16Buffers * 16 * kPairBytes, "mlp_backward");
+    if (attr != SNERF_OK) return attr;
     hipLaunchKernelGGL(kernel, dim3((unsigned)table.wg_start[table.count]), dim3(256), lds_bytes, stream, table,
                        reinterpret_cast<const unsigned short*>(grads), reinterpret_cast<const unsigned short*>(acts), partial,
                        partial);
@@ -955,6 +943,12 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     if ((total + 127) / 128 > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many samples");
     hipStream_t s = (hipStream_t)stream;
     const Workspace ws = plan_workspace(plan, total, f16);
+    // every limit is checked BEFORE anything is enqueued: the chain kernel publishes one maximum per 32-row dY region
+    // into a kRegionWords-word slot, and the reduction's job table holds kMaxJobs entries
+    if ((int)ws.jobs.size() > kMaxJobs) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many weight-gradient jobs");
+    if (plan.grad_head() / 32 + 1 > kRegionWords)
+        return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: %d gradient regions exceed the region-maximum table (%d)",
+                           plan.grad_head() / 32 + 1, kRegionWords);
     float* grads = workspace;
     float* partial = workspace + ws.grads_floats;
 
@@ -966,7 +960,8 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     a.grad_rows = plan.grad_rows(); a.grad_feature = plan.grad_feature(); a.grad_yv = plan.grad_yv();
     a.grad_head = plan.grad_head();
     if (f16) { a.act_rows = plan.act16_rows(); a.grad_rows = plan.grad16_rows(); }
-    // partial[0..64): zero page for padded staging rows; partial[64..192): per-region max |dY| (f16x3)
+    // partial[0, 64): zero page for padded staging rows; [192, 448): 1 KiB zero page; [448, 448 + 64 x 128): the region
+    // maxima |dY| of the f16 modes, in 64 copies (kRegionSlots) of kRegionWords words, indexed by workgroup
     hipError_t he = hipMemsetAsync(partial, 0, (kRegionTableFloat0 + kRegionSlots * kRegionWords) * sizeof(float), s);
     if (he != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: memset: %s", hipGetErrorString(he));
     int rc;
@@ -987,7 +982,6 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
                                     plan.views_width);
     }
     if (rc != SNERF_OK) return rc;
-    if ((int)ws.jobs.size() > kMaxJobs) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many weight-gradient jobs");
     // f16x3: the large products (8 in-tiles wide) run on the fp16 pipe with one power-of-two scale per dY region; the
     // small head/encoding products are DMA-bound and stay on the fp32 kernel
     std::vector<WgradJob> jobs = ws.jobs;

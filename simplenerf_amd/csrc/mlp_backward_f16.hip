@@ -272,13 +272,9 @@ int launch_chain_half(const HalfChainArgs& args, hipStream_t stream) {
     const long long blocks = (args.c.total + 127) / 128;
     const size_t lds_bytes = sizeof(float) * (kUnitBuffers * (size_t)args.slot_floats + 1024);  // ring + DMA dump area
     auto kernel = mlp_backward_chain_f16x3_kernel<WT, VT, VIEWDEP, P>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024)));
-        if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
-    }
+    static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
+    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024)), "mlp_backward");
+    if (attr != SNERF_OK) return attr;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, args);
     return snerf::check_launch("mlp_backward(chain, f16x3)");
 }

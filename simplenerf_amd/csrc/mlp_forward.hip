@@ -155,13 +155,9 @@ int launch(const MlpArgs& a, hipStream_t stream) {
     if (blocks > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: too many samples in one call");
     const size_t lds_bytes = sizeof(float) * (2 * SlabStream<WT>::kBufFloats + (size_t)a.const_floats);
     auto kernel = mlp_forward_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE>;
-    static bool configured = false;  // raising the dynamic-LDS cap is idempotent; racing threads only repeat it
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(sizeof(float) * (2 * SlabStream<WT>::kBufFloats + kMaxConstFloats)));
-        if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
-    }
+    static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
+    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (2 * SlabStream<WT>::kBufFloats + kMaxConstFloats)), "mlp_forward");
+    if (attr != SNERF_OK) return attr;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a);
     return snerf::check_launch("mlp_forward");
 }

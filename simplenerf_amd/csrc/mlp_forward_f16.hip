@@ -232,13 +232,9 @@ int launch_half(const HalfArgs& args, hipStream_t stream) {
     if (blocks > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: too many samples in one call");
     const size_t lds_bytes = sizeof(float) * (kUnitBuffers * (size_t)args.slot_floats + 1024 + (size_t)args.const_floats);
     auto kernel = mlp_forward_f16x3_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE, P>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024 + 5120)));
-        if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_forward: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
-    }
+    static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
+    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024 + 5120)), "mlp_forward");
+    if (attr != SNERF_OK) return attr;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, args);
     return snerf::check_launch("mlp_forward(f16x3)");
 }

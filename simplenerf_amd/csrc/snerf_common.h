@@ -6,6 +6,7 @@
 #include <cstdio>
 
 #include "../../include/simplenerf_hip.h"
+#include "device_once.h"
 
 namespace snerf {
 
@@ -23,6 +24,18 @@ inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SNERF_E_HIP, "%s: %s", what, hipGetErrorString(e));
     return SNERF_OK;
+}
+
+// Raise a kernel's dynamic-LDS cap on the CURRENT device, once per device and launch site (device_once.h).
+inline int raise_dynamic_lds(DeviceOnce& once, const void* kernel, int bytes, const char* what) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return fail(SNERF_E_HIP, "%s: hipGetDevice: %s", what, hipGetErrorString(e));
+    return once.run(device, [&]() -> int {
+        hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (err != hipSuccess) return fail(SNERF_E_HIP, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(err));
+        return SNERF_OK;
+    });
 }
 
 // Grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8 blocks, never more than the work.

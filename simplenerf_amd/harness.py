@@ -12,6 +12,7 @@ from typing import Dict, Iterable, Optional, Tuple
 import torch
 
 from . import ops
+from .models.SimpleNeRFHip01 import row_segments, slice_row_segments
 
 Tensor = torch.Tensor
 DEFAULT_KEYS = ('rgb_fine', 'depth_fine', 'depth_var_fine')
@@ -58,13 +59,13 @@ def render_rays_blockwise(model, camera: dict, ndc: bool, device, first_ray: int
     """Render a ray range in blocks (bounding the per-sample buffers), keeping only ``keys``."""
     keys = tuple(keys)
     pieces = {k: [] for k in keys}
-    for start in range(first_ray, first_ray + num_rays, ray_block):
+    # a rank that owns no rays (ceil-division shards of a tiny frame) still runs one zero-ray call, so that its
+    # outputs have the right trailing shapes for the gather
+    for start in (range(first_ray, first_ray + num_rays, ray_block) if num_rays > 0 else (first_ray,)):
         count = min(ray_block, first_ray + num_rays - start)
         out = model(frame_batch(camera, ndc, device, start, count))
         for k in keys:
             pieces[k].append(out[k])
-    if num_rays == 0:
-        return {k: torch.empty((0,), device=device) for k in keys}
     return {k: torch.cat(v, 0) for k, v in pieces.items()}
 
 
@@ -75,7 +76,8 @@ def gather_rays(local: Dict[str, Tensor], num_rays: int, rank: int, world_size: 
     import torch.distributed as dist
     per = -(-num_rays // world_size)
     keys = sorted(local)
-    cols = [local[k].reshape(local[k].shape[0], -1) for k in keys]
+    # (rows, width) view of each key; a zero-row tensor keeps its trailing shape (reshape(0, -1) is ambiguous)
+    cols = [local[k].reshape(local[k].shape[0], int(torch.Size(local[k].shape[1:]).numel())) for k in keys]
     widths = [c.shape[1] for c in cols]
     packed = torch.cat(cols, 1) if cols else torch.empty((0, 0))
     pad = torch.zeros((per, packed.shape[1]), dtype=packed.dtype, device=packed.device)
@@ -160,16 +162,22 @@ def allreduce_gradients(parameters, world_size: int, group=None) -> None:
     if world_size == 1:
         return
     import torch.distributed as dist
-    params = [p for p in parameters if p.grad is not None]
+    # EVERY trainable parameter takes part, zeros standing in for a missing gradient: a rank whose shard of a short last
+    # batch is empty (or whose loss terms skipped an MLP) must still flatten the same layout as its peers
+    params = [p for p in parameters if p.requires_grad]
     if not params:
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(world_size)
     offset = 0
     for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[offset:offset + n].view_as(p.grad))
+        n = p.numel()
+        piece = flat[offset:offset + n].view_as(p)
+        if p.grad is None:
+            p.grad = piece.clone()
+        else:
+            p.grad.copy_(piece)
         offset += n
 
 
@@ -191,10 +199,11 @@ def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch
     n = input_batch['rays_o'].shape[0]
     sub = int(sub_batch_size or n)
     totals: Dict[str, Tensor] = {}
-    base = int(input_batch.get('row_offset', 0))
+    # global rows of this rank's rows (keys of the training draws): one offset, or the assembler's segment list when a
+    # rank holds a pixel-ray shard followed by a sparse-depth shard of the global batch
+    segments = row_segments(input_batch, n)
     if single_pass and sub < n:
         whole = dict(input_batch)
-        whole['row_offset'] = base
         output = model(whole)
         # one split per output tensor: its backward is a single concatenation of the sub-batch gradients (slicing per
         # sub-batch would zero-fill and add a full-size gradient per slice)
@@ -210,7 +219,7 @@ def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch
                     piece[key] = dict(value)
                 else:
                     piece[key] = value
-            piece['row_offset'] = base + start
+            piece['row_segments'] = slice_row_segments(segments, start, min(sub, n - start))
             out_piece = {k: (pieces[k][index] if pieces[k] is not None else v) for k, v in output.items()}
             losses = loss_computer.compute_losses(piece, out_piece)
             objective = losses['TotalLoss'] if objective is None else objective + losses['TotalLoss']
@@ -231,7 +240,8 @@ def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch
                 piece[key] = dict(value)
             else:
                 piece[key] = value
-        piece['row_offset'] = base + start
+        piece['row_segments'] = slice_row_segments(segments, start, min(sub, n - start))
+        piece['row_offset'] = piece['row_segments'][0][2]
         losses = loss_computer.compute_losses(piece, model(piece))
         losses['TotalLoss'].backward()
         for name, entry in losses.items():
@@ -307,7 +317,7 @@ class GraphedTrainStep:
             for p in self.model.parameters():
                 if p.grad is not None:
                     p.grad.zero_()
-            self.model.set_random_draws(self.model.draw_training_randomness(rows, int(batch.get('row_offset', 0)), self.device))
+            self.model.set_random_draws(self.model.draw_training_randomness(rows, row_segments(batch, rows), self.device))
             piece = dict(batch)
             piece['common_data'] = dict(batch.get('common_data', {}))
             losses = self.losses.compute_losses(piece, self.model(piece))
@@ -316,9 +326,9 @@ class GraphedTrainStep:
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
                 self.static[k].copy_(v)
-            elif k != 'common_data':
+            elif k not in ('common_data', 'row_segments', 'row_offset'):    # rows only key the draws, made outside the graph
                 self.static[k] = v
-        self.model.draw_training_randomness(self.n, int(batch.get('row_offset', 0)), self.device, out=self.draws)
+        self.model.draw_training_randomness(self.n, row_segments(batch, self.n), self.device, out=self.draws)
         key = self._weights(batch['iter_num'])
         if self.graph is None or key != self.weights_key:
             self._capture()                    # records the work (on these inputs); nothing is computed until the replay

@@ -1,17 +1,15 @@
 """Learning-rate schedules of the reference's trainer, evaluated on the host in double precision once per iteration
 (the value is written into ``optimizer.param_groups[..]['lr']``, src/Trainer01.py:293-295).
 
-Both follow the arithmetic of the reference's classes operation for operation, so the rates are the same doubles
-(pinned by tests/golden/optim_adam.npz):
+Both follow the arithmetic of the reference's classes operation for operation -- including WHICH library evaluates the
+transcendental functions (the reference's log-linear schedule uses numpy's exp / sin / log, which differ from libm's by
+1 ulp on ~4 % of iterations) -- so the rates are the same doubles (pinned by tests/golden/optim_adam.npz and, densely,
+tests/golden/lr_schedules.npz):
   ExponentialDecay  -- src/lr_decayers/NeRFLearningRateDecayer01.py:15-24
   LogLinearDecay    -- src/lr_decayers/MipNeRFLearningRateDecayer01.py:16-35
 Each is constructed from the experiment dictionary and exposes ``get_updated_learning_rate(iter_num)``.
 """
-import math
-
-
-def _unit_clip(x: float) -> float:
-    return 0.0 if x < 0 else (1.0 if x > 1 else x)
+import numpy
 
 
 class ExponentialDecay:
@@ -34,13 +32,13 @@ class LogLinearDecay:
     def __init__(self, configs: dict):
         opt = configs['optimizer']
         self.configs = configs
-        self.log_start, self.log_end = math.log(opt['lr_initial']), math.log(opt['lr_final'])
+        self.log_start, self.log_end = numpy.log(opt['lr_initial']), numpy.log(opt['lr_final'])
         self.horizon = configs['num_iterations']
         self.warm_steps, self.warm_floor = opt['lr_decay_steps'], opt['lr_decay_mult']
 
     def get_updated_learning_rate(self, iter_num):
         warm = 1.0
         if self.warm_steps > 0:
-            warm = self.warm_floor + (1 - self.warm_floor) * math.sin(0.5 * math.pi * _unit_clip(iter_num / self.warm_steps))
-        t = _unit_clip(iter_num / self.horizon)
-        return warm * math.exp(self.log_start * (1 - t) + self.log_end * t)
+            warm = self.warm_floor + (1 - self.warm_floor) * numpy.sin(0.5 * numpy.pi * numpy.clip(iter_num / self.warm_steps, 0, 1))
+        t = numpy.clip(iter_num / self.horizon, 0, 1)
+        return float(warm * numpy.exp(self.log_start * (1 - t) + self.log_end * t))

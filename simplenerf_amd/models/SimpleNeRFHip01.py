@@ -19,9 +19,12 @@ Differences from the reference that a caller can observe:
   * training-mode randomness (stratified jitter, inverse-CDF ``u``, density noise) is drawn on the device by the
     library's counter-based Philox4x32-10 (snerf_random_uniform / snerf_random_normal) instead of on the CPU
     generator: element (ray, sample) of a draw is a function of (``configs['seed']``, number of training forwards so
-    far, kind of draw, ``input_batch['row_offset']`` + ray, sample) only, so a rank that renders rows
-    [row_offset, row_offset+n) of a batch draws what a single process would for those rows.  ``set_random_draws``
-    injects explicit draws (used by the parity tests to replay the reference's CPU stream);
+    far, kind of draw, GLOBAL row of the ray, sample) only, so a rank that holds a part of a batch draws what a single
+    process would for those rows.  The global rows come from ``input_batch['row_offset']`` (rows are
+    [row_offset, row_offset+n)) or, when a rank's rows are not contiguous in the global batch -- a pixel-ray shard
+    followed by a sparse-depth shard, as ``BatchAssembler`` produces -- from ``input_batch['row_segments']``, a list of
+    (first local row, count, first global row).  ``set_random_draws`` injects explicit draws (used by the parity tests
+    to replay the reference's CPU stream);
   * ``predict_visibility`` (off in every shipped config) is not built;
   * gradients flow from ``rgb_*``, ``acc_*``, ``depth_*``, ``depth_ndc_*`` (incl. the augmentation-prefixed ones) and
     ``raw_sigma_*`` / ``raw_rgb*_*`` to the parameters -- a superset of what the shipped losses read (SURVEY 8a row
@@ -41,6 +44,50 @@ Tensor = torch.Tensor
 _SKIP_AFTER = 4  # reference: self.skips = [4]
 _DRAW_KINDS = ('t_rand', 'u', 'noise_coarse', 'noise_points_augmentation', 'noise_views_augmentation', 'noise_fine',
                'noise_points_augmentation_fine', 'noise_views_augmentation_fine')
+
+
+def row_segments(batch: dict, n: int) -> List[tuple]:
+    """[(first local row, count, first global row)] covering rows 0..n of ``batch``: its ``row_segments`` entry if
+    present, else one segment at ``row_offset`` (default 0).  Adjacent segments that are contiguous globally are merged."""
+    segs = batch.get('row_segments')
+    if segs is None:
+        return [(0, n, int(batch.get('row_offset', 0)))]
+    out: List[tuple] = []
+    pos = 0
+    for first, count, glob in segs:
+        first, count, glob = int(first), int(count), int(glob)
+        if first != pos or count < 0:
+            raise RuntimeError(f'row_segments must tile the batch rows in order, got {list(segs)} for {n} rows')
+        pos += count
+        if count == 0:
+            continue
+        if out and out[-1][2] + out[-1][1] == glob:
+            out[-1] = (out[-1][0], out[-1][1] + count, out[-1][2])
+        else:
+            out.append((first, count, glob))
+    if pos != n:
+        raise RuntimeError(f'row_segments cover {pos} rows, the batch has {n}')
+    return out or [(0, 0, 0)]
+
+
+def slice_row_segments(segments: List[tuple], start: int, count: int) -> List[tuple]:
+    """Segments of the sub-batch made of local rows [start, start+count)."""
+    out = []
+    for first, cnt, glob in segments:
+        lo, hi = max(first, start), min(first + cnt, start + count)
+        if hi > lo:
+            out.append((lo - start, hi - lo, glob + lo - first))
+    return out or [(0, 0, 0)]
+
+
+def _draw_segments(fn, segments, shape, device, out, *args):
+    """One keyed draw of ``shape`` whose rows follow ``segments``: a launch per segment into that segment's row block."""
+    if len(segments) == 1:
+        return fn(*args[:2], segments[0][2], shape, device, *args[2:], out=out)
+    target = out if out is not None else torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    for first, count, glob in segments:
+        fn(*args[:2], glob, (count,) + tuple(shape[1:]), device, *args[2:], out=target[first:first + count])
+    return target
 
 
 class MlpParameters(torch.nn.Module):
@@ -207,21 +254,23 @@ class SimpleNeRFHip(torch.nn.Module):
                         shapes[f'noise_{prefix[:-1]}_fine'] = (n, s_c + s_f, 1)
         return shapes
 
-    def draw_training_randomness(self, n: int, row_offset: int, device, out: Optional[Dict[str, Tensor]] = None
+    def draw_training_randomness(self, n: int, row_offset, device, out: Optional[Dict[str, Tensor]] = None
                                  ) -> Dict[str, Tensor]:
         """The draws the next training-mode forward would make itself, produced up front (and counted as that forward's):
-        pass the result to ``set_random_draws``.  ``out`` supplies pre-allocated tensors to fill (static graph inputs)."""
+        pass the result to ``set_random_draws``.  ``row_offset``: the first global row (int) or a ``row_segments`` list.
+        ``out`` supplies pre-allocated tensors to fill (static graph inputs)."""
         call = self._train_calls
         self._train_calls += 1
         noise_std = float(self.configs['model']['raw_noise_std'])
+        segments = row_segments({'row_segments': row_offset}, n) if isinstance(row_offset, (list, tuple)) else [(0, n, int(row_offset))]
         draws = {}
         for key, shape in self.training_draw_shapes(n).items():
             stream = call * len(_DRAW_KINDS) + _DRAW_KINDS.index(key)
             target = None if out is None else out[key]
             if key.startswith('noise'):
-                draws[key] = ops.random_normal(self.seed, stream, row_offset, shape, device, noise_std, out=target)
+                draws[key] = _draw_segments(ops.random_normal, segments, shape, device, target, self.seed, stream, noise_std)
             else:
-                draws[key] = ops.random_uniform(self.seed, stream, row_offset, shape, device, out=target)
+                draws[key] = _draw_segments(ops.random_uniform, segments, shape, device, target, self.seed, stream)
         return draws
 
     def _packed_mlp(self, name: str) -> ops.PackedMlp:
@@ -261,7 +310,7 @@ class SimpleNeRFHip(torch.nn.Module):
         noise_std = float(mcfg['raw_noise_std'])
         perturb = bool(mcfg['perturb'] > 0.) and training
 
-        row_offset = int(batch.get('row_offset', 0))
+        segments = row_segments(batch, n) if training else None
         call = self._train_calls
         if training and draws is None:
             self._train_calls += 1
@@ -274,8 +323,9 @@ class SimpleNeRFHip(torch.nn.Module):
                 return None if t is None else t.to(dev)
             stream = call * len(_DRAW_KINDS) + _DRAW_KINDS.index(key)
             if normal:
-                return ops.random_normal(self.seed, stream, row_offset, shape, dev, noise_std) if noise_std > 0. else None
-            return ops.random_uniform(self.seed, stream, row_offset, shape, dev) if perturb else None
+                return _draw_segments(ops.random_normal, segments, shape, dev, None, self.seed, stream, noise_std) \
+                    if noise_std > 0. else None
+            return _draw_segments(ops.random_uniform, segments, shape, dev, None, self.seed, stream) if perturb else None
 
         out: Dict[str, Tensor] = {}
 

@@ -105,6 +105,7 @@ class PackedMlp:
     # When set to a list, every forward() brackets its kernel launch with a pair of events recorded on the launch
     # stream and appends (start, end, num_samples) -- bench.py uses this to time the dominant kernel in situ.
     event_log = None
+    backward_event_log = None   # same for backward(): (start, end, num_samples) around the whole snerf_mlp_backward call
 
     def __init__(self, mlp_cfg: dict, device):
         lib = _lib.load()
@@ -213,10 +214,17 @@ class PackedMlp:
         work = torch.empty(lib.snerf_mlp_backward_workspace_floats(ctypes.byref(self.desc), n, s), dtype=torch.float32,
                            device=dev)
         arr = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        log = PackedMlp.backward_event_log
         with torch.cuda.device(dev):
+            if log is not None:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
             st = lib.snerf_mlp_backward(ctypes.byref(self.desc), _ptr(self.buffer), _ptr(saved), _ptr(sigma), _ptr(rgb),
                                         _ptr(d_sigma), _ptr(d_rgb), n, s, _ptr(work), arr, len(grads), int(precision),
                                         _stream())
+            if log is not None:
+                t1.record()
+                log.append((t0, t1, n * s))
         _lib.check(st, 'snerf_mlp_backward')
         return grads
 

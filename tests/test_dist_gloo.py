@@ -140,3 +140,39 @@ def test_two_rank_training_iteration_equals_single_process(tmp_path):
     marker = str(tmp_path / 'done')
     mp.spawn(_train_worker, args=(2, _free_port(), marker), nprocs=2, join=True)
     assert open(marker).read() == 'ok'
+
+
+@pytest.mark.parametrize('ranks', [2, 3])
+def test_bench_self_launches_its_ranks(ranks):
+    """``python bench.py --gpus N`` with no launcher around it (how the driver calls it): bench.py starts its N rank
+    processes itself, they rendezvous over torch.distributed (gloo here, RCCL on a GPU node), every rank contributes its
+    1024-ray block to the gather, and the parent relays ONE JSON line whose ``collective`` object reports the ranks.  The
+    renderer is replaced by the CPU stand-in (SNERF_BENCH_STANDIN=1) -- what is exercised is the launcher and the N > 1
+    protocol, which needs no GPU."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(SNERF_BENCH_STANDIN='1', SNERF_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', str(ranks), '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == ranks and line['steps'] == 3 and line['warmup'] == 1 and line['scaling'] == 'weak'
+    assert line['collective'] == {'backend': 'gloo', 'ranks': ranks}
+    assert line['data'] == 'stand-in' and line['value'] > 0
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """A rank that dies takes the launch down with a non-zero status instead of leaving the others in the rendezvous."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(SNERF_BENCH_STANDIN='1', SNERF_DIST_BACKEND='no-such-backend')
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]

@@ -123,3 +123,45 @@ def test_draws_match_oracle_and_do_not_depend_on_sharding():
     big = ops.random_normal(1, 0, 0, (1 << 20, 8), DEV)
     assert abs(float(big.mean())) < 3e-3 and abs(float(big.std()) - 1) < 3e-3 and torch.isfinite(big).all()
     assert ops.random_uniform(1, 0, 0, (0, 5), DEV).shape == (0, 5)
+
+
+def test_two_rank_assembler_batches_draw_what_a_single_process_draws():
+    """with the rays of a batch sharded over ranks, every ray must still get the jitter, inverse-CDF
+    draws and density noise it gets in a single-process run.  A rank's rows are a pixel-ray shard followed by a
+    sparse-depth shard of the global [pixel | sparse] batch, so the assembler hands the model ``row_segments``; here two
+    assemblers (rank 0 and 1 of 2) and a single-process one feed the training-mode renderer, and the per-ray outputs of
+    the union, re-ordered by global row, are bit-identical to the single-process outputs."""
+    from simplenerf_amd import synth
+    from simplenerf_amd.models.ModelFactory import get_model
+    g = util.load('batch_assembly.npz')
+    cfg = synth.make_configs('config3')           # perturb on, raw_noise_std 1: every kind of draw is consumed
+    cfg['data_loader'].update(num_rays=96, sparse_depth={'num_rays': 32})
+    cfg['seed'] = 5
+    shapes = util.model_param_shapes(cfg)
+
+    def model():
+        m = get_model(cfg, None)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
+        return m.to(DEV).train()
+
+    one = BatchAssembler(cfg, golden_scene(g), DEV)
+    halves = [BatchAssembler(cfg, golden_scene(g), DEV, rank=r, world_size=2) for r in range(2)]
+    whole_model, rank_models = model(), [model(), model()]
+    keys = ('z_vals_coarse', 'z_vals_fine', 'raw_sigma_coarse', 'points_augmentation_raw_sigma_coarse',
+            'views_augmentation_raw_sigma_coarse', 'raw_sigma_fine', 'rgb_fine')
+    for it in range(2):
+        batch = one.get_next_batch(it)
+        assert batch['row_segments'] == [(0, 96, 0), (96, 32, 96)]
+        parts = [h.get_next_batch(it) for h in halves]
+        assert parts[0]['row_segments'] == [(0, 48, 0), (48, 16, 96)] and parts[1]['row_segments'] == [(0, 48, 48), (48, 16, 112)]
+        with torch.no_grad():
+            ref = whole_model(batch)
+            outs = [m(p) for m, p in zip(rank_models, parts)]
+        rows = torch.cat([torch.cat([torch.arange(c, device=DEV) + gl for _, c, gl in p['row_segments']]) for p in parts])
+        assert torch.equal(torch.sort(rows)[0], torch.arange(128, device=DEV))
+        assert torch.equal(torch.cat([p['indices'] for p in parts])[torch.argsort(rows)], batch['indices'])
+        for k in keys:
+            union = torch.cat([o[k] for o in outs])[torch.argsort(rows)]
+            assert torch.equal(union, ref[k]), (it, k)
+    # and the draws really are per-row: rank 1's rows differ from rank 0's
+    assert not torch.equal(outs[0]['z_vals_coarse'], outs[1]['z_vals_coarse'])

@@ -110,7 +110,11 @@ def test_lr_decayers_follow_the_reference():
                                         'lr_final': 5e-6, 'lr_decay_steps': 2500, 'lr_decay_mult': 0.01}})
     for it, a, b in zip(g['probe_iters'], g['nerf_lr'], g['mip_lr']):
         assert nerf.get_updated_learning_rate(int(it)) == float(a)          # bit-identical doubles
-        assert mip.get_updated_learning_rate(int(it)) == pytest.approx(float(b), rel=1e-15)
+        assert mip.get_updated_learning_rate(int(it)) == float(b)
+    dense = util.load('lr_schedules.npz')       # every 37th iteration up to 500 000, both schedules: the same doubles
+    for it, a, b in zip(dense['iters'], dense['nerf_lr'], dense['mip_lr']):
+        assert nerf.get_updated_learning_rate(int(it)) == float(a), it
+        assert mip.get_updated_learning_rate(int(it)) == float(b), it
     with pytest.raises(RuntimeError, match='Unknown lr decayer'):
         get_lr_decayer({'optimizer': {'lr_decayer_name': 'CosineDecayer01'}})
 
@@ -169,7 +173,8 @@ def test_batch_assembler_epoch_and_shard_arithmetic():
         covered = []
         for rank in range(world):
             asm.rank, asm.world_size = rank, world
-            first, count = asm._shard(40, 100)
+            first, count, offset = asm._shard(40, 100)
+            assert offset == first - 40
             covered += list(range(first, first + count))
         assert covered == list(range(40, 140))
 
@@ -210,3 +215,36 @@ def test_frame_writer_round_trips(tmp_path):
     assert numpy.array_equal(decode(tmp_path / 'depth' / '0001.png'), numpy.round(depth / depth.max() * 255).astype('uint8'))
     with pytest.raises(RuntimeError, match='Unknown image format'):
         harness.save_image(tmp_path / 'x.jpg', image)
+
+
+def test_row_segments_tile_merge_and_slice():
+    """Global-row bookkeeping of the training draws (a rank's rows are a pixel shard followed by a sparse
+    shard, not one contiguous range of the single-process batch)."""
+    from simplenerf_amd.models.SimpleNeRFHip01 import row_segments, slice_row_segments
+    assert row_segments({}, 7) == [(0, 7, 0)] and row_segments({'row_offset': 40}, 7) == [(0, 7, 40)]
+    # single process: pixel rows [0,2048) then sparse rows [2048,4096) are one contiguous range
+    assert row_segments({'row_segments': [(0, 2048, 0), (2048, 2048, 2048)]}, 4096) == [(0, 4096, 0)]
+    # rank 1 of 2: pixel rows 1024.. and sparse rows 2048+1024.. of the global batch
+    segs = row_segments({'row_segments': [(0, 1024, 1024), (1024, 1024, 3072)]}, 2048)
+    assert segs == [(0, 1024, 1024), (1024, 1024, 3072)]
+    assert slice_row_segments(segs, 0, 1024) == [(0, 1024, 1024)] and slice_row_segments(segs, 1024, 1024) == [(0, 1024, 3072)]
+    assert slice_row_segments(segs, 512, 1024) == [(0, 512, 1536), (512, 512, 3072)]
+    assert slice_row_segments(segs, 2048, 10) == [(0, 0, 0)]
+    with pytest.raises(RuntimeError):
+        row_segments({'row_segments': [(0, 5, 0), (6, 1, 9)]}, 7)
+    with pytest.raises(RuntimeError):
+        row_segments({'row_segments': [(0, 5, 0)]}, 7)
+    # the union over ranks of the global rows of a sharded [pixel | sparse] batch is every row exactly once
+    total_p, total_s, world = 1000, 37, 3
+    seen = []
+    for rank in range(world):
+        parts = []
+        for total, base in ((total_p, 0), (total_s, total_p)):
+            per = -(-total // world)
+            lo = min(total, rank * per)
+            parts.append((min(total, lo + per) - lo, base + lo))
+        local = 0
+        for count, glob in parts:
+            seen += list(range(glob, glob + count))
+            local += count
+    assert sorted(seen) == list(range(total_p + total_s))

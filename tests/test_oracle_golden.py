@@ -250,7 +250,11 @@ def test_learning_rate_schedules_match_reference():
     g = util.load('optim_adam.npz')
     for it, nerf, mip in zip(g['probe_iters'], g['nerf_lr'], g['mip_lr']):
         assert optim_oracle.nerf_learning_rate(5e-4, 250, int(it)) == float(nerf)
-        assert optim_oracle.mipnerf_learning_rate(5e-4, 5e-6, 500000, 2500, 0.01, int(it)) == pytest.approx(float(mip), rel=1e-15)
+        assert optim_oracle.mipnerf_learning_rate(5e-4, 5e-6, 500000, 2500, 0.01, int(it)) == float(mip)
+    dense = util.load('lr_schedules.npz')           # every 37th iteration of the whole horizon: the same doubles
+    for it, nerf, mip in zip(dense['iters'], dense['nerf_lr'], dense['mip_lr']):
+        assert optim_oracle.nerf_learning_rate(5e-4, 250, int(it)) == float(nerf), it
+        assert optim_oracle.mipnerf_learning_rate(5e-4, 5e-6, 500000, 2500, 0.01, int(it)) == float(mip), it
 
 
 # ---------------------------------------------------------------- G9 batch assembly, index stream, draws

@@ -13,6 +13,7 @@ Fixtures written:
                                 ties, negatives, values > 1, +-inf and NaN
     inference_outputs.npz       f3: DataPreprocessor.retrieve_inference_outputs (:897-925) on a seeded network-output
                                 dictionary of a small frame: which outputs leave the device and in what form
+    lr_schedules.npz            f4: both learning-rate decayers sampled every 37 iterations up to 500 000
 """
 import os
 import sys
@@ -110,8 +111,28 @@ def make_inference_outputs(cams):
     save('inference_outputs.npz', **arrays)
 
 
+def make_lr_schedules():
+    """Both reference decayers sampled every 37 iterations over their whole horizon (the round-1 fixture held 7 probes,
+    which missed that numpy's exp/sin differ from libm's by 1 ulp on ~4 % of iterations)."""
+    sys.path.insert(0, '/root/reference/src')
+    from lr_decayers.LearningRateDecayerFactory import get_lr_decayer
+    iters = numpy.arange(0, 500001, 37, dtype=numpy.int64)
+    nerf = get_lr_decayer({'optimizer': {'lr_decayer_name': 'NeRFLearningRateDecayer01', 'lr_initial': 5e-4, 'lr_decay': 250}})
+    mip = get_lr_decayer({'num_iterations': 500000,
+                          'optimizer': {'lr_decayer_name': 'MipNeRFLearningRateDecayer01', 'lr_initial': 5e-4,
+                                        'lr_final': 5e-6, 'lr_decay_steps': 2500, 'lr_decay_mult': 0.01}})
+    save('lr_schedules.npz', iters=iters,
+         nerf_lr=numpy.array([nerf.get_updated_learning_rate(int(i)) for i in iters], dtype=numpy.float64),
+         mip_lr=numpy.array([mip.get_updated_learning_rate(int(i)) for i in iters], dtype=numpy.float64))
+
+
 if __name__ == '__main__':
+    only = sys.argv[1:]
     cams = cams_from_disk()
-    make_config4(cams)
-    make_display()
-    make_inference_outputs(cams)
+    if not only or 'config4' in only:
+        make_config4(cams)
+    if not only or 'display' in only:
+        make_display()
+        make_inference_outputs(cams)
+    if not only or 'lr' in only:
+        make_lr_schedules()
