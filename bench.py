@@ -207,15 +207,16 @@ def time_training(precision, device, steps, warmup, single_pass=False):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    ops.PackedMlp.event_log, ops.PackedMlp.backward_event_log = [], []
+    ops.profile_enable(64 * steps)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    fwd, ops.PackedMlp.event_log = ops.PackedMlp.event_log, None
-    bwd, ops.PackedMlp.backward_event_log = ops.PackedMlp.backward_event_log, None
-    return elapsed / steps * 1e3, sum(a.elapsed_time(b) for a, b, _ in fwd) / steps, sum(a.elapsed_time(b) for a, b, _ in bwd) / steps, rows
+    fwd, _ = ops.profile_collect(ops.PROFILE_MLP_FORWARD)
+    bwd, _ = ops.profile_collect(ops.PROFILE_MLP_BACKWARD)
+    ops.profile_enable(0)
+    return elapsed / steps * 1e3, sum(fwd) / steps, sum(bwd) / steps, rows
 
 
 def training_record(device, steps=10, warmup=3):
@@ -397,13 +398,15 @@ def render_bench(args, rank, world, device, dist):
         for _ in range(args.warmup):
             step()
         fence()
-        ops.PackedMlp.event_log = []
+        # the library brackets every fused PE+MLP launch with HIP events on the launch stream (snerf_profile_enable)
+        ops.profile_enable(4 * args.steps + 16)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         fence()
         elapsed = time.perf_counter() - t0
-    log, ops.PackedMlp.event_log = ops.PackedMlp.event_log, None
+    launch_ms, launch_samples = ops.profile_collect(ops.PROFILE_MLP_FORWARD)
+    ops.profile_enable(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -411,8 +414,8 @@ def render_bench(args, rank, world, device, dist):
     if rank != 0:
         return
 
-    kernel_ms = sum(a.elapsed_time(b) for a, b, _ in log)
-    kernel_flop = sum(n for _, _, n in log) * FLOP_PER_SAMPLE
+    kernel_ms = sum(launch_ms)
+    kernel_flop = sum(launch_samples) * FLOP_PER_SAMPLE
     achieved = kernel_flop / (kernel_ms * 1e-3) / 1e12
     if args.precision == 'fp32':
         peak, dtype, kernel_name = PEAK_FP32_MFMA_TFLOPS, 'f32', 'mlp_forward_kernel<8,4,true,false,false>'
@@ -439,8 +442,8 @@ def render_bench(args, rank, world, device, dist):
                    'parallelism': f'ray-shard x{world}' + (' + 1 gather/step' if world > 1 else '')},
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': achieved / peak, 'traffic': pmc_traffic(args.precision),
-                     'kernel': kernel_name, 'note': note, 'launches': len(log),
-                     'avg_launch_ms': kernel_ms / max(1, len(log)),
+                     'kernel': kernel_name, 'note': note, 'launches': len(launch_ms),
+                     'avg_launch_ms': kernel_ms / max(1, len(launch_ms)),
                      'kernel_share_of_step': kernel_ms / (elapsed * 1e3)},
     }
     if world > 1:
@@ -454,15 +457,15 @@ def render_bench(args, rank, world, device, dist):
                 for _ in range(args.warmup):
                     alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
                 torch.cuda.synchronize()
-                ops.PackedMlp.event_log = []
+                ops.profile_enable(4 * steps + 16)
                 t0 = time.perf_counter()
                 for _ in range(steps):
                     alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
                 torch.cuda.synchronize()
                 alt_elapsed = time.perf_counter() - t0
-            alt_log, ops.PackedMlp.event_log = ops.PackedMlp.event_log, None
-            alt_ms = sum(a.elapsed_time(b) for a, b, _ in alt_log)
-            alt_tf = sum(n for _, _, n in alt_log) * FLOP_PER_SAMPLE / (alt_ms * 1e-3) / 1e12
+            alt_ms, alt_samples = ops.profile_collect(ops.PROFILE_MLP_FORWARD)
+            ops.profile_enable(0)
+            alt_tf = sum(alt_samples) * FLOP_PER_SAMPLE / (sum(alt_ms) * 1e-3) / 1e12
             return alt_elapsed, alt_tf
 
         sustained_steps = 300       # ~1 s of device time: long enough for the clocks to settle under the load

@@ -30,7 +30,7 @@ enum snerf_status {
 
 /* ABI version of this header; bumped on any signature change (new enum values such as SNERF_PRECISION_F16 extend a
  * version without changing it: older callers never pass them). */
-#define SNERF_ABI_VERSION 4
+#define SNERF_ABI_VERSION 5
 int snerf_abi_version(void);
 const char* snerf_last_error(void);
 
@@ -124,7 +124,9 @@ int snerf_mlp_forward(const snerf_mlp_desc* desc, const float* packed, const flo
  *   sigma, rgb                      device: those outputs themselves (ReLU / sigmoid derivatives)
  *   workspace    device, snerf_mlp_backward_workspace_floats(...) floats of scratch
  *   param_grads  num_params device pointers, same order and shapes as snerf_mlp_pack's `params`; each tensor is
- *                OVERWRITTEN with dL/dparam (sums over samples are taken in a fixed order: bit-reproducible)
+ *                OVERWRITTEN with dL/dparam when accumulate == 0, or has dL/dparam ADDED to it when accumulate != 0
+ *                (what autograd does with the gradients of the trainer's second sub-batch, src/Trainer01.py:82-96, without
+ *                a separate add launch per tensor).  Sums over samples are taken in a fixed order: bit-reproducible
  *   precision    SNERF_PRECISION_FP32; SNERF_PRECISION_F16X3 for the fp16-split forward_train / dgrad chain / large
  *                weight-gradient products (the small head and encoding products stay on the fp32 matrix cores); or
  *                SNERF_PRECISION_F16 (16-bit mode).  The layout of saved_acts depends on the precision: pass to
@@ -140,7 +142,7 @@ int snerf_mlp_forward_train(const snerf_mlp_desc* desc, const float* packed, con
 size_t snerf_mlp_backward_workspace_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples);
 int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packed, const float* saved_acts, const float* sigma,
                        const float* rgb, const float* d_sigma, const float* d_rgb, long long num_rays, int num_samples,
-                       float* workspace, float* const* param_grads, int num_params, int precision,
+                       float* workspace, float* const* param_grads, int num_params, int precision, int accumulate,
                        snerf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -178,6 +180,88 @@ int snerf_resample_depths(const float* depths_coarse, const float* weights_coars
                           int num_coarse, int num_fine, const float* u, float* depths_fine, snerf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * The one-call render ops (SURVEY 8b "Ownership / errors": render_forward / render_backward).
+ *
+ * snerf_render_forward enqueues on ONE stream everything SimpleNeRF.render_rays does for a batch of rays
+ * (src/models/SimpleNeRF01.py:108-270): coarse depths (K2) -> for the main coarse MLP and, when present, the points- and
+ * views-augmentation coarse MLPs: fused encoding + MLP (K3) and compositing (K4) -> inverse-CDF resampling of the main
+ * coarse weights + merge (K5) -> the same for the fine-level MLPs on the merged depths.  snerf_render_backward enqueues
+ * what autograd replays for it: per level the compositing backward (K6) and the MLP parameter-gradient backward (K7).
+ * Like every entry point they only enqueue: no allocation, no synchronisation; every buffer is the caller's.
+ *
+ * Levels (the six MLPs a SimpleNeRF model can hold, :17-41): a NULL `desc` means the level is absent.  Levels 1, 2, 4, 5
+ * are the augmentation models, which the reference evaluates in training mode only -- the caller passes them only then.
+ */
+enum snerf_render_level {
+    SNERF_LEVEL_MAIN_COARSE = 0, SNERF_LEVEL_POINTS_AUG_COARSE = 1, SNERF_LEVEL_VIEWS_AUG_COARSE = 2,
+    SNERF_LEVEL_MAIN_FINE = 3, SNERF_LEVEL_POINTS_AUG_FINE = 4, SNERF_LEVEL_VIEWS_AUG_FINE = 5
+};
+#define SNERF_RENDER_LEVELS 6
+
+typedef struct snerf_render_config {
+    int ndc;              /* configs['data_loader']['ndc'] */
+    int white_bkgd;       /* model.white_bkgd (:462-463) */
+    int lindisp;          /* model.lindisp (:286-289) */
+    int num_coarse;       /* coarse_mlp.num_samples */
+    int num_fine;         /* fine_mlp.num_samples, or 0 when the model has no fine MLP */
+    int precision;        /* enum snerf_precision, for every MLP of the call */
+    int keep_activations; /* != 0: training forward (snerf_mlp_forward_train); level outputs need `saved_acts` */
+} snerf_render_config;
+
+typedef struct snerf_render_mlp {
+    const snerf_mlp_desc* desc; /* NULL = level absent */
+    const float* packed;        /* device, snerf_mlp_pack's stream for that descriptor */
+} snerf_render_mlp;
+
+typedef struct snerf_render_rays {          /* device pointers, layouts of the reference's input_batch (:113-137) */
+    const float *rays_o, *rays_d;           /* (n,3) world rays */
+    const float* view_dirs;                 /* (n,3), or NULL when no MLP uses view directions */
+    const float *rays_o_ndc, *rays_d_ndc;   /* (n,3), required when ndc */
+    const float *near, *far;                /* (n): the columns the depths are spaced between (near_ndc/far_ndc when ndc) */
+    const float* t_rand;                    /* (n, num_coarse) stratified-jitter draws (:299) or NULL */
+    const float* u;                         /* (n, num_fine) inverse-CDF draws (:341) or NULL (deterministic linspace) */
+    const float* sigma_noise[SNERF_RENDER_LEVELS]; /* per level (n, S) density noise, already scaled (:669-672), or NULL */
+    const float* depths_fine;               /* (n, num_coarse+num_fine): use these fine depths instead of resampling
+                                               (parity-test hook: sample_pdf has a rounding-dependent discontinuity), or NULL */
+} snerf_render_rays;
+
+typedef struct snerf_render_level_out {     /* S = num_coarse for levels 0-2, num_coarse + num_fine for levels 3-5 */
+    float *rgb, *acc, *depth, *depth_var;   /* (n,3), (n), (n), (n): required for a present level */
+    float *depth_ndc, *depth_var_ndc;       /* (n): required when ndc */
+    float *alpha, *visibility, *weights;    /* (n,S): each may be NULL */
+    float *sigma, *raw_rgb;                 /* (n,S), (n,S,3): the MLP outputs ('raw_sigma', 'raw_rgb'), required */
+    float* saved_acts;                      /* snerf_mlp_saved_floats(desc, n, S) floats, required when keep_activations */
+} snerf_render_level_out;
+
+typedef struct snerf_render_outputs {
+    float* depths_coarse;                   /* (n, num_coarse) 'z_vals_coarse', required */
+    float* depths_fine;                     /* (n, num_coarse+num_fine) 'z_vals_fine'; required when num_fine > 0 and
+                                               rays.depths_fine is NULL */
+    snerf_render_level_out level[SNERF_RENDER_LEVELS];
+} snerf_render_outputs;
+
+/* Scratch of snerf_render_forward in floats (the main coarse weights, when level[0].weights is NULL). */
+size_t snerf_render_workspace_floats(const snerf_render_config* cfg, long long num_rays);
+int snerf_render_forward(const snerf_render_config* cfg, const snerf_render_mlp* mlps, const snerf_render_rays* rays,
+                         long long num_rays, const snerf_render_outputs* out, float* workspace, snerf_stream_t stream);
+
+typedef struct snerf_render_level_grads {   /* dL/d(output) of one level, each (shape as the output) or NULL = zero */
+    const float *rgb, *acc, *depth, *depth_ndc, *sigma, *raw_rgb;
+    float* const* param_grads;              /* the level's parameter gradients, as snerf_mlp_backward; NULL = skip level */
+    int num_params;
+    int accumulate;                         /* as snerf_mlp_backward */
+} snerf_render_level_grads;
+
+/* Scratch of snerf_render_backward in floats: d sigma + d rgb of the largest level + the largest snerf_mlp_backward
+ * workspace among the present levels (levels run one after another on the stream and share it). */
+size_t snerf_render_backward_workspace_floats(const snerf_render_config* cfg, const snerf_render_mlp* mlps, long long num_rays);
+/* `out` = the buffers snerf_render_forward (keep_activations != 0) filled for the same cfg / mlps / rays.  A level whose
+ * param_grads is NULL, or whose six gradient pointers are all NULL, is skipped (its param_grads are not touched). */
+int snerf_render_backward(const snerf_render_config* cfg, const snerf_render_mlp* mlps, const snerf_render_rays* rays,
+                          long long num_rays, const snerf_render_outputs* out, const snerf_render_level_grads* grads,
+                          float* workspace, snerf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Output post-processing (next-row f3).  Replaces post_process_image / post_process_depth
  * (src/data_preprocessors/DataPreprocessor01.py:1106-1114) on the device, so a rendered frame crosses PCIe as uint8.
  *   rgb (n,3) device; depth (n) device or NULL;  image (n,3) uint8 device;  depth_out (n) device or NULL
@@ -187,6 +271,21 @@ int snerf_resample_depths(const float* depths_coarse, const float* weights_coars
  */
 int snerf_to_display(const float* rgb, const float* depth, long long num_rays, unsigned char* image, float* depth_out,
                      snerf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Opt-in event timing of the dominant kernels (the measurement row, SURVEY 8d: "achieved" of the roofline is measured
+ * live with HIP events on the stream the kernel is launched on).  While enabled, every snerf_mlp_forward[_train] launch
+ * (kind SNERF_PROFILE_MLP_FORWARD) and every snerf_mlp_backward call (SNERF_PROFILE_MLP_BACKWARD) -- also those issued
+ * from inside snerf_render_forward / _backward -- is bracketed by an event pair owned by the library.
+ *   snerf_profile_enable(capacity)   create `capacity` event pairs and start recording; capacity <= 0 stops and frees
+ *   snerf_profile_collect(kind, ms, samples, capacity)   waits for the recorded events of that kind and writes each
+ *        launch's duration in milliseconds and its number of samples (rays x samples); returns how many, or < 0
+ *   snerf_profile_reset()            forget the recorded launches, keep recording
+ * Process-wide, off by default (one relaxed atomic load on the launch path).  Do not enable during graph capture. */
+enum snerf_profile_kind { SNERF_PROFILE_MLP_FORWARD = 0, SNERF_PROFILE_MLP_BACKWARD = 1 };
+int snerf_profile_enable(int capacity);
+int snerf_profile_collect(int kind, float* milliseconds, long long* samples, int capacity);
+int snerf_profile_reset(void);
 
 #ifdef __cplusplus
 }

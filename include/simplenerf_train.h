@@ -113,6 +113,11 @@ typedef struct snerf_batch {
     float* sparse_depth_values_ndc; /* device (n,1) or NULL */
     unsigned char* mask_pixel_rays; /* device (n) bytes: indices_mask_nerf */
     unsigned char* mask_sparse_rays;/* device (n) bytes: indices_mask_sparse_depth, or NULL */
+    long long* global_rows;         /* device (n) int64 or NULL: the row each ray has in the SINGLE-PROCESS batch (pixel rays
+                                       first, then sparse-depth rays) -- first_pixel_row + i for the pixel rows,
+                                       first_sparse_row + (i - num_pixel_rays) for the others.  A per-row tensor, so that it
+                                       is cut along with the batch by a trainer that slices sub-batches
+                                       (src/Trainer01.py:82-90); the renderer keys its training draws on it */
 } snerf_batch;
 
 /*   indices   device (n) int64 global pixel indices  view*height*width + y*width + x; the first num_pixel_rays rows
@@ -123,8 +128,8 @@ typedef struct snerf_batch {
 int snerf_assemble_batch(const long long* indices, long long num_rays, long long num_pixel_rays,
                          const float* camera_table, int num_views, int height, int width, const float* images,
                          const float* sparse_depths, const float* sparse_errors, const float* sparse_depths_ndc, int ndc,
-                         float near, float far, float near_ndc, float far_ndc, const snerf_batch* out,
-                         snerf_stream_t stream);
+                         float near, float far, float near_ndc, float far_ndc, long long first_pixel_row,
+                         long long first_sparse_row, const snerf_batch* out, snerf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * B2  shuffled index stream.  Replaces the host-side index list of generate_indices / select_batch_indices (:252-270,
@@ -151,11 +156,13 @@ int snerf_shuffled_indices(unsigned long long seed, unsigned long long epoch, lo
  * only on (seed, stream_id, first_row + row, col), so a ray's draws do not depend on how rays are sharded over ranks.
  *   uniform: [0,1) with 24 random bits, like torch.rand;  normal: Box-Muller on pairs of 24-bit uniforms, times scale
  *   out  device (num_rows, row_width)
+ *   row_ids  device (num_rows) int64 global row of each output row (snerf_batch.global_rows), or NULL: row r is global row
+ *            first_row + r
  */
-int snerf_random_uniform(unsigned long long seed, unsigned int stream_id, long long first_row, long long num_rows,
-                         int row_width, float* out, snerf_stream_t stream);
-int snerf_random_normal(unsigned long long seed, unsigned int stream_id, long long first_row, long long num_rows,
-                        int row_width, float scale, float* out, snerf_stream_t stream);
+int snerf_random_uniform(unsigned long long seed, unsigned int stream_id, long long first_row, const long long* row_ids,
+                         long long num_rows, int row_width, float* out, snerf_stream_t stream);
+int snerf_random_normal(unsigned long long seed, unsigned int stream_id, long long first_row, const long long* row_ids,
+                        long long num_rows, int row_width, float scale, float* out, snerf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * O1  Adam update of every parameter tensor in one launch per 64 tensors.  Replaces the optimiser call of the

@@ -12,7 +12,7 @@ from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_s
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsimplenerf_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MlpDesc(ctypes.Structure):
@@ -33,7 +33,48 @@ class Batch(ctypes.Structure):
     _fields_ = [(name, c_void_p) for name in (
         'rays_o', 'rays_d', 'view_dirs', 'rays_o_ndc', 'rays_d_ndc', 'pixel_id', 'target_rgb', 'near', 'far', 'near_ndc',
         'far_ndc', 'sparse_depth_values', 'sparse_depth_errors', 'sparse_depth_values_ndc', 'mask_pixel_rays',
-        'mask_sparse_rays')]
+        'mask_sparse_rays', 'global_rows')]
+
+
+RENDER_LEVELS = 6
+
+
+class RenderConfig(ctypes.Structure):
+    """struct snerf_render_config"""
+    _fields_ = [(name, c_int) for name in ('ndc', 'white_bkgd', 'lindisp', 'num_coarse', 'num_fine', 'precision',
+                                           'keep_activations')]
+
+
+class RenderMlp(ctypes.Structure):
+    """struct snerf_render_mlp"""
+    _fields_ = [('desc', POINTER(MlpDesc)), ('packed', c_void_p)]
+
+
+class RenderRays(ctypes.Structure):
+    """struct snerf_render_rays"""
+    _fields_ = [(name, c_void_p) for name in ('rays_o', 'rays_d', 'view_dirs', 'rays_o_ndc', 'rays_d_ndc', 'near', 'far',
+                                              't_rand', 'u')] + \
+               [('sigma_noise', c_void_p * RENDER_LEVELS), ('depths_fine', c_void_p)]
+
+
+LEVEL_OUT_FIELDS = ('rgb', 'acc', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc', 'alpha', 'visibility', 'weights',
+                    'sigma', 'raw_rgb', 'saved_acts')
+
+
+class RenderLevelOut(ctypes.Structure):
+    """struct snerf_render_level_out"""
+    _fields_ = [(name, c_void_p) for name in LEVEL_OUT_FIELDS]
+
+
+class RenderOutputs(ctypes.Structure):
+    """struct snerf_render_outputs"""
+    _fields_ = [('depths_coarse', c_void_p), ('depths_fine', c_void_p), ('level', RenderLevelOut * RENDER_LEVELS)]
+
+
+class RenderLevelGrads(ctypes.Structure):
+    """struct snerf_render_level_grads"""
+    _fields_ = [(name, c_void_p) for name in ('rgb', 'acc', 'depth', 'depth_ndc', 'sigma', 'raw_rgb')] + \
+               [('param_grads', POINTER(c_void_p)), ('num_params', c_int), ('accumulate', c_int)]
 
 
 CAMERA_FLOATS = 24
@@ -58,7 +99,16 @@ SIGNATURES = {
                                         c_int, c_void_p]),
     'snerf_mlp_backward_workspace_floats': (c_size_t, [POINTER(MlpDesc), c_longlong, c_int]),
     'snerf_mlp_backward': (c_int, [POINTER(MlpDesc), _FP, _FP, _FP, _FP, _FP, _FP, c_longlong, c_int, _FP,
-                                   POINTER(c_void_p), c_int, c_int, c_void_p]),
+                                   POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
+    'snerf_profile_enable': (c_int, [c_int]),
+    'snerf_profile_collect': (c_int, [c_int, POINTER(c_float), POINTER(c_longlong), c_int]),
+    'snerf_profile_reset': (c_int, []),
+    'snerf_render_workspace_floats': (c_size_t, [POINTER(RenderConfig), c_longlong]),
+    'snerf_render_forward': (c_int, [POINTER(RenderConfig), POINTER(RenderMlp), POINTER(RenderRays), c_longlong,
+                                     POINTER(RenderOutputs), _FP, c_void_p]),
+    'snerf_render_backward_workspace_floats': (c_size_t, [POINTER(RenderConfig), POINTER(RenderMlp), c_longlong]),
+    'snerf_render_backward': (c_int, [POINTER(RenderConfig), POINTER(RenderMlp), POINTER(RenderRays), c_longlong,
+                                      POINTER(RenderOutputs), POINTER(RenderLevelGrads), _FP, c_void_p]),
     'snerf_composite_backward': (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_longlong, c_int, c_int, c_int, _FP, _FP, _FP, _FP,
                                          _FP, _FP, c_void_p]),
     'snerf_composite': (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_longlong, c_int, c_int, c_int, _FP, _FP, _FP, _FP, _FP,
@@ -74,11 +124,11 @@ SIGNATURES = {
                                               c_void_p]),
     'snerf_camera_table': (c_int, [_FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
     'snerf_assemble_batch': (c_int, [c_void_p, c_longlong, c_longlong, _FP, c_int, c_int, c_int, _FP, _FP, _FP, _FP, c_int,
-                                     c_float, c_float, c_float, c_float, POINTER(Batch), c_void_p]),
+                                     c_float, c_float, c_float, c_float, c_longlong, c_longlong, POINTER(Batch), c_void_p]),
     'snerf_shuffled_indices': (c_int, [c_ulonglong, c_ulonglong, c_longlong, c_longlong, c_longlong, c_void_p, c_int,
                                        c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    'snerf_random_uniform': (c_int, [c_ulonglong, c_uint, c_longlong, c_longlong, c_int, _FP, c_void_p]),
-    'snerf_random_normal': (c_int, [c_ulonglong, c_uint, c_longlong, c_longlong, c_int, c_float, _FP, c_void_p]),
+    'snerf_random_uniform': (c_int, [c_ulonglong, c_uint, c_longlong, c_void_p, c_longlong, c_int, _FP, c_void_p]),
+    'snerf_random_normal': (c_int, [c_ulonglong, c_uint, c_longlong, c_void_p, c_longlong, c_int, c_float, _FP, c_void_p]),
     'snerf_adam_step': (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                 POINTER(c_longlong), c_int, c_longlong, c_double, c_double, c_double, c_double,
                                 c_void_p]),

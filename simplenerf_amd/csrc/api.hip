@@ -10,3 +10,80 @@ char* error_buffer() {
 
 extern "C" int snerf_abi_version(void) { return SNERF_ABI_VERSION; }
 extern "C" const char* snerf_last_error(void) { return snerf::error_buffer(); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Opt-in timing of the dominant kernels (bench.py's roofline leg): while enabled, every snerf_mlp_forward[_train]
+// launch (kind 0) and every snerf_mlp_backward call (kind 1) is bracketed by a pair of HIP events recorded on the
+// stream it is enqueued on -- also when it is issued from inside snerf_render_forward / _backward.  Off by default;
+// the hot path then pays one relaxed atomic load.  Not for use during graph capture (the records would be captured).
+#include <atomic>
+#include <mutex>
+#include <vector>
+
+namespace snerf {
+namespace {
+struct ProfileEntry { hipEvent_t start, stop; long long samples; int kind; };
+std::mutex g_profile_mutex;
+std::vector<ProfileEntry> g_profile;     // pre-created event pairs
+int g_profile_used = 0;
+std::atomic<int> g_profile_on{0};
+}  // namespace
+
+int profile_begin(int kind, hipStream_t stream, long long samples) {
+    if (!g_profile_on.load(std::memory_order_relaxed)) return -1;
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
+    if (g_profile_used >= (int)g_profile.size()) return -1;
+    const int slot = g_profile_used++;
+    g_profile[slot].samples = samples;
+    g_profile[slot].kind = kind;
+    (void)hipEventRecord(g_profile[slot].start, stream);
+    return slot;
+}
+
+void profile_end(int slot, hipStream_t stream) {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
+    if (slot < (int)g_profile.size()) (void)hipEventRecord(g_profile[slot].stop, stream);
+}
+}  // namespace snerf
+
+extern "C" int snerf_profile_enable(int capacity) {
+    using namespace snerf;
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
+    g_profile_on.store(0);
+    for (ProfileEntry& e : g_profile) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
+    g_profile.clear();
+    g_profile_used = 0;
+    if (capacity <= 0) return SNERF_OK;
+    g_profile.resize((size_t)capacity);
+    for (ProfileEntry& e : g_profile) {
+        if (hipEventCreate(&e.start) != hipSuccess || hipEventCreate(&e.stop) != hipSuccess)
+            return fail(SNERF_E_HIP, "profile_enable: hipEventCreate failed");
+    }
+    g_profile_on.store(1);
+    return SNERF_OK;
+}
+
+extern "C" int snerf_profile_collect(int kind, float* milliseconds, long long* samples, int capacity) {
+    using namespace snerf;
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
+    int count = 0;
+    for (int i = 0; i < g_profile_used; ++i) {
+        const ProfileEntry& e = g_profile[i];
+        if (e.kind != kind) continue;
+        if (count >= capacity) break;
+        float ms = 0.0f;
+        if (hipEventSynchronize(e.stop) != hipSuccess || hipEventElapsedTime(&ms, e.start, e.stop) != hipSuccess)
+            return fail(SNERF_E_HIP, "profile_collect: event %d not readable", i);
+        if (milliseconds) milliseconds[count] = ms;
+        if (samples) samples[count] = e.samples;
+        ++count;
+    }
+    return count;
+}
+
+extern "C" int snerf_profile_reset(void) {
+    std::lock_guard<std::mutex> lock(snerf::g_profile_mutex);
+    snerf::g_profile_used = 0;
+    return SNERF_OK;
+}

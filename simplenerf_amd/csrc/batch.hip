@@ -34,6 +34,7 @@ struct AssembleArgs {
     const float* sparse_errors;
     const float* sparse_depths_ndc;
     float near, far, near_ndc, far_ndc;
+    long long first_pixel_row, first_sparse_row;
     snerf_batch out;
 };
 
@@ -51,6 +52,7 @@ __global__ void __launch_bounds__(256) assemble_batch_kernel(AssembleArgs a) {
         const bool ok = idx >= 0 && idx < frame * a.num_views;
         o.mask_pixel_rays[i] = ok && pixel_row;
         if (o.mask_sparse_rays) o.mask_sparse_rays[i] = ok && !pixel_row;
+        if (o.global_rows) o.global_rows[i] = pixel_row ? a.first_pixel_row + i : a.first_sparse_row + (i - a.num_pixel_rays);
         float* on = a.ndc ? o.rays_o_ndc + 3 * i : nullptr;
         float* dn = a.ndc ? o.rays_d_ndc + 3 * i : nullptr;
         float sd = -1.0f, se = -1.0f, sn = -1.0f, nr = -1.0f, fr = -1.0f, nn = -1.0f, fn = -1.0f;
@@ -151,14 +153,15 @@ __device__ __forceinline__ Philox philox4x32_10(unsigned c0, unsigned c1, unsign
 
 template <bool NORMAL>
 __global__ void __launch_bounds__(256) random_kernel(unsigned seed_lo, unsigned seed_hi, unsigned stream_id, long long first_row,
-                                                     long long num_rows, int row_width, float scale, float* __restrict__ out) {
+                                                     const long long* __restrict__ row_ids, long long num_rows, int row_width,
+                                                     float scale, float* __restrict__ out) {
     const int blocks_per_row = (row_width + 3) / 4;
     const long long total = num_rows * blocks_per_row;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const long long row = t / blocks_per_row;
         const int block = (int)(t - row * blocks_per_row);
-        const unsigned long long grow = (unsigned long long)(first_row + row);
+        const unsigned long long grow = (unsigned long long)(row_ids ? row_ids[row] : first_row + row);
         const Philox p = philox4x32_10((unsigned)grow, (unsigned)(grow >> 32), (unsigned)block, stream_id, seed_lo, seed_hi);
         float v[4];
         if (NORMAL) {
@@ -183,8 +186,8 @@ __global__ void __launch_bounds__(256) random_kernel(unsigned seed_lo, unsigned 
     }
 }
 
-int launch_random(bool normal, unsigned long long seed, unsigned stream_id, long long first_row, long long num_rows,
-                  int row_width, float scale, float* out, snerf_stream_t stream) {
+int launch_random(bool normal, unsigned long long seed, unsigned stream_id, long long first_row, const long long* row_ids,
+                  long long num_rows, int row_width, float scale, float* out, snerf_stream_t stream) {
     SNERF_REQUIRE(out, "random draws: NULL output");
     SNERF_REQUIRE(num_rows >= 0 && row_width >= 1 && first_row >= 0, "random draws: bad shape (%lld rows from %lld, width %d)",
                   num_rows, first_row, row_width);
@@ -193,10 +196,10 @@ int launch_random(bool normal, unsigned long long seed, unsigned stream_id, long
     const dim3 grid(snerf::stride_grid(work, 256)), block(256);
     if (normal)
         hipLaunchKernelGGL(random_kernel<true>, grid, block, 0, (hipStream_t)stream, (unsigned)seed, (unsigned)(seed >> 32),
-                           stream_id, first_row, num_rows, row_width, scale, out);
+                           stream_id, first_row, row_ids, num_rows, row_width, scale, out);
     else
         hipLaunchKernelGGL(random_kernel<false>, grid, block, 0, (hipStream_t)stream, (unsigned)seed, (unsigned)(seed >> 32),
-                           stream_id, first_row, num_rows, row_width, scale, out);
+                           stream_id, first_row, row_ids, num_rows, row_width, scale, out);
     return snerf::check_launch("random draws");
 }
 
@@ -214,8 +217,8 @@ extern "C" int snerf_camera_table(const float* intrinsics, const float* poses, i
 extern "C" int snerf_assemble_batch(const long long* indices, long long num_rays, long long num_pixel_rays,
                                     const float* camera_table, int num_views, int height, int width, const float* images,
                                     const float* sparse_depths, const float* sparse_errors, const float* sparse_depths_ndc,
-                                    int ndc, float near, float far, float near_ndc, float far_ndc, const snerf_batch* out,
-                                    snerf_stream_t stream) {
+                                    int ndc, float near, float far, float near_ndc, float far_ndc, long long first_pixel_row,
+                                    long long first_sparse_row, const snerf_batch* out, snerf_stream_t stream) {
     SNERF_REQUIRE(indices && camera_table && images && out, "assemble_batch: NULL pointer");
     SNERF_REQUIRE(num_rays >= 0 && num_pixel_rays >= 0 && num_pixel_rays <= num_rays,
                   "assemble_batch: %lld pixel rays of %lld rows", num_pixel_rays, num_rays);
@@ -226,7 +229,8 @@ extern "C" int snerf_assemble_batch(const long long* indices, long long num_rays
                   "assemble_batch: ndc requested but an NDC output is NULL");
     if (num_rays == 0) return SNERF_OK;
     AssembleArgs a{indices, num_rays, num_pixel_rays, reinterpret_cast<const snerf::Camera*>(camera_table), num_views, height,
-                   width, ndc, images, sparse_depths, sparse_errors, sparse_depths_ndc, near, far, near_ndc, far_ndc, *out};
+                   width, ndc, images, sparse_depths, sparse_errors, sparse_depths_ndc, near, far, near_ndc, far_ndc,
+                   first_pixel_row, first_sparse_row, *out};
     hipLaunchKernelGGL(assemble_batch_kernel, dim3(snerf::stride_grid(num_rays, 256)), dim3(256), 0, (hipStream_t)stream, a);
     return snerf::check_launch("assemble_batch");
 }
@@ -263,11 +267,13 @@ extern "C" int snerf_shuffled_indices(unsigned long long seed, unsigned long lon
 }
 
 extern "C" int snerf_random_uniform(unsigned long long seed, unsigned int stream_id, long long first_row,
-                                    long long num_rows, int row_width, float* out, snerf_stream_t stream) {
-    return launch_random(false, seed, stream_id, first_row, num_rows, row_width, 1.0f, out, stream);
+                                    const long long* row_ids, long long num_rows, int row_width, float* out,
+                                    snerf_stream_t stream) {
+    return launch_random(false, seed, stream_id, first_row, row_ids, num_rows, row_width, 1.0f, out, stream);
 }
 
-extern "C" int snerf_random_normal(unsigned long long seed, unsigned int stream_id, long long first_row, long long num_rows,
-                                   int row_width, float scale, float* out, snerf_stream_t stream) {
-    return launch_random(true, seed, stream_id, first_row, num_rows, row_width, scale, out, stream);
+extern "C" int snerf_random_normal(unsigned long long seed, unsigned int stream_id, long long first_row,
+                                   const long long* row_ids, long long num_rows, int row_width, float scale, float* out,
+                                   snerf_stream_t stream) {
+    return launch_random(true, seed, stream_id, first_row, row_ids, num_rows, row_width, scale, out, stream);
 }

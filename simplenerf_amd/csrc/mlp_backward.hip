@@ -705,7 +705,8 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
 // in flight per lane -- the small head/encoding jobs have few outputs but up to 512 chunks, so a single serial loop
 // per output would be pure HBM latency), then wave 0 adds the four quarter sums in order.  The summation tree depends
 // only on the chunk count, so results are bit-reproducible run to run.
-__global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float* __restrict__ partial, GradPointers ptrs) {
+__global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float* __restrict__ partial, GradPointers ptrs,
+                                                     int accumulate) {
     __shared__ float quarter[4][64];
     const WgradJob& job = table.jobs[blockIdx.y];
     const float unscale =
@@ -754,9 +755,14 @@ __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float
                     const int e = pe_position_feature(i, job.x_kind);
                     col = (e >= job.feat_lo && e < job.feat_hi) ? e - job.feat_lo : -1;
                 }
-                if (col >= 0) grad_w[(long long)o * job.w_ld + job.w_col + col] = sum * unscale;
+                // accumulate: dL/dparam is added to what the tensor holds (the trainer's later sub-batches) -- one
+                // read-modify-write per element by its only writer, so the result stays bit-reproducible
+                if (col >= 0) {
+                    float* dst = grad_w + (long long)o * job.w_ld + job.w_col + col;
+                    *dst = accumulate ? *dst + sum * unscale : sum * unscale;
+                }
             } else {
-                grad_b[o] = sum;
+                grad_b[o] = accumulate ? grad_b[o] + sum : sum;
             }
         }
         __syncthreads();
@@ -926,7 +932,7 @@ extern "C" size_t snerf_mlp_backward_workspace_floats(const snerf_mlp_desc* desc
 extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packed, const float* saved_acts,
                                   const float* sigma, const float* rgb, const float* d_sigma, const float* d_rgb,
                                   long long num_rays, int num_samples, float* workspace, float* const* param_grads,
-                                  int num_params, int precision, snerf_stream_t stream) {
+                                  int num_params, int precision, int accumulate, snerf_stream_t stream) {
     snerf::MlpPlan plan;
     const int st = snerf::build_plan(desc, &plan);
     if (st != SNERF_OK) return st;
@@ -951,6 +957,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
                            plan.grad_head() / 32 + 1, kRegionWords);
     float* grads = workspace;
     float* partial = workspace + ws.grads_floats;
+    snerf::ProfileScope timed(SNERF_PROFILE_MLP_BACKWARD, s, total);
 
     ChainArgs a;
     a.packed = packed; a.acts = saved_acts; a.sigma = sigma; a.rgb = rgb; a.d_sigma = d_sigma; a.d_rgb = d_rgb;
@@ -1047,7 +1054,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     GradPointers ptrs;
     for (int i = 0; i < num_params; ++i) ptrs.p[i] = param_grads[i];
     hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)std::min<long long>((max_work + 63) / 64, 1024), table.count), dim3(256), 0, s, table, partial,
-                       ptrs);
+                       ptrs, accumulate ? 1 : 0);
     rc = snerf::check_launch("mlp_backward(reduce)");
     if (rc != SNERF_OK) return rc;
     return SNERF_OK;

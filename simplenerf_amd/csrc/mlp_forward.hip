@@ -189,6 +189,7 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     a.acts = saved_acts; a.act_rows = plan.act_rows(); a.act_pev = plan.act_pev(); a.act_h1 = plan.act_h(1);
     a.act_feature = plan.act_feature(); a.act_hv = plan.act_hv(); a.act_mask = plan.act_mask();
     hipStream_t s = (hipStream_t)stream;
+    snerf::ProfileScope timed(SNERF_PROFILE_MLP_FORWARD, s, a.total);
     if (precision == SNERF_PRECISION_F16X3) return snerf::mlp_forward_f16x3(plan, a, train, 3, s);
     if (precision == SNERF_PRECISION_F16) {
         a.act_rows = plan.act16_rows();  // 16-bit pieces: same row numbers, rows of 64 bytes (mlp_plan.h)

@@ -26,6 +26,18 @@ inline int check_launch(const char* what) {
     return SNERF_OK;
 }
 
+// Opt-in event timing of the dominant kernels (api.hip, snerf_profile_enable): brackets the enclosing scope's launches.
+int profile_begin(int kind, hipStream_t stream, long long samples);
+void profile_end(int slot, hipStream_t stream);
+struct ProfileScope {
+    int slot;
+    hipStream_t stream;
+    ProfileScope(int kind, hipStream_t s, long long samples) : slot(profile_begin(kind, s, samples)), stream(s) {}
+    ~ProfileScope() { profile_end(slot, stream); }
+    ProfileScope(const ProfileScope&) = delete;
+    ProfileScope& operator=(const ProfileScope&) = delete;
+};
+
 // Raise a kernel's dynamic-LDS cap on the CURRENT device, once per device and launch site (device_once.h).
 inline int raise_dynamic_lds(DeviceOnce& once, const void* kernel, int bytes, const char* what) {
     int device = 0;

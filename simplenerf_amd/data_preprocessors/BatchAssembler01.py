@@ -19,10 +19,10 @@ What differs from the reference, by design:
     (default 0), not numpy's global Mersenne Twister; pass ``indices=`` (and ``indices_sparse=``) to replay a given
     order, e.g. the reference's;
   * with several ranks, ``rank``/``world_size`` give each rank a contiguous slice of every batch of the SAME global
-    stream, so the union over ranks is the single-process batch; the returned ``row_segments`` = [(first local row,
-    count, first GLOBAL row)] say where the rank's pixel-ray rows and sparse-depth rows sit in that single-process batch
-    (pixel rows first, then sparse rows), which is what the renderer keys its training draws on -- every ray gets the
-    jitter and density noise it would get in a single-process run, whatever the number of ranks.
+    stream, so the union over ranks is the single-process batch; the returned ``global_rows`` (int64, one per row) say
+    where each of the rank's rows sits in that single-process batch (pixel rows first, then sparse rows), which is what
+    the renderer keys its training draws on -- every ray gets the jitter and density noise it would get in a
+    single-process run, whatever the number of ranks and however the trainer cuts the batch into sub-batches.
 Reference behaviour kept: batches are consecutive slices of the epoch order and the order is renewed when a slice
 reaches the end (:559-563, a short last batch included); a full-image request returns pixel rays only (:564-567);
 during pre-cropping the candidates are the central window (:258-268) -- and stay so for the whole run, because the
@@ -94,19 +94,20 @@ class BatchAssembler:
         return first + lo, min(count, lo + per) - lo, lo
 
     def select_batch_indices(self, iter_num: int, image_num: Optional[int] = None):
-        """-> (indices int64 GPU tensor, number of pixel-ray rows, sparse rows present?, row segments)   (reference :553-584)"""
+        """-> (indices int64 GPU tensor, number of pixel-ray rows, sparse rows present?, (first global pixel row, first global
+        sparse row))   (reference :553-584)"""
         h, w = self.resolution
         if image_num is not None:
             image_index = self.frame_nums.index(int(image_num))
             first, count, lo = self._shard(image_index * h * w, h * w)
-            return torch.arange(first, first + count, dtype=torch.int64, device=self.device), count, False, [(0, count, lo)]
+            return torch.arange(first, first + count, dtype=torch.int64, device=self.device), count, False, (lo, lo + count)
         first, total, self.i_batch, epoch = self._next_slice(self.i_batch, self.epoch, self.num_rays, self.domain)
         first, count, lo = self._shard(first, total)
         indices = ops.shuffled_indices(self.seed, self.epoch, first, count, self.domain, self.device,
                                        num_views=self.num_views, resolution=self.resolution, crop=self.crop)
         self.epoch = epoch
         if not self.sparse_depth_needed:
-            return indices, count, False, [(0, count, lo)]
+            return indices, count, False, (lo, lo + count)
         domain = self.sparse_candidates.shape[0]
         first, total_sd, self.i_batch_sparse_depth, epoch = self._next_slice(self.i_batch_sparse_depth, self.epoch_sparse,
                                                                              self.num_rays_sparse_depth, domain)
@@ -115,7 +116,7 @@ class BatchAssembler:
                                       candidates=self.sparse_candidates)
         self.epoch_sparse = epoch
         # global rows: the single-process batch is [all pixel rows (total) | all sparse rows (total_sd)]
-        return torch.cat([indices, sparse]), count, True, [(0, count, lo), (count, n_sd, total + lo_sd)]
+        return torch.cat([indices, sparse]), count, True, (lo, total + lo_sd)
 
     def get_next_batch(self, iter_num: int, image_num: Optional[int] = None, indices: Optional[Tensor] = None,
                        indices_sparse: Optional[Tensor] = None) -> Dict[str, object]:
@@ -124,17 +125,18 @@ class BatchAssembler:
             num_pixel = indices.shape[0]
             indices = torch.cat([indices, indices_sparse]) if with_sparse else indices
             indices = indices.to(self.device, torch.int64)
-            segments = [(0, indices.shape[0], 0)]
+            first_rows = (0, num_pixel)
         else:
-            indices, num_pixel, with_sparse, segments = self.select_batch_indices(iter_num, image_num)
+            indices, num_pixel, with_sparse, first_rows = self.select_batch_indices(iter_num, image_num)
         sp = self.sparse if with_sparse else {k: None for k in self.sparse}
         batch = ops.assemble_batch(indices, num_pixel, self.table, self.resolution, self.images, self.ndc, self.near, self.far,
                                    self.near_ndc, self.far_ndc, sp['sparse_depths'], sp['sparse_errors'],
-                                   sp['sparse_depths_ndc'] if self.ndc else None, with_sparse_mask=with_sparse)
+                                   sp['sparse_depths_ndc'] if self.ndc else None, with_sparse_mask=with_sparse,
+                                   first_pixel_row=first_rows[0], first_sparse_row=first_rows[1])
         out: Dict[str, object] = {'common_data': {}, 'indices': indices, 'indices_mask_nerf': batch.pop('indices_mask_nerf')}
         if with_sparse:
             out['indices_mask_sparse_depth'] = batch.pop('indices_mask_sparse_depth')
-        out.update(iter_num=iter_num, num_frames=self.num_views, row_segments=segments)
+        out.update(iter_num=iter_num, num_frames=self.num_views)
         out.update(batch)
         # shared tensors with the leading per-GPU axis of the reference (:545-550); a view, not a copy
         out['common_data'] = {'poses': self.poses[None], 'intrinsics': self.intrinsics[None], 'images': self.images[None],

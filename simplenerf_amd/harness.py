@@ -12,7 +12,7 @@ from typing import Dict, Iterable, Optional, Tuple
 import torch
 
 from . import ops
-from .models.SimpleNeRFHip01 import row_segments, slice_row_segments
+from .models.SimpleNeRFHip01 import global_rows
 
 Tensor = torch.Tensor
 DEFAULT_KEYS = ('rgb_fine', 'depth_fine', 'depth_var_fine')
@@ -199,9 +199,9 @@ def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch
     n = input_batch['rays_o'].shape[0]
     sub = int(sub_batch_size or n)
     totals: Dict[str, Tensor] = {}
-    # global rows of this rank's rows (keys of the training draws): one offset, or the assembler's segment list when a
-    # rank holds a pixel-ray shard followed by a sparse-depth shard of the global batch
-    segments = row_segments(input_batch, n)
+    # global rows (keys of the training draws): the batch's per-row ``global_rows`` tensor is sliced with the other
+    # tensors; without it the rows are row_offset + r
+    base = int(input_batch.get('row_offset', 0))
     if single_pass and sub < n:
         whole = dict(input_batch)
         output = model(whole)
@@ -219,7 +219,7 @@ def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch
                     piece[key] = dict(value)
                 else:
                     piece[key] = value
-            piece['row_segments'] = slice_row_segments(segments, start, min(sub, n - start))
+            piece['row_offset'] = base + start
             out_piece = {k: (pieces[k][index] if pieces[k] is not None else v) for k, v in output.items()}
             losses = loss_computer.compute_losses(piece, out_piece)
             objective = losses['TotalLoss'] if objective is None else objective + losses['TotalLoss']
@@ -240,8 +240,7 @@ def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch
                 piece[key] = dict(value)
             else:
                 piece[key] = value
-        piece['row_segments'] = slice_row_segments(segments, start, min(sub, n - start))
-        piece['row_offset'] = piece['row_segments'][0][2]
+        piece['row_offset'] = base + start
         losses = loss_computer.compute_losses(piece, model(piece))
         losses['TotalLoss'].backward()
         for name, entry in losses.items():
@@ -284,6 +283,11 @@ class GraphedTrainStep:
         self.weights_key = None
         self.totals: Dict[str, Tensor] = {}
 
+    @staticmethod
+    def _rows(batch, n):
+        first, rows = global_rows(batch, n)
+        return rows if rows is not None else first
+
     def _weights(self, iter_num):
         return tuple(self.losses.get_loss_weight(cfg, iter_num) for cfg in self.losses.losses.values())
 
@@ -317,7 +321,7 @@ class GraphedTrainStep:
             for p in self.model.parameters():
                 if p.grad is not None:
                     p.grad.zero_()
-            self.model.set_random_draws(self.model.draw_training_randomness(rows, row_segments(batch, rows), self.device))
+            self.model.set_random_draws(self.model.draw_training_randomness(rows, self._rows(batch, rows), self.device))
             piece = dict(batch)
             piece['common_data'] = dict(batch.get('common_data', {}))
             losses = self.losses.compute_losses(piece, self.model(piece))
@@ -326,9 +330,9 @@ class GraphedTrainStep:
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
                 self.static[k].copy_(v)
-            elif k not in ('common_data', 'row_segments', 'row_offset'):    # rows only key the draws, made outside the graph
+            elif k != 'common_data':
                 self.static[k] = v
-        self.model.draw_training_randomness(self.n, row_segments(batch, self.n), self.device, out=self.draws)
+        self.model.draw_training_randomness(self.n, self._rows(batch, self.n), self.device, out=self.draws)
         key = self._weights(batch['iter_num'])
         if self.graph is None or key != self.weights_key:
             self._capture()                    # records the work (on these inputs); nothing is computed until the replay

@@ -20,11 +20,11 @@ Differences from the reference that a caller can observe:
     library's counter-based Philox4x32-10 (snerf_random_uniform / snerf_random_normal) instead of on the CPU
     generator: element (ray, sample) of a draw is a function of (``configs['seed']``, number of training forwards so
     far, kind of draw, GLOBAL row of the ray, sample) only, so a rank that holds a part of a batch draws what a single
-    process would for those rows.  The global rows come from ``input_batch['row_offset']`` (rows are
-    [row_offset, row_offset+n)) or, when a rank's rows are not contiguous in the global batch -- a pixel-ray shard
-    followed by a sparse-depth shard, as ``BatchAssembler`` produces -- from ``input_batch['row_segments']``, a list of
-    (first local row, count, first global row).  ``set_random_draws`` injects explicit draws (used by the parity tests
-    to replay the reference's CPU stream);
+    process would for those rows.  The global rows come from ``input_batch['global_rows']`` (int64 (n,), emitted by
+    ``BatchAssembler``; a per-row tensor, because a rank's rows are a pixel-ray shard followed by a sparse-depth shard of
+    the global batch and because the reference's trainer slices every tensor of the batch into sub-batches,
+    src/Trainer01.py:82-90) or, without it, are ``input_batch.get('row_offset', 0)`` + ray.  ``set_random_draws`` injects
+    explicit draws (used by the parity tests to replay the reference's CPU stream);
   * ``predict_visibility`` (off in every shipped config) is not built;
   * gradients flow from ``rgb_*``, ``acc_*``, ``depth_*``, ``depth_ndc_*`` (incl. the augmentation-prefixed ones) and
     ``raw_sigma_*`` / ``raw_rgb*_*`` to the parameters -- a superset of what the shipped losses read (SURVEY 8a row
@@ -46,48 +46,16 @@ _DRAW_KINDS = ('t_rand', 'u', 'noise_coarse', 'noise_points_augmentation', 'nois
                'noise_points_augmentation_fine', 'noise_views_augmentation_fine')
 
 
-def row_segments(batch: dict, n: int) -> List[tuple]:
-    """[(first local row, count, first global row)] covering rows 0..n of ``batch``: its ``row_segments`` entry if
-    present, else one segment at ``row_offset`` (default 0).  Adjacent segments that are contiguous globally are merged."""
-    segs = batch.get('row_segments')
-    if segs is None:
-        return [(0, n, int(batch.get('row_offset', 0)))]
-    out: List[tuple] = []
-    pos = 0
-    for first, count, glob in segs:
-        first, count, glob = int(first), int(count), int(glob)
-        if first != pos or count < 0:
-            raise RuntimeError(f'row_segments must tile the batch rows in order, got {list(segs)} for {n} rows')
-        pos += count
-        if count == 0:
-            continue
-        if out and out[-1][2] + out[-1][1] == glob:
-            out[-1] = (out[-1][0], out[-1][1] + count, out[-1][2])
-        else:
-            out.append((first, count, glob))
-    if pos != n:
-        raise RuntimeError(f'row_segments cover {pos} rows, the batch has {n}')
-    return out or [(0, 0, 0)]
-
-
-def slice_row_segments(segments: List[tuple], start: int, count: int) -> List[tuple]:
-    """Segments of the sub-batch made of local rows [start, start+count)."""
-    out = []
-    for first, cnt, glob in segments:
-        lo, hi = max(first, start), min(first + cnt, start + count)
-        if hi > lo:
-            out.append((lo - start, hi - lo, glob + lo - first))
-    return out or [(0, 0, 0)]
-
-
-def _draw_segments(fn, segments, shape, device, out, *args):
-    """One keyed draw of ``shape`` whose rows follow ``segments``: a launch per segment into that segment's row block."""
-    if len(segments) == 1:
-        return fn(*args[:2], segments[0][2], shape, device, *args[2:], out=out)
-    target = out if out is not None else torch.empty(tuple(shape), dtype=torch.float32, device=device)
-    for first, count, glob in segments:
-        fn(*args[:2], glob, (count,) + tuple(shape[1:]), device, *args[2:], out=target[first:first + count])
-    return target
+def global_rows(batch: dict, n: int):
+    """(first_row, rows): the global rows of the batch's rays in the single-process batch, which key the training draws.
+    ``batch['global_rows']`` (int64 GPU tensor (n,), e.g. from BatchAssembler -- a per-row tensor, so a trainer that slices
+    sub-batches slices it along) wins; else rows are ``batch['row_offset']`` (default 0) + r."""
+    rows = batch.get('global_rows')
+    if rows is not None:
+        if not isinstance(rows, torch.Tensor) or tuple(rows.shape) != (n,):
+            raise RuntimeError(f"input_batch['global_rows'] must be an int64 tensor of shape ({n},)")
+        return 0, rows
+    return int(batch.get('row_offset', 0)), None
 
 
 class MlpParameters(torch.nn.Module):
@@ -148,40 +116,72 @@ class MlpParameters(torch.nn.Module):
         raise RuntimeError('MlpParameters only holds weights; evaluation happens in the fused HIP kernel')
 
 
-class _ShadeFunction(torch.autograd.Function):
-    """One MLP evaluated on (N,S) samples + compositing, with hand-written backward kernels (K6, K7).
+# C-ABI level order (include/simplenerf_hip.h, enum snerf_render_level): attribute name and output-key prefix
+_LEVELS = (('coarse_model', '', 'coarse'), ('pts_aug_coarse_model', 'points_augmentation_', 'coarse'),
+           ('views_aug_coarse_model', 'views_augmentation_', 'coarse'), ('fine_model', '', 'fine'),
+           ('pts_aug_fine_model', 'points_augmentation_', 'fine'), ('views_aug_fine_model', 'views_augmentation_', 'fine'))
+_NOISE_KEYS = ('noise_coarse', 'noise_points_augmentation', 'noise_views_augmentation', 'noise_fine',
+               'noise_points_augmentation_fine', 'noise_views_augmentation_fine')
+_DIFF_KEYS = ('rgb', 'acc', 'depth', 'depth_ndc', 'sigma', 'raw_rgb')          # outputs with a gradient path
+_PLAIN_KEYS = ('alpha', 'visibility', 'weights', 'depth_var', 'depth_var_ndc')   # returned without one
 
-    forward  = snerf_mlp_forward_train + snerf_composite
-    backward = snerf_composite_backward -> (d sigma, d rgb) -> snerf_mlp_backward -> parameter gradients
-    """
-    COMPOSITE_KEYS = ('rgb', 'acc', 'alpha', 'visibility', 'weights', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc')
+
+class _RenderFunction(torch.autograd.Function):
+    """The whole of render_rays as ONE autograd node: forward = snerf_render_forward (training variant: activations
+    kept), backward = snerf_render_backward (per level: compositing backward K6 -> MLP backward K7).
+
+    Parameter gradients are written by the kernels straight into ``p.grad`` -- overwritten when the parameter has none
+    yet, ADDED to it otherwise (the trainer's second sub-batch, src/Trainer01.py:82-96) -- instead of being returned for
+    autograd to accumulate with one add launch per tensor; the Function therefore returns None for its parameter inputs.
+    ``model.return_param_grads = True`` restores the plain autograd contract (needed for torch.autograd.grad)."""
 
     @staticmethod
-    def forward(ctx, packed, precision, ndc, white, march_o, march_d, view_dirs, depths, noise, rays_o, rays_d, *params):
-        sigma, rgb, saved = packed.forward_train(march_o, march_d, view_dirs, depths, noise, precision)
-        comp = ops.composite(sigma, rgb, depths, march_d, ndc, white, rays_o, rays_d)
-        ctx.packed, ctx.ndc, ctx.white, ctx.precision = packed, ndc, white, precision
-        ctx.param_shapes = [tuple(p.shape) for p in params]
-        ctx.save_for_backward(sigma, rgb, saved, depths, march_d, rays_o, rays_d)
-        outs = [comp.get(k) for k in _ShadeFunction.COMPOSITE_KEYS if k in comp]
-        ctx.keys = [k for k in _ShadeFunction.COMPOSITE_KEYS if k in comp] + ['sigma', 'rgb_raw']
-        no_grad = [comp[k] for k in ('alpha', 'visibility', 'weights', 'depth_var', 'depth_var_ndc') if k in comp]
-        ctx.mark_non_differentiable(*no_grad)
+    def forward(ctx, model, call, rays, draws, *params):
+        z_coarse, z_fine, out = call.forward(rays, draws)
+        ctx.model, ctx.call = model, call
+        ctx.layout = []
+        flat, plain = [], []
+        for level in call.levels:
+            d = out[level]
+            for k in _DIFF_KEYS:
+                if k in d:
+                    ctx.layout.append((level, k))
+                    flat.append(d[k])
+            plain += [d[k] for k in _PLAIN_KEYS if k in d]
+        plain += [z_coarse] + ([z_fine] if z_fine is not None and draws.get('z_vals_fine') is None else [])
+        ctx.mark_non_differentiable(*plain)
         ctx.set_materialize_grads(False)
-        return tuple(outs) + (sigma, rgb)
+        ctx.num_plain = len(plain)
+        return tuple(flat) + tuple(plain)
 
     @staticmethod
     def backward(ctx, *grad_outputs):
-        sigma, rgb, saved, depths, march_d, rays_o, rays_d = ctx.saved_tensors
-        g = dict(zip(ctx.keys, grad_outputs))
-        d_sigma, d_rgb = ops.composite_backward(sigma, rgb, depths, march_d, ctx.ndc, ctx.white, rays_o, rays_d,
-                                                g.get('rgb'), g.get('acc'), g.get('depth'), g.get('depth_ndc'))
-        if g.get('sigma') is not None:
-            d_sigma = d_sigma + g['sigma'].reshape(d_sigma.shape)
-        if g.get('rgb_raw') is not None:
-            d_rgb = d_rgb + g['rgb_raw']
-        grads = ctx.packed.backward(saved, sigma, rgb, d_sigma, d_rgb, ctx.param_shapes, ctx.precision)
-        return (None,) * 11 + tuple(grads)
+        call, model = ctx.call, ctx.model
+        grads: Dict[int, Dict[str, Tensor]] = {}
+        for (level, key), g in zip(ctx.layout, grad_outputs):
+            if g is not None:
+                grads.setdefault(level, {})[key] = g
+        direct = not model.return_param_grads
+        param_grads, accumulate, returned = {}, {}, []
+        for level in call.levels:
+            params = getattr(model, _LEVELS[level][0]).abi_params()
+            if level not in grads or not any(p.requires_grad for p in params):
+                returned += [None] * len(params)
+                continue
+            if direct and all(p.grad is not None for p in params):
+                param_grads[level], accumulate[level] = [p.grad for p in params], True
+            else:
+                param_grads[level] = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in params]
+                accumulate[level] = False
+            returned += [None] * len(params) if direct else param_grads[level]
+        call.backward(grads, param_grads, accumulate)
+        if direct:
+            for level, tensors in param_grads.items():
+                if not accumulate[level]:
+                    for p, g in zip(getattr(model, _LEVELS[level][0]).abi_params(), tensors):
+                        if p.requires_grad:
+                            p.grad = g if p.grad is None else p.grad.add_(g)
+        return (None, None, None, None) + tuple(returned)
 
 
 class SimpleNeRFHip(torch.nn.Module):
@@ -214,6 +214,9 @@ class SimpleNeRFHip(torch.nn.Module):
         self._draws: Optional[dict] = None
         self.seed = int(configs.get('seed', 0))
         self._train_calls = 0   # training-mode forwards so far: selects the Philox stream of each draw
+        # False (default): the backward kernels write / accumulate parameter gradients straight into ``p.grad``;
+        # True: they are returned to autograd (torch.autograd.grad, hooks), which then accumulates them itself
+        self.return_param_grads = bool(mcfg.get('hip_return_param_grads', False))
 
     # ------------------------------------------------------------------------------------------
     def set_random_draws(self, draws: Optional[dict]) -> None:
@@ -257,20 +260,20 @@ class SimpleNeRFHip(torch.nn.Module):
     def draw_training_randomness(self, n: int, row_offset, device, out: Optional[Dict[str, Tensor]] = None
                                  ) -> Dict[str, Tensor]:
         """The draws the next training-mode forward would make itself, produced up front (and counted as that forward's):
-        pass the result to ``set_random_draws``.  ``row_offset``: the first global row (int) or a ``row_segments`` list.
-        ``out`` supplies pre-allocated tensors to fill (static graph inputs)."""
+        pass the result to ``set_random_draws``.  ``row_offset``: the first global row (int) or the batch's
+        ``global_rows`` tensor.  ``out`` supplies pre-allocated tensors to fill (static graph inputs)."""
         call = self._train_calls
         self._train_calls += 1
         noise_std = float(self.configs['model']['raw_noise_std'])
-        segments = row_segments({'row_segments': row_offset}, n) if isinstance(row_offset, (list, tuple)) else [(0, n, int(row_offset))]
+        first, rows = (0, row_offset) if isinstance(row_offset, torch.Tensor) else (int(row_offset), None)
         draws = {}
         for key, shape in self.training_draw_shapes(n).items():
             stream = call * len(_DRAW_KINDS) + _DRAW_KINDS.index(key)
             target = None if out is None else out[key]
             if key.startswith('noise'):
-                draws[key] = _draw_segments(ops.random_normal, segments, shape, device, target, self.seed, stream, noise_std)
+                draws[key] = ops.random_normal(self.seed, stream, first, shape, device, noise_std, out=target, rows=rows)
             else:
-                draws[key] = _draw_segments(ops.random_uniform, segments, shape, device, target, self.seed, stream)
+                draws[key] = ops.random_uniform(self.seed, stream, first, shape, device, out=target, rows=rows)
         return draws
 
     def _packed_mlp(self, name: str) -> ops.PackedMlp:
@@ -294,85 +297,101 @@ class SimpleNeRFHip(torch.nn.Module):
         retraw = retraw or training
         with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         mcfg = self.configs['model']
-        rays_o, rays_d = batch['rays_o'], batch['rays_d']
-        if self.ndc:
-            march_o, march_d = batch['rays_o_ndc'], batch['rays_d_ndc']
-            near, far = batch['near_ndc'], batch['far_ndc']
-        else:
-            march_o, march_d = rays_o, rays_d
-            near, far = batch['near'], batch['far']
-        need_dirs = mcfg['coarse_mlp']['use_view_dirs'] or (self.fine_mlp_needed and mcfg['fine_mlp']['use_view_dirs'])
-        view_dirs = batch['view_dirs'] if need_dirs else batch.get('view_dirs')
+        rays_o = batch['rays_o']
         n = rays_o.shape[0]
         dev = rays_o.device
-        draws = self._draws
+        injected = self._draws
         self._draws = None
         noise_std = float(mcfg['raw_noise_std'])
         perturb = bool(mcfg['perturb'] > 0.) and training
-
-        segments = row_segments(batch, n) if training else None
-        call = self._train_calls
-        if training and draws is None:
+        first_row, rows = global_rows(batch, n) if training else (0, None)
+        call_index = self._train_calls
+        if training and injected is None:
             self._train_calls += 1
+
+        # which of the six MLPs take part: the augmentation models run in training mode only (:170-199, :234-263)
+        present = [None] * 6
+        present[0] = 'coarse_model'
+        if self.fine_mlp_needed:
+            present[3] = 'fine_model'
+        if training:
+            for prefix, level, name in self._train_only:
+                if level == 'coarse' or self.fine_mlp_needed:
+                    present[[row[0] for row in _LEVELS].index(name)] = name
+        s_c = mcfg['coarse_mlp']['num_samples']
+        s_f = mcfg['fine_mlp']['num_samples'] if self.fine_mlp_needed else 0
 
         def draw(key, shape, normal):
             if not training:
                 return None
-            if draws is not None:
-                t = draws.get(key)
+            if injected is not None:
+                t = injected.get(key)
                 return None if t is None else t.to(dev)
-            stream = call * len(_DRAW_KINDS) + _DRAW_KINDS.index(key)
+            stream = call_index * len(_DRAW_KINDS) + _DRAW_KINDS.index(key)
             if normal:
-                return _draw_segments(ops.random_normal, segments, shape, dev, None, self.seed, stream, noise_std) \
-                    if noise_std > 0. else None
-            return _draw_segments(ops.random_uniform, segments, shape, dev, None, self.seed, stream) if perturb else None
+                return ops.random_normal(self.seed, stream, first_row, shape, dev, noise_std, rows=rows) if noise_std > 0. else None
+            return ops.random_uniform(self.seed, stream, first_row, shape, dev, rows=rows) if perturb else None
+
+        # draws in the reference's consumption order (A.3): jitter, coarse-level noises, u, fine-level noises
+        draws: dict = {'t_rand': draw('t_rand', (n, s_c), False)}
+        for level in (0, 1, 2):
+            if present[level]:
+                draws[('noise', level)] = draw(_NOISE_KEYS[level], (n, s_c, 1), True)
+        if self.fine_mlp_needed:
+            override = injected.get('z_vals_fine') if injected is not None else None
+            if override is not None:
+                draws['z_vals_fine'] = override.to(dev)
+            else:
+                draws['u'] = draw('u', (n, s_f), False)
+            for level in (3, 4, 5):
+                if present[level]:
+                    draws[('noise', level)] = draw(_NOISE_KEYS[level], (n, s_c + s_f, 1), True)
+
+        packed = [self._packed_mlp(name) if name else None for name in present]
+        per_sample = ('alpha', 'visibility', 'weights') if retraw else ('alpha',)
+        call = ops.RenderCall(packed, self.ndc, bool(mcfg['white_bkgd']), bool(mcfg['lindisp']), s_c, s_f, self.precision,
+                              keep_activations=with_grad, per_sample=per_sample)
+        if with_grad:
+            params = [p for name in present if name for p in getattr(self, name).abi_params()]
+            res = _RenderFunction.apply(self, call, batch, draws, *params)
+            out_levels, it = {}, iter(res)
+            for level in call.levels:
+                out_levels[level] = {k: next(it) for k in _DIFF_KEYS if self.ndc or k != 'depth_ndc'}
+            for level in call.levels:
+                for k in _PLAIN_KEYS:
+                    if (k in per_sample or k.startswith('depth_var')) and (self.ndc or not k.endswith('_ndc')):
+                        out_levels[level][k] = next(it)
+            z_coarse = next(it)
+            z_fine = draws['z_vals_fine'] if 'z_vals_fine' in draws else (next(it) if self.fine_mlp_needed else None)
+        else:
+            z_coarse, z_fine, out_levels = call.forward(batch, draws)
 
         out: Dict[str, Tensor] = {}
 
-        def shade(name, prefix, level, depths, noise_key):
-            s = depths.shape[1]
-            packed = self._packed_mlp(name)
-            noise = draw(noise_key, (n, s, 1), True)
-            if with_grad:
-                res = _ShadeFunction.apply(packed, self.precision, self.ndc, bool(mcfg['white_bkgd']), march_o, march_d, view_dirs, depths,
-                                           noise, rays_o, rays_d, *getattr(self, name).abi_params())
-                keys = [k for k in _ShadeFunction.COMPOSITE_KEYS if self.ndc or not k.endswith('_ndc')]
-                comp = dict(zip(keys, res[:len(keys)]))
-                sigma, rgb = res[len(keys)], res[len(keys) + 1]
-            else:
-                sigma, rgb = packed.forward(march_o, march_d, view_dirs, depths, noise, self.precision)
-                comp = ops.composite(sigma, rgb, depths, march_d, self.ndc, mcfg['white_bkgd'], rays_o, rays_d)
+        def emit(level):
+            _, prefix, tag = _LEVELS[level]
+            d = out_levels[level]
             # key order as volume_rendering's return_dict (:465-477)
             for k in ('rgb', 'acc', 'alpha', 'visibility', 'weights', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc'):
-                if k in comp:
-                    out[f'{prefix}{k}_{level}'] = comp[k]
+                if k in d:
+                    out[f'{prefix}{k}_{tag}'] = d[k]
             if retraw:
-                out[f'{prefix}raw_sigma_{level}'] = sigma
-                variant = 'rgb_view_dependent' if packed.use_view_dirs else 'rgb_view_independent'
-                out[f'{prefix}raw_{variant}_{level}'] = rgb
-                out[f'{prefix}raw_rgb_{level}'] = rgb
-            return comp
+                out[f'{prefix}raw_sigma_{tag}'] = d['sigma']
+                variant = 'rgb_view_dependent' if packed[level].use_view_dirs else 'rgb_view_independent'
+                out[f'{prefix}raw_{variant}_{tag}'] = d['raw_rgb']
+                out[f'{prefix}raw_rgb_{tag}'] = d['raw_rgb']
 
-        s_c = mcfg['coarse_mlp']['num_samples']
-        z_coarse = ops.coarse_depths(near, far, s_c, mcfg['lindisp'], draw('t_rand', (n, s_c), False))
-        comp_c = shade('coarse_model', '', 'coarse', z_coarse, 'noise_coarse')
+        emit(0)
         out['z_vals_coarse'] = z_coarse
-        if training:
-            for prefix, level, name in self._train_only:
-                if level == 'coarse':
-                    shade(name, prefix, 'coarse', z_coarse, f'noise_{prefix[:-1]}')
+        for level in (1, 2):
+            if present[level]:
+                emit(level)
         if self.fine_mlp_needed:
-            s_f = mcfg['fine_mlp']['num_samples']
-            if draws is not None and draws.get('z_vals_fine') is not None:
-                z_fine = draws['z_vals_fine'].to(dev)
-            else:
-                z_fine = ops.resample_depths(z_coarse, comp_c['weights'].detach(), s_f, draw('u', (n, s_f), False))
-            shade('fine_model', '', 'fine', z_fine, 'noise_fine')
+            emit(3)
             out['z_vals_fine'] = z_fine
-            if training:
-                for prefix, level, name in self._train_only:
-                    if level == 'fine':
-                        shade(name, prefix, 'fine', z_fine, f'noise_{prefix[:-1]}_fine')
+            for level in (4, 5):
+                if present[level]:
+                    emit(level)
         if not retraw:
             for level in ('coarse', 'fine'):
                 for k in ('z_vals', 'visibility', 'weights'):

@@ -42,6 +42,32 @@ def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+# ---------------------------------------------------------------------------------------------- measurement hook
+PROFILE_MLP_FORWARD, PROFILE_MLP_BACKWARD = 0, 1
+
+
+def profile_enable(capacity: int) -> None:
+    """Start (capacity > 0) or stop (0) the library's event timing of its MLP forward launches / backward calls
+    (snerf_profile_enable): the events are recorded by the library on the stream each launch is enqueued on, also for
+    launches issued from inside the one-call render ops."""
+    _lib.check(_lib.load().snerf_profile_enable(int(capacity)), 'snerf_profile_enable')
+
+
+def profile_reset() -> None:
+    _lib.check(_lib.load().snerf_profile_reset(), 'snerf_profile_reset')
+
+
+def profile_collect(kind: int, capacity: int = 65536):
+    """-> (milliseconds, samples): per recorded launch of ``kind`` its duration and its number of (ray, sample) rows.
+    Waits for the events."""
+    ms = (ctypes.c_float * capacity)()
+    samples = (ctypes.c_longlong * capacity)()
+    count = _lib.load().snerf_profile_collect(int(kind), ms, samples, capacity)
+    if count < 0:
+        _lib.check(count, 'snerf_profile_collect')
+    return list(ms[:count]), list(samples[:count])
+
+
 # ---------------------------------------------------------------------------------------------- K1
 def generate_rays(resolution, intrinsic, pose, near: float, ndc: bool, device, first_ray: int = 0,
                   num_rays: Optional[int] = None, pixel_offset: float = 0.0) -> Dict[str, Tensor]:
@@ -102,10 +128,6 @@ def mlp_desc(mlp_cfg: dict) -> MlpDesc:
 class PackedMlp:
     """Device-resident packed weight stream of one MLP (see csrc/mlp_layout.h)."""
 
-    # When set to a list, every forward() brackets its kernel launch with a pair of events recorded on the launch
-    # stream and appends (start, end, num_samples) -- bench.py uses this to time the dominant kernel in situ.
-    event_log = None
-    backward_event_log = None   # same for backward(): (start, end, num_samples) around the whole snerf_mlp_backward call
 
     def __init__(self, mlp_cfg: dict, device):
         lib = _lib.load()
@@ -147,17 +169,10 @@ class PackedMlp:
         rgb = torch.empty((n, s, 3), dtype=torch.float32, device=depths.device)
         if n == 0:
             return sigma, rgb
-        log = PackedMlp.event_log
         with torch.cuda.device(depths.device):
-            if log is not None:
-                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0.record()
             st = lib.snerf_mlp_forward(ctypes.byref(self.desc), _ptr(self.buffer), _ptr(origins), _ptr(dirs),
                                        _ptr(view_dirs), _ptr(depths), n, s, _ptr(sigma_noise), _ptr(sigma), _ptr(rgb),
                                        int(precision), _stream())
-            if log is not None:
-                t1.record()
-                log.append((t0, t1, n * s))
         _lib.check(st, 'snerf_mlp_forward')
         return sigma, rgb
 
@@ -182,23 +197,17 @@ class PackedMlp:
         saved = torch.empty(lib.snerf_mlp_saved_floats(ctypes.byref(self.desc), n, s), dtype=torch.float32, device=dev)
         if n == 0:
             return sigma, rgb, saved
-        log = PackedMlp.event_log
         with torch.cuda.device(dev):
-            if log is not None:
-                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0.record()
             st = lib.snerf_mlp_forward_train(ctypes.byref(self.desc), _ptr(self.buffer), _ptr(origins), _ptr(dirs),
                                              _ptr(view_dirs), _ptr(depths), n, s, _ptr(sigma_noise), _ptr(sigma), _ptr(rgb),
                                              _ptr(saved), int(precision), _stream())
-            if log is not None:
-                t1.record()
-                log.append((t0, t1, n * s))
         _lib.check(st, 'snerf_mlp_forward_train')
         return sigma, rgb, saved
 
     def backward(self, saved: Tensor, sigma: Tensor, rgb: Tensor, d_sigma: Tensor, d_rgb: Tensor,
-                 param_shapes: List[tuple], precision: int = 0) -> List[Tensor]:
-        """dL/dparam for every parameter (C-ABI order), given dL/dsigma (n,S[,1]) and dL/drgb (n,S,3)."""
+                 param_shapes: List[tuple], precision: int = 0, into: Optional[List[Tensor]] = None) -> List[Tensor]:
+        """dL/dparam for every parameter (C-ABI order), given dL/dsigma (n,S[,1]) and dL/drgb (n,S,3).  ``into``: existing
+        gradient tensors to ADD to (the kernel accumulates; no separate add launches) instead of fresh ones."""
         lib = _lib.load()
         n, s = sigma.shape[0], sigma.shape[1]
         dev = sigma.device
@@ -209,24 +218,195 @@ class PackedMlp:
         if len(param_shapes) != self.num_params:
             raise RuntimeError(f'expected {self.num_params} parameter shapes, got {len(param_shapes)}')
         if n == 0:
-            return [torch.zeros(tuple(shape), dtype=torch.float32, device=dev) for shape in param_shapes]
-        grads = [torch.empty(tuple(shape), dtype=torch.float32, device=dev) for shape in param_shapes]
+            return into if into is not None else [torch.zeros(tuple(shape), dtype=torch.float32, device=dev) for shape in param_shapes]
+        if into is not None:
+            for g, shape in zip(into, param_shapes):
+                if tuple(g.shape) != tuple(shape) or g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous():
+                    raise RuntimeError(f'backward(into=...): expected a contiguous float32 GPU tensor of shape {tuple(shape)}')
+        grads = into if into is not None else [torch.empty(tuple(shape), dtype=torch.float32, device=dev) for shape in param_shapes]
         work = torch.empty(lib.snerf_mlp_backward_workspace_floats(ctypes.byref(self.desc), n, s), dtype=torch.float32,
                            device=dev)
         arr = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
-        log = PackedMlp.backward_event_log
         with torch.cuda.device(dev):
-            if log is not None:
-                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0.record()
             st = lib.snerf_mlp_backward(ctypes.byref(self.desc), _ptr(self.buffer), _ptr(saved), _ptr(sigma), _ptr(rgb),
                                         _ptr(d_sigma), _ptr(d_rgb), n, s, _ptr(work), arr, len(grads), int(precision),
-                                        _stream())
-            if log is not None:
-                t1.record()
-                log.append((t0, t1, n * s))
+                                        int(into is not None), _stream())
         _lib.check(st, 'snerf_mlp_backward')
         return grads
+
+
+# ---------------------------------------------------------------------------------------------- one-call render ops
+class RenderCall:
+    """One ``snerf_render_forward`` (and, for training, its ``snerf_render_backward``): the whole of SimpleNeRF.render_rays
+    (src/models/SimpleNeRF01.py:108-270) enqueued by ONE call into the library.  Output tensors are carved out of three
+    allocations -- per-ray outputs, per-sample outputs, and (training) one saved-activation buffer per level -- instead
+    of ~20 separate ones.
+
+    ``mlps``: six entries (C-ABI level order: main / points-aug / views-aug at the coarse level, then at the fine level),
+    ``PackedMlp`` or None.  ``rays``: the reference's input_batch tensors.  ``draws``: t_rand, u, per-level sigma noise,
+    optional fine-depth override.  ``per_sample``: which (n,S) composite outputs to produce ('alpha', 'visibility',
+    'weights')."""
+
+    PER_RAY = (('rgb', 3), ('acc', 1), ('depth', 1), ('depth_var', 1), ('depth_ndc', 1), ('depth_var_ndc', 1))
+
+    def __init__(self, mlps: List[Optional['PackedMlp']], ndc: bool, white_bkgd: bool, lindisp: bool, num_coarse: int,
+                 num_fine: int, precision: int, keep_activations: bool, per_sample=('alpha',)):
+        lib = _lib.load()
+        self.lib = lib
+        self.mlps = list(mlps) + [None] * (_lib.RENDER_LEVELS - len(mlps))
+        self.ndc, self.keep = bool(ndc), bool(keep_activations)
+        self.num_coarse, self.num_fine = int(num_coarse), int(num_fine) if self.mlps[3] is not None else 0
+        self.cfg = _lib.RenderConfig(int(bool(ndc)), int(bool(white_bkgd)), int(bool(lindisp)), self.num_coarse, self.num_fine,
+                                     int(precision), int(self.keep))
+        self.c_mlps = (_lib.RenderMlp * _lib.RENDER_LEVELS)()
+        for l, m in enumerate(self.mlps):
+            if m is not None:
+                self.c_mlps[l].desc = ctypes.pointer(m.desc)
+                self.c_mlps[l].packed = m.buffer.data_ptr()
+        self.per_sample = tuple(per_sample)
+        self.levels = [l for l, m in enumerate(self.mlps) if m is not None]
+        self.c_rays = _lib.RenderRays()
+        self.c_out = _lib.RenderOutputs()
+        self.held: list = []      # tensors whose pointers sit in the structs
+
+    def samples(self, level: int) -> int:
+        return self.num_coarse if level < 3 else self.num_coarse + self.num_fine
+
+    def forward(self, rays: Dict[str, Tensor], draws: Dict[str, Optional[Tensor]]):
+        """-> (z_vals_coarse, z_vals_fine or None, {level: {name: tensor}})"""
+        lib = self.lib
+        n = rays['rays_o'].shape[0]
+        dev = rays['rays_o'].device
+        self.n, self.device = n, dev
+        r = self.c_rays
+        held = self.held = []
+
+        def put(name, t, shape):
+            t = _dev(t, name, shape)
+            held.append(t)
+            return 0 if t is None else t.data_ptr()
+
+        r.rays_o, r.rays_d = put('rays_o', rays['rays_o'], (n, 3)), put('rays_d', rays['rays_d'], (n, 3))
+        need_dirs = any(self.mlps[l].desc.use_view_dirs for l in self.levels)
+        if need_dirs and rays.get('view_dirs') is None:
+            raise KeyError('view_dirs')
+        r.view_dirs = put('view_dirs', rays.get('view_dirs'), (n, 3)) if need_dirs else 0
+        if self.ndc:
+            r.rays_o_ndc, r.rays_d_ndc = put('rays_o_ndc', rays['rays_o_ndc'], (n, 3)), put('rays_d_ndc', rays['rays_d_ndc'], (n, 3))
+            near, far = rays['near_ndc'], rays['far_ndc']
+        else:
+            r.rays_o_ndc = r.rays_d_ndc = 0
+            near, far = rays['near'], rays['far']
+        r.near, r.far = put('near', near.reshape(-1), (n,)), put('far', far.reshape(-1), (n,))
+        r.t_rand = put('t_rand', draws.get('t_rand'), (n, self.num_coarse))
+        r.u = put('u', draws.get('u'), (n, self.num_fine)) if self.num_fine else 0
+        for l in range(_lib.RENDER_LEVELS):
+            noise = draws.get(('noise', l)) if l in self.levels else None
+            r.sigma_noise[l] = put('sigma_noise', None if noise is None else noise.reshape(n, self.samples(l)), (n, self.samples(l)))
+        override = draws.get('z_vals_fine') if self.num_fine else None
+        r.depths_fine = put('z_vals_fine', override, (n, self.num_coarse + self.num_fine))
+
+        # ---- outputs: one allocation per group, views carved out of it
+        per_ray = [(name, width) for name, width in self.PER_RAY if self.ndc or not name.endswith('_ndc')]
+        ray_floats = sum(w for _, w in per_ray) * n * len(self.levels)
+        sample_floats = n * self.num_coarse + (n * (self.num_coarse + self.num_fine) if self.num_fine and override is None else 0)
+        for l in self.levels:
+            sample_floats += n * self.samples(l) * (4 + len(self.per_sample))
+        small = torch.empty((ray_floats,), dtype=torch.float32, device=dev)
+        big = torch.empty((sample_floats,), dtype=torch.float32, device=dev)
+        pos = {'small': 0, 'big': 0}
+
+        def carve(pool, name, shape):
+            buf = small if pool == 'small' else big
+            size = 1
+            for d in shape:
+                size *= d
+            t = buf[pos[pool]:pos[pool] + size].view(shape)
+            pos[pool] += size
+            return t
+
+        o = self.c_out
+        z_coarse = carve('big', 'z', (n, self.num_coarse))
+        o.depths_coarse = z_coarse.data_ptr()
+        z_fine = None
+        if self.num_fine:
+            z_fine = held[-1] if override is not None else carve('big', 'z', (n, self.num_coarse + self.num_fine))
+            o.depths_fine = 0 if override is not None else z_fine.data_ptr()
+        out: Dict[int, Dict[str, Tensor]] = {}
+        for l in range(_lib.RENDER_LEVELS):
+            lo = o.level[l]
+            if l not in self.levels:
+                for f in _lib.LEVEL_OUT_FIELDS:
+                    setattr(lo, f, 0)
+                continue
+            s = self.samples(l)
+            d = out[l] = {}
+            for name, width in per_ray:
+                d[name] = carve('small', name, (n, 3) if width == 3 else (n,))
+                setattr(lo, name, d[name].data_ptr())
+            if not self.ndc:
+                lo.depth_ndc = lo.depth_var_ndc = 0
+            for name in ('alpha', 'visibility', 'weights'):
+                if name in self.per_sample:
+                    d[name] = carve('big', name, (n, s))
+                    setattr(lo, name, d[name].data_ptr())
+                else:
+                    setattr(lo, name, 0)
+            d['sigma'], d['raw_rgb'] = carve('big', 'sigma', (n, s, 1)), carve('big', 'raw_rgb', (n, s, 3))
+            lo.sigma, lo.raw_rgb = d['sigma'].data_ptr(), d['raw_rgb'].data_ptr()
+            if self.keep:
+                d['saved'] = torch.empty((lib.snerf_mlp_saved_floats(ctypes.byref(self.mlps[l].desc), n, s),), dtype=torch.float32, device=dev)
+                lo.saved_acts = d['saved'].data_ptr()
+            else:
+                lo.saved_acts = 0
+        work = None
+        if self.num_fine and override is None and 'weights' not in self.per_sample:
+            work = torch.empty((lib.snerf_render_workspace_floats(ctypes.byref(self.cfg), n),), dtype=torch.float32, device=dev)
+        if n > 0:
+            with torch.cuda.device(dev):
+                st = lib.snerf_render_forward(ctypes.byref(self.cfg), self.c_mlps, ctypes.byref(r), n, ctypes.byref(o), _ptr(work),
+                                              _stream())
+            _lib.check(st, 'snerf_render_forward')
+        self.z_coarse, self.z_fine, self.out = z_coarse, z_fine, out
+        return z_coarse, z_fine, out
+
+    def backward(self, grads: Dict[int, Dict[str, Optional[Tensor]]], param_grads: Dict[int, List[Tensor]],
+                 accumulate: Dict[int, bool]) -> None:
+        """``grads[level]``: dL/d(rgb, acc, depth, depth_ndc, sigma, raw_rgb) (missing/None = zero);
+        ``param_grads[level]``: the level's gradient tensors in C-ABI order, overwritten or (``accumulate[level]``) added to."""
+        lib = self.lib
+        n, dev = self.n, self.device
+        if n == 0:
+            return
+        c_grads = (_lib.RenderLevelGrads * _lib.RENDER_LEVELS)()
+        keep = []
+        for l in self.levels:
+            g = grads.get(l) or {}
+            if l not in param_grads or not any(g.get(k) is not None for k in ('rgb', 'acc', 'depth', 'depth_ndc', 'sigma', 'raw_rgb')):
+                continue
+            s = self.samples(l)
+            cg = c_grads[l]
+            for name, shape in (('rgb', (n, 3)), ('acc', (n,)), ('depth', (n,)), ('depth_ndc', (n,)), ('sigma', (n, s, 1)),
+                                ('raw_rgb', (n, s, 3))):
+                t = g.get(name)
+                if t is not None:
+                    t = _dev(t.reshape(shape), f'grad {name}', shape)
+                    keep.append(t)
+                setattr(cg, name, 0 if t is None else t.data_ptr())
+            tensors = param_grads[l]
+            if len(tensors) != self.mlps[l].num_params:
+                raise RuntimeError(f'level {l}: expected {self.mlps[l].num_params} gradient tensors, got {len(tensors)}')
+            arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+            keep.append(arr)
+            cg.param_grads = arr
+            cg.num_params = len(tensors)
+            cg.accumulate = int(bool(accumulate.get(l, False)))
+        work = torch.empty((lib.snerf_render_backward_workspace_floats(ctypes.byref(self.cfg), self.c_mlps, n),),
+                           dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = lib.snerf_render_backward(ctypes.byref(self.cfg), self.c_mlps, ctypes.byref(self.c_rays), n,
+                                           ctypes.byref(self.c_out), c_grads, _ptr(work), _stream())
+        _lib.check(st, 'snerf_render_backward')
 
 
 # ---------------------------------------------------------------------------------------------- K4
@@ -499,9 +679,12 @@ def camera_table(intrinsics: Tensor, poses: Tensor, resolution) -> Tensor:
 def assemble_batch(indices: Tensor, num_pixel_rays: int, table: Tensor, resolution, images: Tensor, ndc: bool, near: float,
                    far: float, near_ndc: float = 0.0, far_ndc: float = 1.0, sparse_depths: Optional[Tensor] = None,
                    sparse_errors: Optional[Tensor] = None, sparse_depths_ndc: Optional[Tensor] = None,
-                   with_sparse_mask: bool = False) -> Dict[str, Tensor]:
+                   with_sparse_mask: bool = False, first_pixel_row: int = 0, first_sparse_row: Optional[int] = None
+                   ) -> Dict[str, Tensor]:
     """One launch: rays (+NDC), view_dirs, pixel_id, target_rgb, near/far columns, sparse-depth columns and the row
-    masks for the global pixel ``indices`` (int64 GPU tensor); the first ``num_pixel_rays`` rows are pixel rays."""
+    masks for the global pixel ``indices`` (int64 GPU tensor); the first ``num_pixel_rays`` rows are pixel rays.
+    ``global_rows`` (int64, (n,)) numbers the rows as the single-process batch would: ``first_pixel_row + i`` for pixel
+    rows, ``first_sparse_row + j`` for sparse rows (default: right behind this call's pixel rows)."""
     lib = _lib.load()
     if not indices.is_cuda or indices.dtype != torch.int64 or indices.dim() != 1:
         raise RuntimeError(f'indices: expected a 1-D int64 GPU tensor, got {indices.dtype} {tuple(indices.shape)} on {indices.device}')
@@ -516,7 +699,8 @@ def assemble_batch(indices: Tensor, num_pixel_rays: int, table: Tensor, resoluti
     f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     out = {'rays_o': f(n, 3), 'rays_d': f(n, 3), 'view_dirs': f(n, 3),
            'pixel_id': torch.empty((n, 3), dtype=torch.int32, device=dev), 'target_rgb': f(n, 3), 'near': f(n, 1), 'far': f(n, 1),
-           'indices_mask_nerf': torch.empty((n,), dtype=torch.bool, device=dev)}
+           'indices_mask_nerf': torch.empty((n,), dtype=torch.bool, device=dev),
+           'global_rows': torch.empty((n,), dtype=torch.int64, device=dev)}
     if ndc:
         out.update(rays_o_ndc=f(n, 3), rays_d_ndc=f(n, 3), near_ndc=f(n, 1), far_ndc=f(n, 1))
     for key, t in zip(('sparse_depth_values', 'sparse_depth_errors', 'sparse_depth_values_ndc'), tables):
@@ -532,12 +716,14 @@ def assemble_batch(indices: Tensor, num_pixel_rays: int, table: Tensor, resoluti
                        ('far', 'far'), ('near_ndc', 'near_ndc'), ('far_ndc', 'far_ndc'),
                        ('sparse_depth_values', 'sparse_depth_values'), ('sparse_depth_errors', 'sparse_depth_errors'),
                        ('sparse_depth_values_ndc', 'sparse_depth_values_ndc'), ('mask_pixel_rays', 'indices_mask_nerf'),
-                       ('mask_sparse_rays', 'indices_mask_sparse_depth')):
+                       ('mask_sparse_rays', 'indices_mask_sparse_depth'), ('global_rows', 'global_rows')):
         setattr(b, field, out[key].data_ptr() if key in out else None)
     with torch.cuda.device(dev):
         st = lib.snerf_assemble_batch(ctypes.c_void_p(indices.data_ptr()), n, int(num_pixel_rays), _ptr(table), v, h, w,
                                       _ptr(images), _ptr(tables[0]), _ptr(tables[1]), _ptr(tables[2]), int(ndc), float(near),
-                                      float(far), float(near_ndc), float(far_ndc), ctypes.byref(b), _stream())
+                                      float(far), float(near_ndc), float(far_ndc), int(first_pixel_row),
+                                      int(first_pixel_row + num_pixel_rays if first_sparse_row is None else first_sparse_row),
+                                      ctypes.byref(b), _stream())
     _lib.check(st, 'snerf_assemble_batch')
     return out
 
@@ -572,32 +758,46 @@ def _draw_target(shape, device, out: Optional[Tensor]) -> Tensor:
     return out
 
 
-def random_uniform(seed: int, stream_id: int, first_row: int, shape, device, out: Optional[Tensor] = None) -> Tensor:
-    """[0,1) Philox draws of shape (rows, width...); element (r, c) depends only on (seed, stream_id, first_row + r, c).
+def _row_ids(rows: Optional[Tensor], count: int) -> Optional[Tensor]:
+    if rows is None:
+        return None
+    if not rows.is_cuda or rows.dtype != torch.int64 or tuple(rows.shape) != (count,):
+        raise RuntimeError(f'global rows: expected an int64 GPU tensor of shape ({count},), got {rows.dtype} {tuple(rows.shape)} on {rows.device}')
+    return rows.contiguous()
+
+
+def random_uniform(seed: int, stream_id: int, first_row: int, shape, device, out: Optional[Tensor] = None,
+                   rows: Optional[Tensor] = None) -> Tensor:
+    """[0,1) Philox draws of shape (rows, width...); element (r, c) depends only on (seed, stream_id, global row of r, c),
+    where the global row is ``rows[r]`` (int64 GPU tensor, e.g. a batch's ``global_rows``) or ``first_row + r``.
     ``out`` (optional) receives the draws in place (static buffers of a captured graph)."""
     lib = _lib.load()
     out = _draw_target(shape, device, out)
-    rows = int(shape[0])
-    width = out.numel() // rows if rows else 1
+    count = int(shape[0])
+    width = out.numel() // count if count else 1
     if out.numel() == 0:
         return out
+    rows = _row_ids(rows, count)
     with torch.cuda.device(out.device):
-        st = lib.snerf_random_uniform(int(seed) & (2 ** 64 - 1), int(stream_id) & 0xFFFFFFFF, int(first_row), rows, max(width, 1),
-                                      _ptr(out), _stream())
+        st = lib.snerf_random_uniform(int(seed) & (2 ** 64 - 1), int(stream_id) & 0xFFFFFFFF, int(first_row),
+                                      ctypes.c_void_p(0 if rows is None else rows.data_ptr()), count, max(width, 1), _ptr(out),
+                                      _stream())
     _lib.check(st, 'snerf_random_uniform')
     return out
 
 
 def random_normal(seed: int, stream_id: int, first_row: int, shape, device, scale: float = 1.0,
-                  out: Optional[Tensor] = None) -> Tensor:
+                  out: Optional[Tensor] = None, rows: Optional[Tensor] = None) -> Tensor:
     lib = _lib.load()
     out = _draw_target(shape, device, out)
-    rows = int(shape[0])
-    width = out.numel() // rows if rows else 1
+    count = int(shape[0])
+    width = out.numel() // count if count else 1
     if out.numel() == 0:
         return out
+    rows = _row_ids(rows, count)
     with torch.cuda.device(out.device):
-        st = lib.snerf_random_normal(int(seed) & (2 ** 64 - 1), int(stream_id) & 0xFFFFFFFF, int(first_row), rows, max(width, 1),
-                                     float(scale), _ptr(out), _stream())
+        st = lib.snerf_random_normal(int(seed) & (2 ** 64 - 1), int(stream_id) & 0xFFFFFFFF, int(first_row),
+                                     ctypes.c_void_p(0 if rows is None else rows.data_ptr()), count, max(width, 1), float(scale),
+                                     _ptr(out), _stream())
     _lib.check(st, 'snerf_random_normal')
     return out

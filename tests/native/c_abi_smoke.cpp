@@ -1,7 +1,8 @@
 // A torch-free consumer of the C ABI: plain HIP runtime + include/*.h, linked against libsimplenerf_hip.so.
 // Generates the rays of a small frame, their coarse depths, a shuffled epoch of pixel indices, Philox draws, one Adam
 // step and a display conversion, runs a 4x128 MLP forward in the three arithmetic modes and its training forward +
-// backward, and checks invariants on the host.  Built and run by tests/test_gpu_native.py.
+// backward, the one-call render ops (snerf_render_forward / _backward) against the same stages issued one by one, and
+// checks invariants on the host.  Built and run by tests/test_gpu_native.py.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -77,7 +78,7 @@ int main() {
 
     // B3: Philox known answer -- counter (row 0, block 0, stream 0), key 0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8
     float* u = dev<float>(4);
-    SNERF_OK_(snerf_random_uniform(0, 0, 0, 1, 4, u, nullptr));
+    SNERF_OK_(snerf_random_uniform(0, 0, 0, nullptr, 1, 4, u, nullptr));
     HIP_OK(hipDeviceSynchronize());
     auto hu = host(u, 4);
     const unsigned kat[4] = {0x6627e8d5u, 0xe169c58du, 0xbc57ac4cu, 0x9b00dbd8u};
@@ -167,7 +168,7 @@ int main() {
             SNERF_OK_(snerf_mlp_forward_train(&desc, packed, o_ndc, d_ndc, dirs, depths, n, S, nullptr, sig[0], col[0], saved,
                                               modes[k], nullptr));
             SNERF_OK_(snerf_mlp_backward(&desc, packed, saved, sig[0], col[0], dsig, dcol, n, S, work, g.data(), np, modes[k],
-                                         nullptr));
+                                         0, nullptr));
         }
         HIP_OK(hipDeviceSynchronize());
         for (int i = 0; i < np; ++i) {
@@ -182,6 +183,79 @@ int main() {
         }
         CHECK(snerf_mlp_forward(&desc, packed, o_ndc, d_ndc, dirs, depths, n, S, nullptr, sig[0], col[0], 7, nullptr) ==
               SNERF_E_UNSUPPORTED);
+
+        // ---- the one-call render ops: coarse + fine pass of that MLP (same weights at both levels) in ONE call, against
+        // the same stages issued one by one; then render_backward twice, the second time accumulating
+        const int Sc = 16, Sf = 16, Sm = Sc + Sf;
+        snerf_render_config cfg = {1, 0, 0, Sc, Sf, SNERF_PRECISION_FP32, 1};
+        snerf_render_mlp mlps[SNERF_RENDER_LEVELS] = {};
+        mlps[SNERF_LEVEL_MAIN_COARSE] = {&desc, packed};
+        mlps[SNERF_LEVEL_MAIN_FINE] = {&desc, packed};
+        snerf_render_rays rr = {};
+        rr.rays_o = rays_o; rr.rays_d = rays_d; rr.view_dirs = dirs; rr.rays_o_ndc = o_ndc; rr.rays_d_ndc = d_ndc;
+        rr.near = near; rr.far = far;
+        snerf_render_outputs ro = {};
+        ro.depths_coarse = dev<float>(n * Sc); ro.depths_fine = dev<float>(n * Sm);
+        for (int l : {0, 3}) {
+            const int s = l == 0 ? Sc : Sm;
+            snerf_render_level_out& lo = ro.level[l];
+            lo.rgb = dev<float>(3 * n); lo.acc = dev<float>(n); lo.depth = dev<float>(n); lo.depth_var = dev<float>(n);
+            lo.depth_ndc = dev<float>(n); lo.depth_var_ndc = dev<float>(n); lo.alpha = dev<float>(n * s);
+            lo.weights = l == 0 ? nullptr : dev<float>(n * s);     // level 0: weights go through the workspace
+            lo.sigma = dev<float>(n * s); lo.raw_rgb = dev<float>(3 * n * s);
+            lo.saved_acts = dev<float>(snerf_mlp_saved_floats(&desc, n, s));
+        }
+        float* rwork = dev<float>(snerf_render_workspace_floats(&cfg, n));
+        SNERF_OK_(snerf_render_forward(&cfg, mlps, &rr, n, &ro, rwork, nullptr));
+        // stage by stage
+        float *zc = dev<float>(n * Sc), *zf = dev<float>(n * Sm), *s0 = dev<float>(n * Sc), *c0s = dev<float>(3 * n * Sc),
+              *w0 = dev<float>(n * Sc), *s1 = dev<float>(n * Sm), *c1s = dev<float>(3 * n * Sm), *rgb1 = dev<float>(3 * n),
+              *acc1 = dev<float>(n), *dd = dev<float>(n), *dv = dev<float>(n), *dn = dev<float>(n), *dvn = dev<float>(n);
+        SNERF_OK_(snerf_coarse_depths(near, far, n, Sc, 0, nullptr, zc, nullptr));
+        SNERF_OK_(snerf_mlp_forward(&desc, packed, o_ndc, d_ndc, dirs, zc, n, Sc, nullptr, s0, c0s, 0, nullptr));
+        SNERF_OK_(snerf_composite(s0, c0s, zc, d_ndc, rays_o, rays_d, n, Sc, 1, 0, rgb1, acc1, nullptr, nullptr, w0, dd, dv, dn, dvn, nullptr));
+        SNERF_OK_(snerf_resample_depths(zc, w0, n, Sc, Sf, nullptr, zf, nullptr));
+        SNERF_OK_(snerf_mlp_forward(&desc, packed, o_ndc, d_ndc, dirs, zf, n, Sm, nullptr, s1, c1s, 0, nullptr));
+        SNERF_OK_(snerf_composite(s1, c1s, zf, d_ndc, rays_o, rays_d, n, Sm, 1, 0, rgb1, acc1, nullptr, nullptr, nullptr, dd, dv, dn, dvn, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        auto za = host(ro.depths_fine, n * Sm), zb = host(zf, n * Sm);
+        auto ra = host(ro.level[3].rgb, 3 * n), rb = host(rgb1, 3 * n);
+        auto da = host(ro.level[3].depth, n), db = host(dd, n);
+        for (size_t i = 0; i < za.size(); ++i) CHECK(za[i] == zb[i]);
+        for (size_t i = 0; i < ra.size(); ++i) CHECK(ra[i] == rb[i]);
+        for (size_t i = 0; i < da.size(); ++i) CHECK(da[i] == db[i]);
+        for (long long i = 0; i < n; ++i)
+            for (int k = 1; k < Sm; ++k) CHECK(za[i * Sm + k] >= za[i * Sm + k - 1]);
+        // backward: d(rgb_fine) = 1, d(depth_coarse) = 0.1; once overwriting, once more accumulating -> exactly twice
+        std::vector<float*> gc(np), gf(np);
+        for (int i = 0; i < np; ++i) { gc[i] = dev<float>((size_t)shape[i][0] * shape[i][1]); gf[i] = dev<float>((size_t)shape[i][0] * shape[i][1]); }
+        float *g_rgb = dev<float>(3 * n), *g_depth = dev<float>(n);
+        std::vector<float> tenth(n, 0.1f);
+        HIP_OK(hipMemcpy(g_rgb, one.data(), 3 * n * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(g_depth, tenth.data(), n * 4, hipMemcpyHostToDevice));
+        snerf_render_level_grads rg[SNERF_RENDER_LEVELS] = {};
+        rg[0].depth = g_depth; rg[0].param_grads = gc.data(); rg[0].num_params = np;
+        rg[3].rgb = g_rgb; rg[3].param_grads = gf.data(); rg[3].num_params = np;
+        float* bwork = dev<float>(snerf_render_backward_workspace_floats(&cfg, mlps, n));
+        SNERF_OK_(snerf_render_backward(&cfg, mlps, &rr, n, &ro, rg, bwork, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<std::vector<float>> once;
+        for (int i = 0; i < np; ++i) once.push_back(host(gf[i], (size_t)shape[i][0] * shape[i][1]));
+        rg[0].accumulate = rg[3].accumulate = 1;
+        SNERF_OK_(snerf_render_backward(&cfg, mlps, &rr, n, &ro, rg, bwork, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        double norm = 0.0;
+        for (int i = 0; i < np; ++i) {
+            auto twice = host(gf[i], (size_t)shape[i][0] * shape[i][1]);
+            for (size_t j = 0; j < twice.size(); ++j) { CHECK(twice[j] == 2.f * once[i][j]); norm += (double)once[i][j] * once[i][j]; }
+        }
+        CHECK(norm > 0.0);
+        auto gcoarse = host(gc[0], (size_t)shape[0][0] * shape[0][1]);
+        double cn = 0.0;
+        for (float v : gcoarse) { CHECK(std::isfinite(v)); cn += (double)v * v; }
+        CHECK(cn > 0.0);
+        rr.view_dirs = nullptr;
+        CHECK(snerf_render_forward(&cfg, mlps, &rr, n, &ro, rwork, nullptr) == SNERF_E_INVALID);
     }
 
     // errors are status codes with a message, not crashes

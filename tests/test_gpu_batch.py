@@ -128,7 +128,7 @@ def test_draws_match_oracle_and_do_not_depend_on_sharding():
 def test_two_rank_assembler_batches_draw_what_a_single_process_draws():
     """with the rays of a batch sharded over ranks, every ray must still get the jitter, inverse-CDF
     draws and density noise it gets in a single-process run.  A rank's rows are a pixel-ray shard followed by a
-    sparse-depth shard of the global [pixel | sparse] batch, so the assembler hands the model ``row_segments``; here two
+    sparse-depth shard of the global [pixel | sparse] batch, so the assembler hands the model per-row ``global_rows``; here two
     assemblers (rank 0 and 1 of 2) and a single-process one feed the training-mode renderer, and the per-ray outputs of
     the union, re-ordered by global row, are bit-identical to the single-process outputs."""
     from simplenerf_amd import synth
@@ -151,13 +151,14 @@ def test_two_rank_assembler_batches_draw_what_a_single_process_draws():
             'views_augmentation_raw_sigma_coarse', 'raw_sigma_fine', 'rgb_fine')
     for it in range(2):
         batch = one.get_next_batch(it)
-        assert batch['row_segments'] == [(0, 96, 0), (96, 32, 96)]
+        assert torch.equal(batch['global_rows'], torch.arange(128, device=DEV))
         parts = [h.get_next_batch(it) for h in halves]
-        assert parts[0]['row_segments'] == [(0, 48, 0), (48, 16, 96)] and parts[1]['row_segments'] == [(0, 48, 48), (48, 16, 112)]
+        assert parts[0]['global_rows'].tolist() == list(range(0, 48)) + list(range(96, 112))
+        assert parts[1]['global_rows'].tolist() == list(range(48, 96)) + list(range(112, 128))
         with torch.no_grad():
             ref = whole_model(batch)
             outs = [m(p) for m, p in zip(rank_models, parts)]
-        rows = torch.cat([torch.cat([torch.arange(c, device=DEV) + gl for _, c, gl in p['row_segments']]) for p in parts])
+        rows = torch.cat([p['global_rows'] for p in parts])
         assert torch.equal(torch.sort(rows)[0], torch.arange(128, device=DEV))
         assert torch.equal(torch.cat([p['indices'] for p in parts])[torch.argsort(rows)], batch['indices'])
         for k in keys:
@@ -165,3 +166,14 @@ def test_two_rank_assembler_batches_draw_what_a_single_process_draws():
             assert torch.equal(union, ref[k]), (it, k)
     # and the draws really are per-row: rank 1's rows differ from rank 0's
     assert not torch.equal(outs[0]['z_vals_coarse'], outs[1]['z_vals_coarse'])
+    # the reference's trainer cuts every tensor of the batch into sub-batches (src/Trainer01.py:82-90): the rows go along
+    batch = one.get_next_batch(2)
+    with torch.no_grad():
+        calls = whole_model._train_calls
+        ref = whole_model(batch)
+        whole_model._train_calls = calls
+        cut = {k: (v[40:100] if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        part = whole_model(cut)
+    assert torch.equal(part['z_vals_coarse'], ref['z_vals_coarse'][40:100]) and torch.equal(part['raw_sigma_fine'], ref['raw_sigma_fine'][40:100])
+    u = ops.random_uniform(9, 4, 0, (128, 5), DEV, rows=batch['global_rows'].flip(0))
+    assert torch.equal(u.flip(0), ops.random_uniform(9, 4, 0, (128, 5), DEV))

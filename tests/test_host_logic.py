@@ -217,34 +217,25 @@ def test_frame_writer_round_trips(tmp_path):
         harness.save_image(tmp_path / 'x.jpg', image)
 
 
-def test_row_segments_tile_merge_and_slice():
+def test_global_rows_key_and_shard_arithmetic():
     """Global-row bookkeeping of the training draws (a rank's rows are a pixel shard followed by a sparse
-    shard, not one contiguous range of the single-process batch)."""
-    from simplenerf_amd.models.SimpleNeRFHip01 import row_segments, slice_row_segments
-    assert row_segments({}, 7) == [(0, 7, 0)] and row_segments({'row_offset': 40}, 7) == [(0, 7, 40)]
-    # single process: pixel rows [0,2048) then sparse rows [2048,4096) are one contiguous range
-    assert row_segments({'row_segments': [(0, 2048, 0), (2048, 2048, 2048)]}, 4096) == [(0, 4096, 0)]
-    # rank 1 of 2: pixel rows 1024.. and sparse rows 2048+1024.. of the global batch
-    segs = row_segments({'row_segments': [(0, 1024, 1024), (1024, 1024, 3072)]}, 2048)
-    assert segs == [(0, 1024, 1024), (1024, 1024, 3072)]
-    assert slice_row_segments(segs, 0, 1024) == [(0, 1024, 1024)] and slice_row_segments(segs, 1024, 1024) == [(0, 1024, 3072)]
-    assert slice_row_segments(segs, 512, 1024) == [(0, 512, 1536), (512, 512, 3072)]
-    assert slice_row_segments(segs, 2048, 10) == [(0, 0, 0)]
+    shard, not one contiguous range of the single-process batch; and the reference's trainer slices every TENSOR of the
+    batch into sub-batches, so the rows travel as a per-row tensor)."""
+    from simplenerf_amd.models.SimpleNeRFHip01 import global_rows
+    assert global_rows({}, 7) == (0, None) and global_rows({'row_offset': 40}, 7) == (40, None)
+    rows = torch.arange(7, dtype=torch.int64) + 100
+    first, got = global_rows({'global_rows': rows, 'row_offset': 5}, 7)
+    assert first == 0 and got is rows
     with pytest.raises(RuntimeError):
-        row_segments({'row_segments': [(0, 5, 0), (6, 1, 9)]}, 7)
-    with pytest.raises(RuntimeError):
-        row_segments({'row_segments': [(0, 5, 0)]}, 7)
+        global_rows({'global_rows': rows}, 6)            # a batch cut without cutting its rows
     # the union over ranks of the global rows of a sharded [pixel | sparse] batch is every row exactly once
+    from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
+    asm = BatchAssembler.__new__(BatchAssembler)
     total_p, total_s, world = 1000, 37, 3
     seen = []
     for rank in range(world):
-        parts = []
-        for total, base in ((total_p, 0), (total_s, total_p)):
-            per = -(-total // world)
-            lo = min(total, rank * per)
-            parts.append((min(total, lo + per) - lo, base + lo))
-        local = 0
-        for count, glob in parts:
-            seen += list(range(glob, glob + count))
-            local += count
+        asm.rank, asm.world_size = rank, world
+        _, count, lo = asm._shard(0, total_p)
+        _, count_s, lo_s = asm._shard(0, total_s)
+        seen += list(range(lo, lo + count)) + list(range(total_p + lo_s, total_p + lo_s + count_s))
     assert sorted(seen) == list(range(total_p + total_s))
