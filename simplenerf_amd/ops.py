@@ -367,7 +367,10 @@ class RenderCall:
                 st = lib.snerf_render_forward(ctypes.byref(self.cfg), self.c_mlps, ctypes.byref(r), n, ctypes.byref(o), _ptr(work),
                                               _stream())
             _lib.check(st, 'snerf_render_forward')
-        self.z_coarse, self.z_fine, self.out = z_coarse, z_fine, out
+        # what backward() needs alive is the memory behind the pointers in the structs: the two pools, the saved
+        # activations and the inputs.  The output VIEWS are not kept here: under autograd they carry the node that owns
+        # this object, and holding them would close a reference cycle that only the cycle collector frees (GBs per call)
+        held += [small, big] + [d['saved'] for d in out.values() if 'saved' in d]
         return z_coarse, z_fine, out
 
     def backward(self, grads: Dict[int, Dict[str, Optional[Tensor]]], param_grads: Dict[int, List[Tensor]],
