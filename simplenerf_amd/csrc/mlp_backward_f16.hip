@@ -6,6 +6,7 @@
 // (hi.hi + hi.lo + lo.hi) into an fp32 accumulator; W^T is pre-split at pack time (MlpPlan::half_dgrad_stages) and
 // streamed through the 3-slot LDS ring, one 32-row IN-feature tile (all of its k-steps over the OUT features) per unit.
 #include <algorithm>
+#include <type_traits>
 
 #include "mlp_device_f16.h"
 
@@ -96,7 +97,19 @@ __device__ __forceinline__ void store_dy(const f32x16 (&acc)[U], float* __restri
 template <int P>
 constexpr int dy_stores(int tiles) { return P == 3 ? 16 * tiles : 2 * tiles; }
 
-template <int WT, int VT, bool VIEWDEP, int P>
+// f(integral_constant<I>), ..., f(integral_constant<N-1>): one inlined copy of the body per index
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// DEPTH > 0: compile-time trunk depth, layer loop fully unrolled -- the unit schedule (k-steps of each unit and its two
+// successors, DMA pieces, counted vmcnt immediates incl. the dY stores, ring slots) folds to constants instead of ~200
+// scalar instructions per unit of 16 MFMAs (see mlp_forward_f16.hip).
+template <int WT, int VT, bool VIEWDEP, int P, int DEPTH>
 // (one workgroup per CU also for P = 1: at the 256-register budget of two the kernel spills ~120 registers and the
 // training iteration measured 11.1 -> 14.4 ms)
 __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfChainArgs args) {
@@ -109,8 +122,9 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
     constexpr int VK = VT * 2;   // k-steps over the views layer's dY
 
     // unit idx -> k-steps: [views^T: WT units of VK][feature^T: WT of HK] (view-dependent MLPs), then (depth-1) x WT of HK
+    const int depth = DEPTH > 0 ? DEPTH : a.depth;
     const int head_units = VIEWDEP ? 2 * WT : 0;
-    const int total_units = head_units + (a.depth - 1) * WT;
+    const int total_units = head_units + (depth - 1) * WT;
     auto ks_of = [&](int idx) {
         if (idx >= total_units) return 0;
         if (VIEWDEP && idx < WT) return VK;
@@ -188,7 +202,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
                     dyv[4 * g + q] = fmaf(w2[q], dhead[3], fmaf(w1[q], dhead[2], w0[q] * dhead[1]));
             }
         }
-        apply_relu_masks<VT>(dyvs, masks, a.depth * WT, lane);
+        apply_relu_masks<VT>(dyvs, masks, depth * WT, lane);
         store_dy<P, VT>(dyvs, grads, a.grad_yv, lane, gback);
         st.note_vmem(dy_stores<P>(VT));
         renormalise<VT>(dyvs, gscale, gback, dy_max ? dy_max + a.grad_yv / 32 : nullptr, lane);
@@ -241,9 +255,8 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
     }
     // ---- trunk, last layer first: dY_l = dh_{l+1} . [h_{l+1} > 0];  dh_l = W_l[:, h-columns]^T dY_l -------------
     unsigned relu_words[WT / 2];   // sign bits of the layer whose dY is formed next; requested one layer ahead
-    load_relu_words<WT>(relu_words, masks, (a.depth - 1) * WT, lane);
-#pragma unroll 1
-    for (int l = a.depth - 1; l >= 0; --l) {
+    load_relu_words<WT>(relu_words, masks, (depth - 1) * WT, lane);
+    auto trunk_layer = [&](int l) __attribute__((always_inline)) {
         mask_with_words<WT>(acc, relu_words);
         if (l > 0) load_relu_words<WT>(relu_words, masks, (l - 1) * WT, lane);   // in flight during this layer's products
         store_dy<P, WT>(acc, grads, l * a.width, lane, gback);
@@ -251,7 +264,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
         unsigned* region = dy_max ? dy_max + (l * a.width) / 32 : nullptr;
         if (l == 0) {
             if (region) publish_max(region, tiles_max<WT>(acc) * gback, lane);
-            break;
+            return;
         }
         renormalise<WT>(acc, gscale, gback, region, lane);
 #pragma unroll
@@ -263,15 +276,21 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
             for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
             seg_product<P, HK>(acc[u], unit, HK, xh, xl, st);
         }
+    };
+    if constexpr (DEPTH > 0) {
+        static_for<0, DEPTH>([&](auto step) __attribute__((always_inline)) { trunk_layer(DEPTH - 1 - decltype(step)::value); });
+    } else {
+#pragma unroll 1
+        for (int l = depth - 1; l >= 0; --l) trunk_layer(l);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int WT, int VT, bool VIEWDEP, int P>
+template <int WT, int VT, bool VIEWDEP, int P, int DEPTH = 0>
 int launch_chain_half(const HalfChainArgs& args, hipStream_t stream) {
     const long long blocks = (args.c.total + 127) / 128;
     const size_t lds_bytes = sizeof(float) * (kUnitBuffers * (size_t)args.slot_floats + 1024);  // ring + DMA dump area
-    auto kernel = mlp_backward_chain_f16x3_kernel<WT, VT, VIEWDEP, P>;
+    auto kernel = mlp_backward_chain_f16x3_kernel<WT, VT, VIEWDEP, P, DEPTH>;
     static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
     const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024)), "mlp_backward");
     if (attr != SNERF_OK) return attr;
@@ -293,6 +312,8 @@ int mlp_backward_chain_f16x3(const MlpPlan& plan, const ChainArgs& a, int produc
     args.slot_floats = products == 3 ? kUnitBufFloats : (most_ks + 3) / 4 * 4 * 256;   // hi halves only (see the forward)
     const int key = plan.wt * 10 + plan.vt;
 #define SNERF_CHAIN(WT_, VT_, VD_) return products == 3 ? launch_chain_half<WT_, VT_, VD_, 3>(args, stream) : launch_chain_half<WT_, VT_, VD_, 1>(args, stream)
+    if (key == 84 && a.depth == 8)   // the shipped 8 x 256 trunk with a views layer: compile-time unit schedule
+        return products == 3 ? launch_chain_half<8, 4, true, 3, 8>(args, stream) : launch_chain_half<8, 4, true, 1, 8>(args, stream);
     switch (key) {
         case 84: SNERF_CHAIN(8, 4, true);
         case 80: SNERF_CHAIN(8, 4, false);

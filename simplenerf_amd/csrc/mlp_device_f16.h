@@ -42,8 +42,13 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform in [0,
 // Unit layout (mlp_pack.hip): [hi fragment of every k-step, 1 KiB each][lo fragment of every k-step].  The single-product
 // kernels (P = 1, SNERF_PRECISION_F16) request only the hi half of each unit -- k KiB-pieces, rounded up to a multiple of
 // four (one DMA instruction per wave; the surplus pieces are the first lo fragments, which nobody reads).
-template <int P>
+// NW = waves of the workgroup that share the ring (4, or 8 for the single-product forward: two waves per SIMD reading ONE
+// weight stream -- the same occupancy as two 4-wave workgroups per CU at half the L2 -> LDS traffic, which is what bounds
+// the 16-bit forward: 2 x 128 KB per layer and CU at fp16 MFMA rates is ~150 GB/s per CU, twice what a CU draws from L2).
+template <int P, int NW = 4>
 struct UnitStreamT {
+    static_assert(NW == 4 || (NW == 8 && P == 1), "8-wave rings are built for the single-product kernels only");
+    static constexpr int kWaves = NW;
     const float* fetch_ptr;  // global address of the next unit to request
     const float* stream_base;
     float* lds;
@@ -67,7 +72,7 @@ struct UnitStreamT {
         pend_left -= pend_left > 0 ? 1 : 0;
         return;
 #endif
-        const int adv = pend_left > 0 ? 1024 : 0;
+        const int adv = pend_left > 0 ? NW * 256 : 0;
         pend_src += adv; pend_dst += adv;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pend_src + lane * 4),
                                          (__attribute__((address_space(3))) void*)pend_dst, 16, 0, 0);
@@ -83,14 +88,14 @@ struct UnitStreamT {
     // the stream into a per-wave dump area instead of touching a live buffer.
     __device__ __forceinline__ void issued_next_none() {
         pend_src = stream_base;
-        pend_dst = lds + kUnitBuffers * slot_floats + wave * 256;  // dump: 4 KiB right after the ring
+        pend_dst = lds + kUnitBuffers * slot_floats + wave * 256;  // dump: NW KiB right after the ring
         pend_left = 0;
         issued = 0;
     }
     __device__ __forceinline__ void begin_fetch(int ksteps, int into_slot) {
-        pend_src = fetch_ptr + wave * 256 - 1024;   // fetch_piece pre-increments
-        pend_dst = lds + into_slot * slot_floats + wave * 256 - 1024;
-        pend_left = P == 3 ? ksteps >> 1 : (ksteps + 3) >> 2;
+        pend_src = fetch_ptr + wave * 256 - NW * 256;   // fetch_piece pre-increments
+        pend_dst = lds + into_slot * slot_floats + wave * 256 - NW * 256;
+        pend_left = P == 3 ? ksteps >> 1 : (ksteps + NW - 1) / NW;
         issued = 0;
         fetch_ptr += ksteps * 512;
     }
@@ -122,7 +127,7 @@ struct UnitStreamT {
         // (the generic 64-way dispatch compiles to a compare-and-branch tree of ~30 scalar instructions, and with one wave
         // per SIMD every instruction is an issue slot: the steady-state counts of the 256-wide trunk -- the successor's
         // k/2 resp. k/4 DMA instructions and nothing else -- are tested first)
-        if (allowed == (P == 3 ? 8 : 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P == 3 ? 8 : 4) : "memory");
+        if (allowed == (P == 3 ? 8 : 16 / NW)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P == 3 ? 8 : 16 / NW) : "memory");
         else wait_vmcnt(allowed);
         younger = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my LDS reads of unit i-1 are complete
@@ -247,7 +252,7 @@ __device__ __forceinline__ void seg_mfma1(f32x16& acc, const float*& p, const f1
         else if (newer == 1) lds_wait_all_but<1>(cur);
         else lds_wait_all_but<0>(cur);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bh[ks], acc, 0, 0, 0);
-        if ((ks & 3) == 0) st.fetch_piece();
+        if ((ks & (Stream::kWaves - 1)) == 0) st.fetch_piece();   // one KiB-piece per wave and kWaves k-steps
     }
     p += NKS * 256;
 }

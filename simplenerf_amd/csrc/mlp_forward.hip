@@ -230,6 +230,6 @@ extern "C" int snerf_mlp_forward_train(const snerf_mlp_desc* desc, const float* 
 extern "C" size_t snerf_mlp_saved_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples) {
     snerf::MlpPlan plan;
     if (snerf::build_plan(desc, &plan) != SNERF_OK || num_rays < 0 || num_samples < 1) return 0;
-    const long long blocks = (num_rays * num_samples + 127) / 128 * 4;  // whole workgroups of 4 wave blocks
+    const long long blocks = (num_rays * num_samples + 255) / 256 * 8;  // whole workgroups of up to 8 wave blocks
     return (size_t)(blocks * plan.act_rows() * 32);
 }

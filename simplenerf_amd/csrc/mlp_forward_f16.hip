@@ -17,10 +17,21 @@
 // Bound: MFMA fp16 (dense peak 2.5 PFLOP/s; 3 MFMA passes per algorithmic product -> 833 TFLOP/s algorithmic ceiling),
 // with the weight stream L2 -> LDS (2.3 MB per 128 samples) as the secondary limit.
 #include <algorithm>
+#include <type_traits>
 
 #include "mlp_device_f16.h"
 
 namespace {
+
+// f(integral_constant<I>), ..., f(integral_constant<N-1>): one inlined copy of the body per index (a `#pragma unroll` on a
+// loop this large is refused by the optimiser)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 struct HalfArgs {
     MlpArgs m;
@@ -36,18 +47,25 @@ struct HalfArgs {
 // (inference: 1.47 -> 1.89 M rays/s on the headline step).  The training variant needs ~120 more registers for the
 // mask words and fragment stores and would spill at the 256-register budget of that occupancy (measured: slower), so
 // it keeps one workgroup per CU.
-template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P>
-__global__ void __launch_bounds__(256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(HalfArgs args) {
+// DEPTH > 0: the trunk depth is a compile-time constant and the layer loop is fully unrolled, so that the whole unit
+// schedule -- k-steps of every unit and of its two successors, DMA pieces per wave, counted vmcnt immediates, ring slots,
+// the point where a request's pieces run out -- folds to constants.  With the generic (DEPTH = 0) loop that bookkeeping
+// is ~250 scalar instructions, compare-and-branch trees included, around the 16 MFMAs of a 256-wide unit: at one or two
+// waves per SIMD every one of them is an issue slot, and the matrix pipe waited on the scalar unit (r02).
+template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P, int DEPTH>
+__global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(HalfArgs args) {
+    constexpr int NW = P == 1 ? 8 : 4;   // waves per workgroup (see UnitStreamT)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const MlpArgs& a = args.m;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
     constexpr int HK = WT * 2;  // k-steps of a full-width activation
+    const int depth = DEPTH > 0 ? DEPTH : a.depth;
 
     // k-steps of staging unit `idx` in stream order: trunk layers (WT units each), feature stage (WT), views layer (VT)
     constexpr int kViewsKs = HK + (SIGMA_PE ? 4 : 0) + 2;
-    const int trunk_units = a.depth * WT;
+    const int trunk_units = depth * WT;
     auto ks_of = [&](int idx) {
         if (idx < trunk_units) {
             const int l = idx / WT;
@@ -57,7 +75,7 @@ __global__ void __launch_bounds__(256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(
         const int v = idx - trunk_units;
         return v < WT ? HK : (v < WT + VT ? kViewsKs : 0);
     };
-    UnitStreamT<P> st;
+    UnitStreamT<P, NW> st;
     st.start(a.packed + args.half_offset, lds, ks_of(0), ks_of(1), lane, wave, args.slot_floats);
     int unit_idx = 0;
     auto next_unit = [&]() {
@@ -67,12 +85,12 @@ __global__ void __launch_bounds__(256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(
     };
     // Biases and head weights live in LDS for the whole kernel: an ordinary global load inside the tile loop would make
     // the compiler wait vmcnt(0), i.e. drain the weight prefetch (LDS-DMA) that is deliberately left in flight.
-    float* consts = lds + kUnitBuffers * args.slot_floats + 1024;  // after the ring and the 4-KiB DMA dump area
-    for (int i = threadIdx.x * 4; i < args.const_floats; i += 256 * 4)
+    float* consts = lds + kUnitBuffers * args.slot_floats + NW * 256;  // after the ring and the DMA dump area (1 KiB per wave)
+    for (int i = threadIdx.x * 4; i < args.const_floats; i += NW * 64 * 4)
         *reinterpret_cast<f32x4*>(consts + i) = *reinterpret_cast<const f32x4*>(a.packed + a.bias_offset + i);
     __syncthreads();
 
-    const long long first = ((long long)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+    const long long first = ((long long)blockIdx.x * NW + wave) * 32 + (lane & 31);
     const bool live = first < a.total;
     const long long g = live ? first : a.total - 1;
     const long long ray = g / a.samples;
@@ -86,11 +104,11 @@ __global__ void __launch_bounds__(256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(
     _Float16* tile16 = nullptr;  // ... or 16-bit fragment pieces, rows of 32 x 16 bit (a.act_rows counts those)
     unsigned* masks = nullptr;
     if (STORE32) {
-        tile = a.acts + ((long long)blockIdx.x * 4 + wave) * a.act_rows * 32;
+        tile = a.acts + ((long long)blockIdx.x * NW + wave) * a.act_rows * 32;
         masks = reinterpret_cast<unsigned*>(tile + a.act_mask * 32);
     }
     if (STORE16) {
-        tile16 = reinterpret_cast<_Float16*>(a.acts) + ((long long)blockIdx.x * 4 + wave) * a.act_rows * 32;
+        tile16 = reinterpret_cast<_Float16*>(a.acts) + ((long long)blockIdx.x * NW + wave) * a.act_rows * 32;
         masks = reinterpret_cast<unsigned*>(tile16 + a.act_mask * 32);
     }
     f16x8 pe_h[4], pe_l[4], pev_h[2], pev_l[2];
@@ -116,7 +134,7 @@ __global__ void __launch_bounds__(256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(
     const float* bout = consts + (a.pts_out_b - a.bias_offset);
     f16x8 xh[HK], xl[HK];
     float head[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // density (and view-independent colour) pre-activations
-    const bool single = a.depth == 1;
+    const bool single = depth == 1;
 
     // One accumulator tile per out tile of the layer (WT x 16 registers -- the matrix pipe's own AGPR file), and the
     // activations xh/xl in arch VGPRs where the MFMA reads them directly.  After the layer's last tile the accumulators
@@ -149,10 +167,9 @@ __global__ void __launch_bounds__(256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(
     if (STORE16) { store_pieces<HK>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK); }
 
     // ---- trunk layers 1 .. depth-1 --------------------------------------------------------------------------------
-#pragma unroll 1
-    for (int l = 1; l < a.depth; ++l) {
+    auto trunk_layer = [&](int l) __attribute__((always_inline)) {
         const float* bl = bias + (long long)l * a.width;
-        const bool last = l == a.depth - 1;
+        const bool last = l == depth - 1;
 #pragma unroll
         for (int u = 0; u < WT; ++u) {
             const float* unit = next_unit();
@@ -168,6 +185,12 @@ __global__ void __launch_bounds__(256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(
 #pragma unroll
         for (int u = 0; u < WT; ++u) split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
         if (STORE16) { store_pieces<HK>(xh, tile16 + (a.act_h1 + l * a.width) * 32, lane); st.note_vmem(HK); }
+    };
+    if constexpr (DEPTH > 0) {
+        static_for<1, DEPTH>([&](auto layer) __attribute__((always_inline)) { trunk_layer(decltype(layer)::value); });
+    } else {
+#pragma unroll 1
+        for (int l = 1; l < depth; ++l) trunk_layer(l);
     }
 
     float sigma = (head[0] + __shfl_xor(head[0], 32, 64)) + bout[0];
@@ -207,13 +230,13 @@ __global__ void __launch_bounds__(256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(
                 f16x8 vh[2], vl[2];
                 split_tile<true>(acc[u], vh[0], vl[0], vh[1], vl[1]);
                 store_pieces<2>(vh, tile16 + (a.act_hv + 32 * u) * 32, lane);
-                relu_mask_tile(acc[u], u, mask_bits, masks, a.depth * WT, lane);
+                relu_mask_tile(acc[u], u, mask_bits, masks, depth * WT, lane);
                 st.note_vmem(2 + (u & 1));
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) col[c] += tile_dot_relu(acc[u], wv + c * VT * 32 + 32 * u, half);
         }
-        if (STORE32) store_relu_masks<VT>(acc, masks, a.depth * WT, lane);
+        if (STORE32) store_relu_masks<VT>(acc, masks, depth * WT, lane);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoidf((col[c] + __shfl_xor(col[c], 32, 64)) + bo[c]);
     }
@@ -226,21 +249,30 @@ __global__ void __launch_bounds__(256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(
     }
 }
 
-template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P>
+template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P, int DEPTH = 0>
 int launch_half(const HalfArgs& args, hipStream_t stream) {
-    const long long blocks = (args.m.total + 127) / 128;
+    constexpr int NW = P == 1 ? 8 : 4;
+    const long long blocks = (args.m.total + NW * 32 - 1) / (NW * 32);
     if (blocks > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: too many samples in one call");
-    const size_t lds_bytes = sizeof(float) * (kUnitBuffers * (size_t)args.slot_floats + 1024 + (size_t)args.const_floats);
-    auto kernel = mlp_forward_f16x3_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE, P>;
+    const size_t lds_bytes = sizeof(float) * (kUnitBuffers * (size_t)args.slot_floats + NW * 256 + (size_t)args.const_floats);
+    auto kernel = mlp_forward_f16x3_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE, P, DEPTH>;
     static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
-    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024 + 5120)), "mlp_forward");
+    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 2048 + 5120)), "mlp_forward");
     if (attr != SNERF_OK) return attr;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, args);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, stream, args);
     return snerf::check_launch("mlp_forward(f16x3)");
 }
 
 template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE>
 int launch_variant(const HalfArgs& args, bool train, int products, hipStream_t stream) {
+    if constexpr (WT == 8 && VIEWDEP) {   // the shipped 8 x 256 trunk: compile-time unit schedule (the view-independent
+                                          // layout spills ~300 registers when unrolled: it keeps the loop)
+        if (args.m.depth == 8) {
+            if (products == 3)
+                return train ? launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, 3, 8>(args, stream) : launch_half<WT, VT, VIEWDEP, SIGMA_PE, false, 3, 8>(args, stream);
+            return train ? launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, 1, 8>(args, stream) : launch_half<WT, VT, VIEWDEP, SIGMA_PE, false, 1, 8>(args, stream);
+        }
+    }
     if (products == 3)
         return train ? launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, 3>(args, stream) : launch_half<WT, VT, VIEWDEP, SIGMA_PE, false, 3>(args, stream);
     return train ? launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, 1>(args, stream) : launch_half<WT, VT, VIEWDEP, SIGMA_PE, false, 1>(args, stream);
@@ -264,8 +296,9 @@ int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, int pro
             return fail(SNERF_E_UNSUPPORTED, "mlp_forward(f16x3): staging unit of %d KiB exceeds the LDS buffer", st.unit_floats / 256);
         most_ks = std::max(most_ks, st.unit_floats / 512);
     }
-    // products = 1 requests the hi half of each unit only: k KiB-pieces rounded up to four (one per wave)
-    args.slot_floats = products == 3 ? kUnitBufFloats : (most_ks + 3) / 4 * 4 * 256;
+    // products = 1 requests the hi half of each unit only: k KiB-pieces rounded up to eight (one per wave of its 8-wave
+    // workgroups)
+    args.slot_floats = products == 3 ? kUnitBufFloats : (most_ks + 7) / 8 * 8 * 256;
     const int key = plan.wt * 100 + plan.vt * 10 + (plan.sigma_pe ? 1 : 0);
     switch (key) {
         case 840: return launch_variant<8, 4, true, false>(args, train, products, stream);
