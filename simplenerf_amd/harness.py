@@ -261,16 +261,19 @@ class GraphedTrainStep:
     and, after the replay, the optimiser step.  ~150 launches and their Python glue become one graph launch: the host
     cost of an iteration drops from ~5.4 ms to well under 1 ms, which is what bounds small per-rank batches.
 
-    One pass over the whole batch (no sub-batching: with 288 GB the reference's 2048-row sub-batches are not needed).
-    The MSE, sparse-depth and augmentation-depth terms average over their mask counts and come out the same as with
-    sub-batches; the coarse-fine consistency term's patch statistics see the whole batch at once and differ by ~10 %
-    (tools/probes/sub_batch_terms.py) -- use ``train_one_iter`` with ``sub_batch_size`` for the reference's exact iteration.  ``p.grad`` of every parameter is a static
+    ``sub_batch_size`` (round 2): the captured work is the reference's iteration exactly -- the batch cut into consecutive
+    sub-batches, model -> losses -> backward per sub-batch, gradients accumulated by the backward kernels
+    (src/Trainer01.py:82-96) -- so a replay is bit-identical to ``train_one_iter(..., sub_batch_size)`` (same draws too:
+    they are generated per sub-batch, each counted as one training forward).  Without it the whole batch is one pass:
+    the MSE, sparse-depth and augmentation-depth terms come out the same, the coarse-fine consistency term's patch
+    statistics see the whole batch at once and differ by ~10 % (tools/probes/sub_batch_terms.py).  ``p.grad`` of every parameter is a static
     buffer the graph overwrites each replay: do not call ``zero_grad(set_to_none=True)`` between iterations.  The loss
     weights of the iteration are baked into the graph; it is re-captured when ``LossComputer.get_loss_weight`` changes
     them (the shipped schedule: once, at iteration 10000).
     """
 
-    def __init__(self, model, loss_computer, sample_batch: Dict[str, object], warmup: int = 2):
+    def __init__(self, model, loss_computer, sample_batch: Dict[str, object], warmup: int = 2,
+                 sub_batch_size: Optional[int] = None):
         self.model, self.losses = model, loss_computer
         self.static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample_batch.items() if k != 'common_data'}
         self.common = dict(sample_batch.get('common_data', {}))
@@ -279,6 +282,7 @@ class GraphedTrainStep:
         self.draws = {k: torch.empty(shape, dtype=torch.float32, device=self.device)
                       for k, shape in model.training_draw_shapes(self.n).items()}
         self.warmup = warmup
+        self.sub = int(sub_batch_size) if sub_batch_size else self.n
         self.graph = None
         self.weights_key = None
         self.totals: Dict[str, Tensor] = {}
@@ -292,12 +296,27 @@ class GraphedTrainStep:
         return tuple(self.losses.get_loss_weight(cfg, iter_num) for cfg in self.losses.losses.values())
 
     def _pass(self):
-        self.model.set_random_draws(self.draws)
-        piece = dict(self.static)
-        piece['common_data'] = dict(self.common)
-        losses = self.losses.compute_losses(piece, self.model(piece))
-        losses['TotalLoss'].backward()
-        return {name: (entry['loss_value'] if isinstance(entry, dict) else entry).detach() for name, entry in losses.items()}
+        totals: Dict[str, Tensor] = {}
+        for start in range(0, self.n, self.sub):
+            cut = slice(start, start + self.sub)
+            self.model.set_random_draws({k: v[cut] for k, v in self.draws.items()})
+            piece = {k: (v[cut] if isinstance(v, torch.Tensor) else v) for k, v in self.static.items()}
+            piece['common_data'] = dict(self.common)
+            losses = self.losses.compute_losses(piece, self.model(piece))
+            losses['TotalLoss'].backward()
+            for name, entry in losses.items():
+                value = (entry['loss_value'] if isinstance(entry, dict) else entry).detach()
+                totals[name] = totals[name] + value if name in totals else value
+        return totals
+
+    def _draw(self, batch):
+        """This iteration's draws into the static buffers: per sub-batch, each counted as one training forward -- what the
+        eager sub-batched iteration draws."""
+        rows = self._rows(batch, self.n)
+        for start in range(0, self.n, self.sub):
+            count = min(self.sub, self.n - start)
+            part = rows[start:start + count] if isinstance(rows, torch.Tensor) else rows + start
+            self.model.draw_training_randomness(count, part, self.device, out={k: v[start:start + count] for k, v in self.draws.items()})
 
     def _capture(self):
         side = torch.cuda.Stream(device=self.device)
@@ -332,7 +351,7 @@ class GraphedTrainStep:
                 self.static[k].copy_(v)
             elif k != 'common_data':
                 self.static[k] = v
-        self.model.draw_training_randomness(self.n, self._rows(batch, self.n), self.device, out=self.draws)
+        self._draw(batch)
         key = self._weights(batch['iter_num'])
         if self.graph is None or key != self.weights_key:
             self._capture()                    # records the work (on these inputs); nothing is computed until the replay
