@@ -30,7 +30,7 @@ enum snerf_status {
 
 /* ABI version of this header; bumped on any signature change (new enum values such as SNERF_PRECISION_F16 extend a
  * version without changing it: older callers never pass them). */
-#define SNERF_ABI_VERSION 5
+#define SNERF_ABI_VERSION 6
 int snerf_abi_version(void);
 const char* snerf_last_error(void);
 
@@ -72,6 +72,9 @@ typedef struct snerf_mlp_desc {
     int sigma_pe_degree;     /* points_sigma_positional_encoding_degree (:576-578), or -1 when the key is absent */
     int use_view_dirs;
     int view_dependent_rgb;
+    int predict_visibility;  /* :582-584, :599-602: views_output_linear gets a 4th row, the per-sample visibility of the point
+                                from a view direction (sigmoid).  Built for view_dependent_rgb MLPs, fp32 arithmetic; off in
+                                every shipped configuration */
 } snerf_mlp_desc;
 
 /* Number of entries of the `params` array below for this descriptor (0 if unsupported):
@@ -144,6 +147,30 @@ int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packed, const fl
                        const float* rgb, const float* d_sigma, const float* d_rgb, long long num_rays, int num_samples,
                        float* workspace, float* const* param_grads, int num_params, int precision, int accumulate,
                        snerf_stream_t stream);
+
+/* ---- predict_visibility (src/models/SimpleNeRF01.py:317-326, :646-649, :691-714, :479-482) -----------------------------
+ * snerf_other_view_dirs: SimpleNeRF.compute_other_view_dirs -- unit directions from each of `num_other` secondary camera
+ * centres to every sample point, (n, S, num_other, 3).  With ndc the sample depths are converted to world depths first
+ * (near plane hard-coded to 1 as in the reference, :319-321).
+ *   depths (n,S); rays_o, rays_d (n,3) WORLD rays; rays_o2 (n, num_other, 3)
+ * snerf_mlp_forward_visibility: snerf_mlp_forward[_train] for a predict_visibility MLP; additionally
+ *   visibility   (n,S)             'visibility' of MLP.forward for the primary view direction, or NULL
+ *   view_dirs2   (n,S,num_other,3) per-sample secondary directions (snerf_other_view_dirs), or NULL with num_other = 0
+ *   visibility2  (n,S,num_other)   'visibility2': the views head evaluated again per secondary direction (:646-649)
+ *   saved_acts   NULL for inference; else as snerf_mlp_forward_train (the visibility outputs carry no gradient: no shipped
+ *                loss reads them, and snerf_mlp_backward writes zeros for the 4th row of views_output_linear)
+ * snerf_composite_visibility2: 'visibility2' of volume_rendering (:479-482): sum_s w[n,s] vis2[n,s,k] / (acc[n] + 1e-6).
+ */
+int snerf_other_view_dirs(const float* depths, const float* rays_o, const float* rays_d, const float* rays_o2,
+                          long long num_rays, int num_samples, int num_other, int ndc, float* view_dirs2,
+                          snerf_stream_t stream);
+int snerf_mlp_forward_visibility(const snerf_mlp_desc* desc, const float* packed, const float* origins, const float* dirs,
+                                 const float* view_dirs, const float* depths, long long num_rays, int num_samples,
+                                 const float* sigma_noise, const float* view_dirs2, int num_other, float* sigma, float* rgb,
+                                 float* visibility, float* visibility2, float* saved_acts, int precision,
+                                 snerf_stream_t stream);
+int snerf_composite_visibility2(const float* weights, const float* acc, const float* visibility2, long long num_rays,
+                                int num_samples, int num_other, float* out, snerf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * K4  alpha compositing.  Replaces SimpleNeRF.volume_rendering (src/models/SimpleNeRF01.py:430-483) and
@@ -223,6 +250,9 @@ typedef struct snerf_render_rays {          /* device pointers, layouts of the r
     const float* sigma_noise[SNERF_RENDER_LEVELS]; /* per level (n, S) density noise, already scaled (:669-672), or NULL */
     const float* depths_fine;               /* (n, num_coarse+num_fine): use these fine depths instead of resampling
                                                (parity-test hook: sample_pdf has a rounding-dependent discontinuity), or NULL */
+    const float* rays_o2;                   /* (n, num_other, 3) secondary camera centres ('rays_o2', :120-133) for the
+                                               predict_visibility MLPs when sec_views_vis, or NULL */
+    int num_other;                          /* num_frames - 1; 0 = no secondary views */
 } snerf_render_rays;
 
 typedef struct snerf_render_level_out {     /* S = num_coarse for levels 0-2, num_coarse + num_fine for levels 3-5 */
@@ -231,6 +261,10 @@ typedef struct snerf_render_level_out {     /* S = num_coarse for levels 0-2, nu
     float *alpha, *visibility, *weights;    /* (n,S): each may be NULL */
     float *sigma, *raw_rgb;                 /* (n,S), (n,S,3): the MLP outputs ('raw_sigma', 'raw_rgb'), required */
     float* saved_acts;                      /* snerf_mlp_saved_floats(desc, n, S) floats, required when keep_activations */
+    float* raw_visibility;                  /* (n,S): predict_visibility levels, may be NULL */
+    float* raw_visibility2;                 /* (n,S,num_other): required for such a level when rays.num_other > 0 */
+    float* visibility2;                     /* (n,num_other): composited, required with raw_visibility2 */
+    float* view_dirs2;                      /* (n,S,num_other,3) scratch, required with raw_visibility2 */
 } snerf_render_level_out;
 
 typedef struct snerf_render_outputs {

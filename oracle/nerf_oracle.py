@@ -110,7 +110,7 @@ def mlp_layout(params: Dict[str, Tensor], prefix: str) -> dict:
 
 
 def mlp_forward(params: Dict[str, Tensor], prefix: str, mlp_cfg: dict, pts: Tensor, view_dirs: Optional[Tensor],
-                sigma_noise: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                sigma_noise: Optional[Tensor] = None, view_dirs2: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """One NeRF MLP on flat points.  pts (B,3), view_dirs (B,3)|None -> sigma (B,1), rgb (B,3).
 
     Follows MLP.forward :626-654, get_view_independent_outputs :656-685, get_view_dependent_outputs :687-715.
@@ -137,33 +137,71 @@ def mlp_forward(params: Dict[str, Tensor], prefix: str, mlp_cfg: dict, pts: Tens
         feature = F.linear(h, params[f'{prefix}feature_linear.weight'], params[f'{prefix}feature_linear.bias'])
         feature = torch.cat([feature, enc[:, lay['pts_in']:]], dim=1)
         enc_views = pos_encode(view_dirs, mlp_cfg['views_positional_encoding_degree'])
-        hv = torch.cat([feature, enc_views], -1)
-        for i in range(lay['views_depth']):
-            hv = F.relu(F.linear(hv, params[f'{prefix}views_linears.{i}.weight'],
-                                 params[f'{prefix}views_linears.{i}.bias']))
-        vout = F.linear(hv, params[f'{prefix}views_output_linear.weight'], params[f'{prefix}views_output_linear.bias'])
+
+
+        def views_head(encoded):       # get_view_dependent_outputs :687-715; `encoded` (B,27) or (B,K,27)
+            feat = feature if encoded.dim() == 2 else feature[:, None, :].repeat([1, encoded.shape[1], 1])
+            hv = torch.cat([feat, encoded], -1)
+            for i in range(lay['views_depth']):
+                hv = F.relu(F.linear(hv, params[f'{prefix}views_linears.{i}.weight'],
+                                     params[f'{prefix}views_linears.{i}.bias']))
+            return F.linear(hv, params[f'{prefix}views_output_linear.weight'], params[f'{prefix}views_output_linear.bias'])
+
+        vout = views_head(enc_views)
         out['rgb_view_dependent'] = torch.sigmoid(vout[..., 0:3])
+        if mlp_cfg.get('predict_visibility', False):          # 4th row of the views head (:708-712)
+            out['visibility'] = torch.sigmoid(vout[..., 3:4])
+            if view_dirs2 is not None:                          # the same head per secondary direction (:646-649)
+                vout2 = views_head(pos_encode(view_dirs2, mlp_cfg['views_positional_encoding_degree']))
+                out['visibility2'] = torch.sigmoid(vout2[..., 3:4])
         out['rgb'] = out['rgb_view_dependent']
     return out
 
 
 def run_mlp(params, prefix, mlp_cfg, pts: Tensor, view_dirs: Optional[Tensor], netchunk: Optional[int],
-            sigma_noise: Optional[Tensor] = None) -> Dict[str, Tensor]:
-    """(N,S,3) points through the MLP in ``netchunk``-row pieces (run_network :363-392, batchify :394-428)."""
+            sigma_noise: Optional[Tensor] = None, view_dirs2: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """(N,S,3) points through the MLP in ``netchunk``-row pieces (run_network :363-392, batchify :394-428).
+    ``view_dirs2`` (N,S,K,3): per-sample secondary directions of a predict_visibility MLP."""
     n, s = pts.shape[:2]
     flat = pts.reshape(-1, 3)
     vflat = None
     if view_dirs is not None and mlp_cfg['use_view_dirs']:
         vflat = view_dirs[:, None].expand(pts.shape).reshape(-1, 3)
     nflat = None if sigma_noise is None else sigma_noise.reshape(-1, 1)
+    v2flat = None
+    if view_dirs2 is not None and mlp_cfg['use_view_dirs'] and mlp_cfg.get('predict_visibility', False):
+        v2flat = view_dirs2.reshape(-1, view_dirs2.shape[-2], 3)
     step = flat.shape[0] if netchunk is None else netchunk
     pieces: Dict[str, list] = {}
     for i in range(0, flat.shape[0], step):
         piece = mlp_forward(params, prefix, mlp_cfg, flat[i:i + step], None if vflat is None else vflat[i:i + step],
-                            None if nflat is None else nflat[i:i + step])
+                            None if nflat is None else nflat[i:i + step], None if v2flat is None else v2flat[i:i + step])
         for k, v in piece.items():
             pieces.setdefault(k, []).append(v)
-    return {k: torch.cat(v, 0).reshape(n, s, -1) for k, v in pieces.items()}
+    return {k: torch.cat(v, 0).reshape([n, s] + list(v[0].shape[1:])) for k, v in pieces.items()}
+
+
+def other_view_dirs(z: Tensor, rays_o: Tensor, rays_d: Tensor, rays_o2: Tensor, ndc: bool) -> Tensor:
+    """compute_other_view_dirs :317-326: unit directions from the secondary camera centres (N,K,3) to every sample."""
+    if ndc:
+        tn = -(1 + rays_o[..., 2]) / rays_d[..., 2]
+        z = (((rays_o[..., None, 2] + tn[..., None] * rays_d[..., None, 2]) / (1 - z + 1e-6)) - rays_o[..., None, 2]) / rays_d[..., None, 2]
+    pts = rays_o[..., None, :] + z[..., None] * rays_d[..., None, :]
+    dirs = pts[:, :, None] - rays_o2[..., None, :, :]
+    return dirs / torch.norm(dirs, dim=-1, keepdim=True)
+
+
+def secondary_origins(batch: Dict[str, Tensor]) -> Tensor:
+    """rays_o2 of render_rays :120-133: given, or the centres of the other training views per ray."""
+    if 'rays_o2' in batch:
+        return batch['rays_o2']
+    poses = batch['common_data']['poses']
+    image_id = batch['pixel_id'][:, 0].long()
+    cols = []
+    for i in range(int(batch['num_frames']) - 1):
+        other = i + (i >= image_id).long()
+        cols.append(poses[other][:, :3, 3])
+    return torch.stack(cols, dim=1)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -220,7 +258,7 @@ _AUG = (('points_augmentation', 'pts_aug'), ('views_augmentation', 'views_aug'))
 
 
 def render_chunk(params: Dict[str, Tensor], configs: dict, batch: Dict[str, Tensor], training: bool, retraw: bool,
-                 rand: Optional[dict] = None) -> Dict[str, Tensor]:
+                 rand: Optional[dict] = None, sec_views_vis: bool = False) -> Dict[str, Tensor]:
     """One ``chunk`` of rays through coarse (+augmented, when training) and fine passes.  (render_rays :108-270)
 
     ``rand`` carries the draws the reference takes from the CPU generator, by name:
@@ -240,12 +278,22 @@ def render_chunk(params: Dict[str, Tensor], configs: dict, batch: Dict[str, Tens
         march_o, march_d = rays_o, rays_d
         near, far = batch['near'], batch['far']
     view_dirs = batch.get('view_dirs')
+    model_predicts = mcfg['coarse_mlp'].get('predict_visibility', False) or \
+        ('fine_mlp' in mcfg and mcfg['fine_mlp'].get('predict_visibility', False))
+    rays_o2 = secondary_origins(batch) if model_predicts and sec_views_vis else None
 
-    def shade(prefix, mlp_cfg, z, noise):
+    def shade(prefix, mlp_cfg, z, noise, dirs2=None):
         pts = ray_points(march_o, march_d, z)
-        raw = run_mlp(params, prefix, mlp_cfg, pts, view_dirs, netchunk, noise)
+        raw = run_mlp(params, prefix, mlp_cfg, pts, view_dirs, netchunk, noise, dirs2)
         comp = composite(raw['sigma'][..., 0], raw['rgb'], z, march_d, ndc, mcfg['white_bkgd'], rays_o, rays_d)
+        if model_predicts and sec_views_vis and 'visibility2' in raw:      # volume_rendering :479-482
+            comp['visibility2'] = torch.sum(comp['weights'][..., None] * raw['visibility2'][..., 0], dim=-2) / (comp['acc'][..., None] + 1e-6)
         return raw, comp
+
+    def dirs2_for(level_cfg, z):   # render_rays :150-152, :213-215: only the MAIN model's flag decides
+        if rays_o2 is None or not level_cfg.get('predict_visibility', False):
+            return None
+        return other_view_dirs(z, rays_o, rays_d, rays_o2, ndc)
 
     out: Dict[str, Tensor] = {}
 
@@ -258,7 +306,8 @@ def render_chunk(params: Dict[str, Tensor], configs: dict, batch: Dict[str, Tens
 
     z_coarse = coarse_depths(near, far, mcfg['coarse_mlp']['num_samples'], mcfg['lindisp'],
                              rand.get('t_rand') if training else None)
-    raw, comp = shade('coarse_model.', mcfg['coarse_mlp'], z_coarse, rand.get('noise_coarse'))
+    dirs2_coarse = dirs2_for(mcfg['coarse_mlp'], z_coarse)
+    raw, comp = shade('coarse_model.', mcfg['coarse_mlp'], z_coarse, rand.get('noise_coarse'), dirs2_coarse)
     weights_coarse = comp['weights']
     out['z_vals_coarse'] = z_coarse
     emit('', 'coarse', raw, comp)
@@ -266,19 +315,20 @@ def render_chunk(params: Dict[str, Tensor], configs: dict, batch: Dict[str, Tens
         for cfg_key, short in _AUG:
             if cfg_key in mcfg and 'coarse_mlp' in mcfg[cfg_key]:
                 raw, comp = shade(f'{short}_coarse_model.', mcfg[cfg_key]['coarse_mlp'], z_coarse,
-                                  rand.get(f'noise_{cfg_key}'))
+                                  rand.get(f'noise_{cfg_key}'), dirs2_coarse)
                 emit(f'{cfg_key}_', 'coarse', raw, comp)
     if 'fine_mlp' in mcfg:
         z_fine = resample_depths(z_coarse, weights_coarse, mcfg['fine_mlp']['num_samples'],
                                  rand.get('u') if training else None)
-        raw, comp = shade('fine_model.', mcfg['fine_mlp'], z_fine, rand.get('noise_fine'))
+        dirs2_fine = dirs2_for(mcfg['fine_mlp'], z_fine)
+        raw, comp = shade('fine_model.', mcfg['fine_mlp'], z_fine, rand.get('noise_fine'), dirs2_fine)
         out['z_vals_fine'] = z_fine
         emit('', 'fine', raw, comp)
         if training:        # fine-level augmentation MLPs on the same fine points (render_rays :234-263)
             for cfg_key, short in _AUG:
                 if cfg_key in mcfg and 'fine_mlp' in mcfg[cfg_key]:
                     raw, comp = shade(f'{short}_fine_model.', mcfg[cfg_key]['fine_mlp'], z_fine,
-                                      rand.get(f'noise_{cfg_key}_fine'))
+                                      rand.get(f'noise_{cfg_key}_fine'), dirs2_fine)
                     emit(f'{cfg_key}_', 'fine', raw, comp)
     if not retraw:
         for level in ('coarse', 'fine'):
@@ -288,15 +338,17 @@ def render_chunk(params: Dict[str, Tensor], configs: dict, batch: Dict[str, Tens
 
 
 def render(params: Dict[str, Tensor], configs: dict, batch: Dict[str, Tensor], training: bool = False,
-           retraw: bool = False, rand_per_chunk: Optional[list] = None) -> Dict[str, Tensor]:
+           retraw: bool = False, rand_per_chunk: Optional[list] = None, sec_views_vis: bool = False) -> Dict[str, Tensor]:
     """Whole batch in ``chunk``-ray pieces, outputs concatenated (forward :67-75, batchify_rays :81-106)."""
     retraw = retraw or training
+    sec_views_vis = sec_views_vis or training
     n = batch['rays_o'].shape[0]
     chunk = configs['model']['chunk']
     pieces: Dict[str, list] = {}
     for ci, i in enumerate(range(0, n, chunk)):
         sub = {k: (v[i:i + chunk] if isinstance(v, torch.Tensor) and v.shape[0] == n else v) for k, v in batch.items()}
-        res = render_chunk(params, configs, sub, training, retraw, None if rand_per_chunk is None else rand_per_chunk[ci])
+        res = render_chunk(params, configs, sub, training, retraw, None if rand_per_chunk is None else rand_per_chunk[ci],
+                           sec_views_vis)
         for k, v in res.items():
             pieces.setdefault(k, []).append(v)
     return {k: torch.cat(v, 0) for k, v in pieces.items()}

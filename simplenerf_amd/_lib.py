@@ -12,14 +12,14 @@ from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_s
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsimplenerf_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class MlpDesc(ctypes.Structure):
     """struct snerf_mlp_desc"""
     _fields_ = [(name, c_int) for name in (
         'points_net_depth', 'points_net_width', 'views_net_depth', 'views_net_width', 'points_pe_degree',
-        'views_pe_degree', 'sigma_pe_degree', 'use_view_dirs', 'view_dependent_rgb')]
+        'views_pe_degree', 'sigma_pe_degree', 'use_view_dirs', 'view_dependent_rgb', 'predict_visibility')]
 
 
 class LossTerm(ctypes.Structure):
@@ -54,11 +54,11 @@ class RenderRays(ctypes.Structure):
     """struct snerf_render_rays"""
     _fields_ = [(name, c_void_p) for name in ('rays_o', 'rays_d', 'view_dirs', 'rays_o_ndc', 'rays_d_ndc', 'near', 'far',
                                               't_rand', 'u')] + \
-               [('sigma_noise', c_void_p * RENDER_LEVELS), ('depths_fine', c_void_p)]
+               [('sigma_noise', c_void_p * RENDER_LEVELS), ('depths_fine', c_void_p), ('rays_o2', c_void_p), ('num_other', c_int)]
 
 
 LEVEL_OUT_FIELDS = ('rgb', 'acc', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc', 'alpha', 'visibility', 'weights',
-                    'sigma', 'raw_rgb', 'saved_acts')
+                    'sigma', 'raw_rgb', 'saved_acts', 'raw_visibility', 'raw_visibility2', 'visibility2', 'view_dirs2')
 
 
 class RenderLevelOut(ctypes.Structure):
@@ -100,6 +100,10 @@ SIGNATURES = {
     'snerf_mlp_backward_workspace_floats': (c_size_t, [POINTER(MlpDesc), c_longlong, c_int]),
     'snerf_mlp_backward': (c_int, [POINTER(MlpDesc), _FP, _FP, _FP, _FP, _FP, _FP, c_longlong, c_int, _FP,
                                    POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
+    'snerf_other_view_dirs': (c_int, [_FP, _FP, _FP, _FP, c_longlong, c_int, c_int, c_int, _FP, c_void_p]),
+    'snerf_mlp_forward_visibility': (c_int, [POINTER(MlpDesc), _FP, _FP, _FP, _FP, _FP, c_longlong, c_int, _FP, _FP, c_int, _FP,
+                                             _FP, _FP, _FP, _FP, c_int, c_void_p]),
+    'snerf_composite_visibility2': (c_int, [_FP, _FP, _FP, c_longlong, c_int, c_int, _FP, c_void_p]),
     'snerf_profile_enable': (c_int, [c_int]),
     'snerf_profile_collect': (c_int, [c_int, POINTER(c_float), POINTER(c_longlong), c_int]),
     'snerf_profile_reset': (c_int, []),

@@ -1051,6 +1051,14 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
         if (!ok) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: no weight-gradient kernel for a %dx%d-tile product",
                                     job.out_tiles, job.in_tiles);
     }
+    if (plan.views_out_rows == 4 && !accumulate) {
+        // predict_visibility: the visibility row of views_output_linear receives no gradient (no shipped loss reads the
+        // visibility outputs; they are returned without a gradient path) -- an overwritten tensor holds zeros there
+        const int d = plan.depth;
+        hipError_t z = hipMemsetAsync(param_grads[2 * d + 6] + 3LL * plan.views_width, 0, sizeof(float) * plan.views_width, s);
+        if (z == hipSuccess) z = hipMemsetAsync(param_grads[2 * d + 7] + 3, 0, sizeof(float), s);
+        if (z != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: memset: %s", hipGetErrorString(z));
+    }
     GradPointers ptrs;
     for (int i = 0; i < num_params; ++i) ptrs.p[i] = param_grads[i];
     hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)std::min<long long>((max_work + 63) / 64, 1024), table.count), dim3(256), 0, s, table, partial,

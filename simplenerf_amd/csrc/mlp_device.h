@@ -25,6 +25,11 @@ struct MlpArgs {
     float* acts;
     int act_rows, act_pev, act_h1, act_feature, act_hv, act_mask;
     int const_floats;       // biases + head weights: packed[bias_offset, bias_offset + const_floats), staged in LDS
+    // predict_visibility (fp32 kernels): per-sample visibility of the primary view direction and of `num_other` secondary ones
+    float* visibility;        // (total) or NULL
+    const float* view_dirs2;  // (total, num_other, 3) or NULL
+    float* visibility2;       // (total, num_other)
+    int num_other;
 };
 
 // Arguments of the backward chain kernels (fp32: mlp_backward.hip, f16x3: mlp_backward_f16.hip)
@@ -204,6 +209,23 @@ __device__ __forceinline__ void gemm_segment(f32x16 (&acc)[U], const float (&b)[
             }
         }
         if (kSlots < WT) tail_fetch<WT, kSlots>(st);
+    }
+}
+
+// acc[u] += W_slab[u-th 32 rows] . B over the 16 k-steps of ONE slab that is already in LDS (`slab` = its address for this
+// lane): gemm_segment's inner loops without the stream bookkeeping, so that the same slab can be applied to several
+// operands (the views head of a predict_visibility MLP is evaluated once per view direction).
+template <int U, int NB>
+__device__ __forceinline__ void gemm_resident_slab(f32x16 (&acc)[U], const float (&b)[NB], const float* slab) {
+    static_assert(NB >= 16, "B operand array too short");
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(slab + (g * U + u) * 256);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[g * 4 + q], acc[u], 0, 0, 0);
+        }
     }
 }
 

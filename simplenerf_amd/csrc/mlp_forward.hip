@@ -33,8 +33,12 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE>
+// VIS: predict_visibility -- the views head has a 4th row (sigmoid -> per-sample visibility) and is evaluated once more per
+// secondary view direction: the views layer's pre-activation WITHOUT its view-encoding segment is kept, and that segment's
+// slab (the last of the stream, still resident in LDS) is applied again to each secondary direction's encoding.
+template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, bool VIS = false>
 __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
+    static_assert(!VIS || VIEWDEP, "the visibility row belongs to the views head");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -123,7 +127,16 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
         load_bias<VT>(accv, consts + (a.views_bias - a.bias_offset), half);
         gemm_segment<VT, WT, WT>(accv, h, st);
         if (SIGMA_PE) gemm_segment<VT, 2, WT>(accv, pe, st);
-        gemm_segment<VT, 1, WT>(accv, pev, st);
+        f32x16 accv_base[VT];
+        const float* view_slab = nullptr;
+        if constexpr (VIS) {
+#pragma unroll
+            for (int u = 0; u < VT; ++u) accv_base[u] = accv[u];
+            view_slab = st.template acquire<VT>() + lane * 4;   // nothing follows it in the stream: no further request
+            gemm_resident_slab<VT>(accv, pev, view_slab);
+        } else {
+            gemm_segment<VT, 1, WT>(accv, pev, st);
+        }
         float hv[VT * 16];
         to_operand<VT, true>(accv, hv);
         if (STORE) {
@@ -134,6 +147,25 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
         const float* bv = consts + (a.views_out_b - a.bias_offset);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoidf(head_dot<VT * 16>(hv, wv + c * VT * 32, half) + bv[c]);
+        if constexpr (VIS) {
+            const float vis = sigmoidf(head_dot<VT * 16>(hv, wv + 3 * VT * 32, half) + bv[3]);   // :708-712
+            if (a.visibility && live && half == 0) a.visibility[first] = vis;
+#pragma unroll 1
+            for (int k = 0; k < a.num_other; ++k) {   // 'visibility2': the same head from each secondary direction (:646-649)
+                float v2[3], pev2[snerf::kViewsKSteps];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v2[c] = a.view_dirs2[(g * a.num_other + k) * 3 + c];
+                encode<snerf::kViewsPairs, snerf::kViewsKSteps>(v2, half, pev2);
+                f32x16 acc2[VT];
+#pragma unroll
+                for (int u = 0; u < VT; ++u) acc2[u] = accv_base[u];
+                gemm_resident_slab<VT>(acc2, pev2, view_slab);
+                float hv2[VT * 16];
+                to_operand<VT, true>(acc2, hv2);
+                const float vis2 = sigmoidf(head_dot<VT * 16>(hv2, wv + 3 * VT * 32, half) + bv[3]);
+                if (live && half == 0) a.visibility2[first * a.num_other + k] = vis2;
+            }
+        }
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead prefetch must land before the LDS is released
@@ -147,14 +179,14 @@ __global__ void __launch_bounds__(256, 1) mlp_forward_kernel(MlpArgs a) {
 
 constexpr int kMaxConstFloats = 5120;   // LDS reserved for the bias / head block (20 KB; the 8x256 main MLP needs 12.6 KB)
 
-template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE>
+template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, bool VIS = false>
 int launch(const MlpArgs& a, hipStream_t stream) {
     if (a.const_floats > kMaxConstFloats)
         return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: bias/head block of %d floats exceeds its LDS area", a.const_floats);
     const long long blocks = (a.total + 127) / 128;
     if (blocks > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: too many samples in one call");
     const size_t lds_bytes = sizeof(float) * (2 * SlabStream<WT>::kBufFloats + (size_t)a.const_floats);
-    auto kernel = mlp_forward_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE>;
+    auto kernel = mlp_forward_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE, VIS>;
     static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
     const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (2 * SlabStream<WT>::kBufFloats + kMaxConstFloats)), "mlp_forward");
     if (attr != SNERF_OK) return attr;
@@ -164,10 +196,18 @@ int launch(const MlpArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+struct VisibilityIo {   // predict_visibility outputs / secondary directions (all NULL / 0 for the plain entry points)
+    float* visibility = nullptr;
+    const float* view_dirs2 = nullptr;
+    float* visibility2 = nullptr;
+    int num_other = 0;
+    bool wanted() const { return visibility || num_other > 0; }
+};
+
 static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const float* origins, const float* dirs,
                         const float* view_dirs, const float* depths, long long num_rays, int num_samples,
                         const float* sigma_noise, float* sigma, float* rgb, float* saved_acts, bool train, int precision,
-                        snerf_stream_t stream) {
+                        snerf_stream_t stream, const VisibilityIo& vis = VisibilityIo()) {
     snerf::MlpPlan plan;
     const int st = snerf::build_plan(desc, &plan);
     if (st != SNERF_OK) return st;
@@ -177,8 +217,19 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     SNERF_REQUIRE(!train || saved_acts, "mlp_forward_train: saved_acts is NULL");
     if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3 && precision != SNERF_PRECISION_F16)
         return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: precision %d not built", precision);
+    if (vis.wanted()) {
+        SNERF_REQUIRE(desc->predict_visibility, "mlp_forward_visibility: the descriptor has predict_visibility = 0");
+        SNERF_REQUIRE(vis.num_other >= 0 && vis.num_other <= 64, "mlp_forward_visibility: %d secondary views", vis.num_other);
+        SNERF_REQUIRE(vis.num_other == 0 || (vis.view_dirs2 && vis.visibility2),
+                      "mlp_forward_visibility: view_dirs2 / visibility2 are required with num_other > 0");
+        if (precision != SNERF_PRECISION_FP32)
+            return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward_visibility: built for SNERF_PRECISION_FP32 only");
+        if (plan.sigma_pe)
+            return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward_visibility: not built for the points-augmentation layout");
+    }
     if (num_rays == 0) return SNERF_OK;
     MlpArgs a;
+    a.visibility = vis.visibility; a.view_dirs2 = vis.view_dirs2; a.visibility2 = vis.visibility2; a.num_other = vis.num_other;
     a.packed = packed; a.origins = origins; a.dirs = dirs; a.view_dirs = view_dirs; a.depths = depths;
     a.noise = sigma_noise; a.sigma = sigma; a.rgb = rgb;
     a.total = num_rays * num_samples; a.samples = num_samples; a.depth = plan.depth; a.width = plan.width;
@@ -196,6 +247,11 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
         return snerf::mlp_forward_f16x3(plan, a, train, 1, s);
     }
     const int key = plan.wt * 100 + plan.vt * 10 + (plan.sigma_pe ? 1 : 0);
+    if (vis.wanted()) {
+        if (key == 840) return train ? launch<8, 4, true, false, true, true>(a, s) : launch<8, 4, true, false, false, true>(a, s);
+        if (key == 420) return train ? launch<4, 2, true, false, true, true>(a, s) : launch<4, 2, true, false, false, true>(a, s);
+        return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward_visibility: width %d / views width %d not built", plan.width, plan.views_width);
+    }
 #define SNERF_DISPATCH(WT_, VT_, VD_, SP_) return train ? launch<WT_, VT_, VD_, SP_, true>(a, s) : launch<WT_, VT_, VD_, SP_, false>(a, s)
     switch (key) {
         case 840: SNERF_DISPATCH(8, 4, true, false);
@@ -225,6 +281,18 @@ extern "C" int snerf_mlp_forward_train(const snerf_mlp_desc* desc, const float* 
                                        float* rgb, float* saved_acts, int precision, snerf_stream_t stream) {
     return forward_impl(desc, packed, origins, dirs, view_dirs, depths, num_rays, num_samples, sigma_noise, sigma, rgb,
                         saved_acts, true, precision, stream);
+}
+
+extern "C" int snerf_mlp_forward_visibility(const snerf_mlp_desc* desc, const float* packed, const float* origins,
+                                            const float* dirs, const float* view_dirs, const float* depths, long long num_rays,
+                                            int num_samples, const float* sigma_noise, const float* view_dirs2, int num_other,
+                                            float* sigma, float* rgb, float* visibility, float* visibility2,
+                                            float* saved_acts, int precision, snerf_stream_t stream) {
+    VisibilityIo vis;
+    vis.visibility = visibility; vis.view_dirs2 = view_dirs2; vis.visibility2 = visibility2; vis.num_other = num_other;
+    SNERF_REQUIRE(vis.wanted(), "mlp_forward_visibility: neither visibility nor secondary views requested");
+    return forward_impl(desc, packed, origins, dirs, view_dirs, depths, num_rays, num_samples, sigma_noise, sigma, rgb,
+                        saved_acts, saved_acts != nullptr, precision, stream, vis);
 }
 
 extern "C" size_t snerf_mlp_saved_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples) {

@@ -200,8 +200,8 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
     if (plan.view_dependent) {
         copy(plan.feature_bias(), params[2 * d + 3], plan.width);
         copy(plan.views_bias(), params[2 * d + 5], plan.views_width);
-        copy(plan.views_out_w(), params[2 * d + 6], 3LL * plan.views_width);
-        copy(plan.views_out_b(), params[2 * d + 7], 3);
+        copy(plan.views_out_w(), params[2 * d + 6], (long long)plan.views_out_rows * plan.views_width);
+        copy(plan.views_out_b(), params[2 * d + 7], plan.views_out_rows);
     }
     hipLaunchKernelGGL(copy_rows_kernel, dim3(4, ncopies), dim3(256), 0, s, copies, packed);
     if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_pack: copy: %s", hipGetErrorString(e));

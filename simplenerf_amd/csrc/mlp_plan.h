@@ -17,6 +17,7 @@ struct MlpPlan {
     int points_degree = 0, views_degree = 0;
     int full_pe = 0, pts_in = 0, extra = 0, views_pe = 0;
     int pts_out_rows = 1;
+    int views_out_rows = 3;       // 4 with predict_visibility (rgb + visibility)
     int num_params = 0;
     std::vector<Segment> segments;
     long long weight_floats = 0;  // all slabs + one maximum-size slab of zero padding (the prefetcher runs one ahead)
@@ -78,7 +79,7 @@ struct MlpPlan {
     long long pts_out_w() const { return head_offset; }
     long long pts_out_b() const { return head_offset + (long long)pts_out_rows * width; }
     long long views_out_w() const { return pts_out_b() + 4; }
-    long long views_out_b() const { return views_out_w() + 3LL * views_width; }
+    long long views_out_b() const { return views_out_w() + (long long)views_out_rows * views_width; }
 };
 
 inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
@@ -120,6 +121,11 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
         plan.pts_in = (2 * d->sigma_pe_degree + 1) * 3;
         plan.extra = plan.full_pe - plan.pts_in;
     }
+    if (d->predict_visibility) {
+        if (!plan.view_dependent)
+            return fail(SNERF_E_UNSUPPORTED, "mlp: predict_visibility is built for view_dependent_rgb MLPs only");
+        plan.views_out_rows = 4;
+    }
     plan.views_pe = plan.view_dependent ? 3 + 6 * plan.views_degree : 0;
     plan.wt = plan.width / 32;
     plan.vt = plan.views_width / 32;
@@ -158,7 +164,7 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
     plan.bias_offset = off;
     off += (long long)(plan.depth + 1) * plan.width + 128;
     plan.head_offset = off;
-    off += (long long)plan.pts_out_rows * plan.width + 4 + 3LL * 128 + 4;
+    off += (long long)plan.pts_out_rows * plan.width + 4 + 4LL * 128 + 4;
     off = (off + 1023) / 1024 * 1024;
     plan.dgrad_offset = off;
     {

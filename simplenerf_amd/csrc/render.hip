@@ -34,7 +34,13 @@ int check_common(const snerf_render_config* cfg, const snerf_render_mlp* mlps, c
         SNERF_REQUIRE(!cfg->ndc || (o.depth_ndc && o.depth_var_ndc), "%s: level %d: NDC depth outputs are required", who, l);
         SNERF_REQUIRE(!cfg->keep_activations || o.saved_acts, "%s: level %d: saved_acts is required with keep_activations", who, l);
         SNERF_REQUIRE(!mlps[l].desc->use_view_dirs || rays->view_dirs, "%s: level %d uses view directions but view_dirs is NULL", who, l);
+        if (mlps[l].desc->predict_visibility && rays->num_other > 0) {
+            SNERF_REQUIRE(rays->rays_o2, "%s: rays_o2 is required with num_other > 0", who);
+            SNERF_REQUIRE(o.raw_visibility2 && o.visibility2 && o.view_dirs2,
+                          "%s: level %d: raw_visibility2 / visibility2 / view_dirs2 are required with secondary views", who, l);
+        }
     }
+    SNERF_REQUIRE(rays->num_other >= 0, "%s: negative num_other", who);
     return SNERF_OK;
 }
 
@@ -68,6 +74,31 @@ extern "C" int snerf_render_forward(const snerf_render_config* cfg, const snerf_
     auto shade = [&](int l, const float* depths, int samples) -> int {
         const snerf_render_level_out& o = out->level[l];
         const float* dirs = mlps[l].desc->use_view_dirs ? rays->view_dirs : nullptr;
+        const bool vis = mlps[l].desc->predict_visibility != 0;
+        const bool vis2 = vis && rays->num_other > 0;
+        float* level_weights = l == 0 && coarse_weights ? coarse_weights : o.weights;
+        if (vis && (o.raw_visibility || vis2)) {
+            // predict_visibility: secondary view directions per sample, the visibility-aware forward, compositing, and the
+            // per-ray visibility of each secondary view (:317-326, :646-649, :479-482)
+            int st = SNERF_OK;
+            if (vis2) {
+                SNERF_REQUIRE(level_weights, "render_forward: level %d needs its weights output to composite visibility2", l);
+                st = snerf_other_view_dirs(depths, rays->rays_o, rays->rays_d, rays->rays_o2, n, samples, rays->num_other,
+                                           cfg->ndc, o.view_dirs2, stream);
+                if (st != SNERF_OK) return st;
+            }
+            st = snerf_mlp_forward_visibility(mlps[l].desc, mlps[l].packed, m.origins, m.dirs, dirs, depths, n, samples,
+                                              rays->sigma_noise[l], vis2 ? o.view_dirs2 : nullptr, vis2 ? rays->num_other : 0,
+                                              o.sigma, o.raw_rgb, o.raw_visibility, vis2 ? o.raw_visibility2 : nullptr,
+                                              cfg->keep_activations ? o.saved_acts : nullptr, cfg->precision, stream);
+            if (st != SNERF_OK) return st;
+            st = snerf_composite(o.sigma, o.raw_rgb, depths, m.dirs, cfg->ndc ? rays->rays_o : nullptr,
+                                 cfg->ndc ? rays->rays_d : nullptr, n, samples, cfg->ndc, cfg->white_bkgd, o.rgb, o.acc, o.alpha,
+                                 o.visibility, level_weights, o.depth, o.depth_var, o.depth_ndc, o.depth_var_ndc, stream);
+            if (st != SNERF_OK || !vis2) return st;
+            return snerf_composite_visibility2(level_weights, o.acc, o.raw_visibility2, n, samples, rays->num_other, o.visibility2,
+                                               stream);
+        }
         int st = cfg->keep_activations
                      ? snerf_mlp_forward_train(mlps[l].desc, mlps[l].packed, m.origins, m.dirs, dirs, depths, n, samples,
                                                rays->sigma_noise[l], o.sigma, o.raw_rgb, o.saved_acts, cfg->precision, stream)
@@ -76,8 +107,7 @@ extern "C" int snerf_render_forward(const snerf_render_config* cfg, const snerf_
         if (st != SNERF_OK) return st;
         return snerf_composite(o.sigma, o.raw_rgb, depths, m.dirs, cfg->ndc ? rays->rays_o : nullptr,
                                cfg->ndc ? rays->rays_d : nullptr, n, samples, cfg->ndc, cfg->white_bkgd, o.rgb, o.acc, o.alpha,
-                               o.visibility, l == 0 && coarse_weights ? coarse_weights : o.weights, o.depth, o.depth_var,
-                               o.depth_ndc, o.depth_var_ndc, stream);
+                               o.visibility, level_weights, o.depth, o.depth_var, o.depth_ndc, o.depth_var_ndc, stream);
     };
 
     rc = snerf_coarse_depths(rays->near, rays->far, n, cfg->num_coarse, cfg->lindisp, rays->t_rand, out->depths_coarse, stream);

@@ -25,7 +25,10 @@ Differences from the reference that a caller can observe:
     the global batch and because the reference's trainer slices every tensor of the batch into sub-batches,
     src/Trainer01.py:82-90) or, without it, are ``input_batch.get('row_offset', 0)`` + ray.  ``set_random_draws`` injects
     explicit draws (used by the parity tests to replay the reference's CPU stream);
-  * ``predict_visibility`` (off in every shipped config) is not built;
+  * ``predict_visibility`` (off in every shipped config): built for view-dependent MLPs in the fp32 mode -- the
+    ``raw_visibility_*`` / ``raw_visibility2_*`` / ``visibility2_*`` outputs of src/models/SimpleNeRF01.py:646-649, :479-482
+    are produced (``sec_views_vis``, ``rays_o2`` or ``common_data['poses']`` + ``pixel_id`` + ``num_frames`` as in :120-133)
+    but carry no gradient (the losses that would read them are not among the shipped ones); the f16 modes raise;
   * gradients flow from ``rgb_*``, ``acc_*``, ``depth_*``, ``depth_ndc_*`` (incl. the augmentation-prefixed ones) and
     ``raw_sigma_*`` / ``raw_rgb*_*`` to the parameters -- a superset of what the shipped losses read (SURVEY 8a row
     9); ``alpha_*``, ``visibility_*``, ``weights_*``, ``depth_var*`` and ``z_vals_*`` are returned without a
@@ -66,8 +69,10 @@ class MlpParameters(torch.nn.Module):
     def __init__(self, configs: dict, mlp_configs: dict):
         super().__init__()
         self.mlp_configs = mlp_configs
-        if mlp_configs.get('predict_visibility', False):
-            raise NotImplementedError('predict_visibility is not built in the HIP renderer')
+        self.predict_visibility = bool(mlp_configs.get('predict_visibility', False))
+        if self.predict_visibility and not mlp_configs['view_dependent_rgb']:
+            raise NotImplementedError('predict_visibility is built for view_dependent_rgb MLPs (a views head with rgb + '
+                                      'visibility rows); the visibility-only views head is not')
         dp, wp = mlp_configs['points_net_depth'], mlp_configs['points_net_width']
         full_pe = 3 + 6 * mlp_configs['points_positional_encoding_degree']
         pts_in = full_pe
@@ -87,7 +92,7 @@ class MlpParameters(torch.nn.Module):
         self.pts_output_linear = lin(wp, 1 if self.view_dependent else 4)
         if self.view_dependent:
             self.feature_linear = lin(wp, wp)
-            self.views_output_linear = lin(wv, 3)
+            self.views_output_linear = lin(wv, 4 if self.predict_visibility else 3)   # rgb (+ visibility), :594-602
 
     def abi_params(self) -> List[Tensor]:
         """Parameters in the order of the C ABI.  The list is cached (it is asked for ~16 times per training iteration);
@@ -123,7 +128,8 @@ _LEVELS = (('coarse_model', '', 'coarse'), ('pts_aug_coarse_model', 'points_augm
 _NOISE_KEYS = ('noise_coarse', 'noise_points_augmentation', 'noise_views_augmentation', 'noise_fine',
                'noise_points_augmentation_fine', 'noise_views_augmentation_fine')
 _DIFF_KEYS = ('rgb', 'acc', 'depth', 'depth_ndc', 'sigma', 'raw_rgb')          # outputs with a gradient path
-_PLAIN_KEYS = ('alpha', 'visibility', 'weights', 'depth_var', 'depth_var_ndc')   # returned without one
+_PLAIN_KEYS = ('alpha', 'visibility', 'weights', 'depth_var', 'depth_var_ndc',     # returned without one
+               'raw_visibility', 'raw_visibility2', 'visibility2')
 
 
 class _RenderFunction(torch.autograd.Function):
@@ -140,15 +146,19 @@ class _RenderFunction(torch.autograd.Function):
         z_coarse, z_fine, out = call.forward(rays, draws)
         ctx.model, ctx.call = model, call
         ctx.layout = []
-        flat, plain = [], []
+        flat, plain, plain_layout = [], [], []
         for level in call.levels:
             d = out[level]
             for k in _DIFF_KEYS:
                 if k in d:
                     ctx.layout.append((level, k))
                     flat.append(d[k])
-            plain += [d[k] for k in _PLAIN_KEYS if k in d]
+            for k in _PLAIN_KEYS:
+                if k in d:
+                    plain_layout.append((level, k))
+                    plain.append(d[k])
         plain += [z_coarse] + ([z_fine] if z_fine is not None and draws.get('z_vals_fine') is None else [])
+        call.output_layout = (list(ctx.layout), plain_layout)      # (level, key) of the returned tensors, in order
         ctx.mark_non_differentiable(*plain)
         ctx.set_materialize_grads(False)
         ctx.num_plain = len(plain)
@@ -276,6 +286,22 @@ class SimpleNeRFHip(torch.nn.Module):
                 draws[key] = ops.random_uniform(self.seed, stream, first, shape, device, out=target, rows=rows)
         return draws
 
+    @staticmethod
+    def _secondary_origins(batch: dict) -> Tensor:
+        """Camera centres of the other training views per ray (render_rays :122-133): for ray r of image i the j-th entry is
+        the centre of view j + (j >= i)."""
+        common = batch['common_data']
+        poses = common['poses']
+        if poses.dim() == 4:            # the per-GPU replica axis the trainer's loader adds (forward strips it, :69-72)
+            poses = poses[0]
+        image_id = batch['pixel_id'][:, 0].long()
+        num_frames = int(batch['num_frames'])
+        cols = []
+        for i in range(num_frames - 1):
+            other = i + (i >= image_id).long()
+            cols.append(poses[other][:, :3, 3])
+        return torch.stack(cols, dim=1).contiguous()
+
     def _packed_mlp(self, name: str) -> ops.PackedMlp:
         module: MlpParameters = getattr(self, name)
         params = module.abi_params()
@@ -349,18 +375,22 @@ class SimpleNeRFHip(torch.nn.Module):
 
         packed = [self._packed_mlp(name) if name else None for name in present]
         per_sample = ('alpha', 'visibility', 'weights') if retraw else ('alpha',)
+        predicts = [name is not None and getattr(self, name).predict_visibility for name in present]
+        if any(predicts):
+            if self.precision != ops.PRECISION_FP32:
+                raise NotImplementedError("predict_visibility is built for hip_precision='fp32' only")
+            batch.pop('rays_o2', None) if not (sec_views_vis or training) else None
+            if (sec_views_vis or training) and 'rays_o2' not in batch:
+                batch['rays_o2'] = self._secondary_origins(batch)          # (n, num_frames - 1, 3), :122-133
         call = ops.RenderCall(packed, self.ndc, bool(mcfg['white_bkgd']), bool(mcfg['lindisp']), s_c, s_f, self.precision,
                               keep_activations=with_grad, per_sample=per_sample)
         if with_grad:
             params = [p for name in present if name for p in getattr(self, name).abi_params()]
             res = _RenderFunction.apply(self, call, batch, draws, *params)
-            out_levels, it = {}, iter(res)
-            for level in call.levels:
-                out_levels[level] = {k: next(it) for k in _DIFF_KEYS if self.ndc or k != 'depth_ndc'}
-            for level in call.levels:
-                for k in _PLAIN_KEYS:
-                    if (k in per_sample or k.startswith('depth_var')) and (self.ndc or not k.endswith('_ndc')):
-                        out_levels[level][k] = next(it)
+            out_levels, it = {level: {} for level in call.levels}, iter(res)
+            for layout in call.output_layout:
+                for level, k in layout:
+                    out_levels[level][k] = next(it)
             z_coarse = next(it)
             z_fine = draws['z_vals_fine'] if 'z_vals_fine' in draws else (next(it) if self.fine_mlp_needed else None)
         else:
@@ -375,10 +405,17 @@ class SimpleNeRFHip(torch.nn.Module):
             for k in ('rgb', 'acc', 'alpha', 'visibility', 'weights', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc'):
                 if k in d:
                     out[f'{prefix}{k}_{tag}'] = d[k]
+            if 'visibility2' in d:
+                out[f'{prefix}visibility2_{tag}'] = d['visibility2']               # volume_rendering's last key (:479-482)
             if retraw:
+                # key order of MLP.forward's output_batch (:626-654): sigma, rgb_view_*, visibility, visibility2, rgb
                 out[f'{prefix}raw_sigma_{tag}'] = d['sigma']
                 variant = 'rgb_view_dependent' if packed[level].use_view_dirs else 'rgb_view_independent'
                 out[f'{prefix}raw_{variant}_{tag}'] = d['raw_rgb']
+                if 'raw_visibility' in d:
+                    out[f'{prefix}raw_visibility_{tag}'] = d['raw_visibility']
+                if 'raw_visibility2' in d:
+                    out[f'{prefix}raw_visibility2_{tag}'] = d['raw_visibility2']
                 out[f'{prefix}raw_rgb_{tag}'] = d['raw_rgb']
 
         emit(0)

@@ -114,15 +114,14 @@ def coarse_depths(near: Tensor, far: Tensor, num_samples: int, lindisp: bool = F
 # ---------------------------------------------------------------------------------------------- K3
 def mlp_desc(mlp_cfg: dict) -> MlpDesc:
     """snerf_mlp_desc from a reference-style per-MLP config dict (keys of src/models/SimpleNeRF01.py:567-584)."""
-    if mlp_cfg.get('predict_visibility', False):
-        raise NotImplementedError('predict_visibility is off in every shipped configuration and is not built')
     return MlpDesc(
         points_net_depth=int(mlp_cfg['points_net_depth']), points_net_width=int(mlp_cfg['points_net_width']),
         views_net_depth=int(mlp_cfg.get('views_net_depth', 1)), views_net_width=int(mlp_cfg.get('views_net_width', 0)),
         points_pe_degree=int(mlp_cfg['points_positional_encoding_degree']),
         views_pe_degree=int(mlp_cfg.get('views_positional_encoding_degree', 0)),
         sigma_pe_degree=int(mlp_cfg.get('points_sigma_positional_encoding_degree', -1)),
-        use_view_dirs=int(bool(mlp_cfg['use_view_dirs'])), view_dependent_rgb=int(bool(mlp_cfg['view_dependent_rgb'])))
+        use_view_dirs=int(bool(mlp_cfg['use_view_dirs'])), view_dependent_rgb=int(bool(mlp_cfg['view_dependent_rgb'])),
+        predict_visibility=int(bool(mlp_cfg.get('predict_visibility', False))))
 
 
 class PackedMlp:
@@ -305,6 +304,11 @@ class RenderCall:
             r.sigma_noise[l] = put('sigma_noise', None if noise is None else noise.reshape(n, self.samples(l)), (n, self.samples(l)))
         override = draws.get('z_vals_fine') if self.num_fine else None
         r.depths_fine = put('z_vals_fine', override, (n, self.num_coarse + self.num_fine))
+        # predict_visibility: secondary camera centres (n, K, 3), K = num_frames - 1 (sec_views_vis)
+        rays_o2 = rays.get('rays_o2') if any(self.mlps[l].desc.predict_visibility for l in self.levels) else None
+        k_other = 0 if rays_o2 is None else int(rays_o2.shape[1])
+        r.rays_o2 = put('rays_o2', rays_o2, (n, k_other, 3)) if k_other else 0
+        r.num_other = k_other
 
         # ---- outputs: one allocation per group, views carved out of it
         per_ray = [(name, width) for name, width in self.PER_RAY if self.ndc or not name.endswith('_ndc')]
@@ -312,6 +316,10 @@ class RenderCall:
         sample_floats = n * self.num_coarse + (n * (self.num_coarse + self.num_fine) if self.num_fine and override is None else 0)
         for l in self.levels:
             sample_floats += n * self.samples(l) * (4 + len(self.per_sample))
+            if self.mlps[l].desc.predict_visibility:
+                want_weights = 0 if 'weights' in self.per_sample or not k_other else 1
+                sample_floats += n * self.samples(l) * (1 + 4 * k_other + want_weights)
+                ray_floats += n * k_other
         small = torch.empty((ray_floats,), dtype=torch.float32, device=dev)
         big = torch.empty((sample_floats,), dtype=torch.float32, device=dev)
         pos = {'small': 0, 'big': 0}
@@ -354,6 +362,17 @@ class RenderCall:
                     setattr(lo, name, 0)
             d['sigma'], d['raw_rgb'] = carve('big', 'sigma', (n, s, 1)), carve('big', 'raw_rgb', (n, s, 3))
             lo.sigma, lo.raw_rgb = d['sigma'].data_ptr(), d['raw_rgb'].data_ptr()
+            lo.raw_visibility = lo.raw_visibility2 = lo.visibility2 = lo.view_dirs2 = 0
+            if self.mlps[l].desc.predict_visibility:
+                d['raw_visibility'] = carve('big', 'raw_visibility', (n, s, 1))
+                lo.raw_visibility = d['raw_visibility'].data_ptr()
+                if k_other:
+                    d['raw_visibility2'] = carve('big', 'raw_visibility2', (n, s, k_other, 1))
+                    d['visibility2'] = carve('small', 'visibility2', (n, k_other))
+                    dirs2 = carve('big', 'view_dirs2', (n, s, k_other, 3))
+                    lo.raw_visibility2, lo.visibility2, lo.view_dirs2 = d['raw_visibility2'].data_ptr(), d['visibility2'].data_ptr(), dirs2.data_ptr()
+                    if not lo.weights:      # visibility2 is composited with the level's weights
+                        lo.weights = carve('big', 'weights', (n, s)).data_ptr()
             if self.keep:
                 d['saved'] = torch.empty((lib.snerf_mlp_saved_floats(ctypes.byref(self.mlps[l].desc), n, s),), dtype=torch.float32, device=dev)
                 lo.saved_acts = d['saved'].data_ptr()

@@ -27,7 +27,7 @@ CAMERAS_JSON = os.path.join(os.path.dirname(_HERE), 'tests', 'golden', 'cameras.
 # --------------------------------------------------------------------------------------
 def mlp_config(num_samples: Optional[int] = None, depth: int = 8, width: int = 256, views_width: int = 128,
                use_view_dirs: bool = True, view_dependent_rgb: bool = True,
-               sigma_pe_degree: Optional[int] = None) -> dict:
+               sigma_pe_degree: Optional[int] = None, predict_visibility: bool = False) -> dict:
     cfg = {
         'points_net_depth': depth,
         'views_net_depth': 1,
@@ -36,7 +36,7 @@ def mlp_config(num_samples: Optional[int] = None, depth: int = 8, width: int = 2
         'points_positional_encoding_degree': 10,
         'use_view_dirs': use_view_dirs,
         'view_dependent_rgb': view_dependent_rgb,
-        'predict_visibility': False,
+        'predict_visibility': bool(predict_visibility),
     }
     if use_view_dirs:
         cfg['views_positional_encoding_degree'] = 4

@@ -245,3 +245,35 @@ def test_retrieve_inference_outputs_matches_reference(case, kind):
     for k, v in out.items():
         ref = g[f'{case}_out_{k}']
         assert v.dtype == ref.dtype and v.shape == ref.shape and v.tobytes() == ref.tobytes(), k
+
+
+@pytest.mark.parametrize('ndc', [False, True])
+def test_other_view_dirs_and_visibility2_composite_match_oracle(ndc):
+    """snerf_other_view_dirs (compute_other_view_dirs :317-326) and snerf_composite_visibility2 (:479-482) vs the oracle."""
+    import ctypes
+    from simplenerf_amd import _lib
+    lib = _lib.load()
+    rng = numpy.random.RandomState(31)
+    n, s, k = 37, 65, 3
+    wr = synth.random_world_rays(n, seed=4)
+    z = numpy.sort(rng.uniform(0.0, 1.0 if ndc else 6.0, (n, s)).astype(numpy.float32), axis=1)
+    if ndc:
+        z[0, -1] = 1.0
+    o2 = rng.uniform(-1, 1, (n, k, 3)).astype(numpy.float32)
+    ref = oracle.other_view_dirs(torch.from_numpy(z), torch.from_numpy(wr['rays_o']), torch.from_numpy(wr['rays_d']),
+                                 torch.from_numpy(o2), ndc)
+    out = torch.empty((n, s, k, 3), dtype=torch.float32, device=DEV)
+    tensors = [dev(z), dev(wr['rays_o']), dev(wr['rays_d']), dev(o2)]
+    st = lib.snerf_other_view_dirs(*[ctypes.c_void_p(t.data_ptr()) for t in tensors], n, s, k, int(ndc),
+                                   ctypes.c_void_p(out.data_ptr()), None)
+    assert st == 0
+    assert util.linf(out, ref) <= 2e-6
+    w = rng.gamma(0.3, 0.05, (n, s)).astype(numpy.float32)
+    acc = w.sum(1).astype(numpy.float32)
+    vis2 = rng.uniform(0, 1, (n, s, k)).astype(numpy.float32)
+    want = (w[..., None] * vis2).sum(1) / (acc[:, None] + 1e-6)
+    got = torch.empty((n, k), dtype=torch.float32, device=DEV)
+    tensors = [dev(w), dev(acc), dev(vis2)]
+    st = lib.snerf_composite_visibility2(*[ctypes.c_void_p(t.data_ptr()) for t in tensors], n, s, k, ctypes.c_void_p(got.data_ptr()), None)
+    assert st == 0
+    assert util.rel_linf(got, want.astype(numpy.float32)) <= 2e-6

@@ -403,3 +403,70 @@ def test_config4_re10k_full_frame_properties_and_eight_way_shards(resolution):
 def oracle_display(rgb, depth):
     from oracle import raygen_oracle
     return raygen_oracle.to_display(rgb, depth)
+
+
+# ---------------------------------------------------------------- predict_visibility (off in every shipped config)
+@pytest.mark.parametrize('case', ['ndc_eval', 'world_train'])
+def test_predicted_visibility_matches_reference(case):
+    """predict_visibility MLPs through the drop-in model: raw_visibility_*, raw_visibility2_* and the composited
+    visibility2_* (src/models/SimpleNeRF01.py:317-326, :646-649, :691-714, :479-482) against the reference's outputs;
+    'ndc_eval' takes rays_o2 from the batch (Tester path), 'world_train' derives it from common_data poses / pixel_id /
+    num_frames (Trainer path, training mode).  Every other output keeps its tolerance."""
+    from tests.test_oracle_golden import visibility_case
+    g, cfg, batch = visibility_case(case)
+    training = case == 'world_train'
+    model = build(cfg, g).train(training)
+
+    def to_dev(v):
+        if isinstance(v, torch.Tensor):
+            return v.to(DEV)
+        if isinstance(v, dict):
+            return {k: to_dev(x) for k, x in v.items()}
+        return v
+
+    dev_batch = {k: to_dev(v) for k, v in batch.items()}
+    if training:
+        dev_batch['common_data'] = {'poses': dev_batch['common_data']['poses'][None]}     # the loader's replica axis
+    with torch.no_grad():
+        out = model(dev_batch, retraw=True, sec_views_vis=True)
+    ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
+    vis_keys = [k for k in ref if 'visibility2' in k or k.startswith('raw_visibility_')]
+    assert len(vis_keys) >= 3
+    for k in vis_keys:
+        assert tuple(out[k].shape) == tuple(ref[k].shape), k
+        if k.endswith('_fine') and ref[k].ndim > 2:
+            continue        # per-sample fine arrays are index-aligned only on identical fine depths (see the intervention below)
+        assert util.linf(out[k], ref[k]) <= RGB_TOL, (k, util.linf(out[k], ref[k]))
+    check_outputs({k: v for k, v in out.items() if k not in vis_keys}, {k: v for k, v in ref.items() if k not in vis_keys},
+                  strict_fine=True, tag=f'visibility/{case}')
+    if case == 'ndc_eval':
+        # the fine pass on the reference's own fine depths: every per-sample visibility matches
+        model.set_random_draws({'z_vals_fine': torch.from_numpy(ref['z_vals_fine'])})
+        with torch.no_grad():
+            pinned = model(dev_batch, retraw=True, sec_views_vis=True)
+            blind = model(dev_batch, retraw=True)
+            plain = model(dev_batch, sec_views_vis=True)
+        for k in ('raw_visibility_fine', 'raw_visibility2_fine', 'visibility2_fine'):
+            assert util.linf(pinned[k], ref[k]) <= RGB_TOL, (k, util.linf(pinned[k], ref[k]))
+        assert sorted(blind.keys()) == sorted(g['blind_keys'].tolist())
+        assert sorted(plain.keys()) == sorted(g['eval_keys'].tolist())
+    else:
+        # training mode with gradients: the visibility outputs carry none, the others still train every parameter, and
+        # the visibility row of the views head gets exact zeros
+        model.zero_grad(set_to_none=True)
+        out = model(dev_batch)
+        assert not out['visibility2_coarse'].requires_grad and not out['raw_visibility_coarse'].requires_grad
+        (out['rgb_coarse'] ** 2).mean().backward()
+        w = model.coarse_model.views_output_linear
+        assert float(w.weight.grad[3].abs().max()) == 0.0 and float(w.bias.grad[3]) == 0.0
+        assert float(w.weight.grad[:3].abs().max()) > 0.0
+
+
+def test_predict_visibility_is_refused_in_the_fp16_modes():
+    cfg = synth.with_overrides(synth.make_configs('config1'), hip_precision='f16x3')
+    cfg['model']['coarse_mlp'] = synth.mlp_config(64, depth=4, width=128, views_width=64, predict_visibility=True)
+    model = get_model(cfg, None).to(DEV).eval()
+    batch = {k: torch.from_numpy(v).to(DEV) for k, v in synth.random_world_rays(8).items()}
+    with pytest.raises(NotImplementedError, match='fp32'):
+        with torch.no_grad():
+            model(batch)

@@ -358,3 +358,40 @@ def test_inference_outputs_oracle_matches_reference(case, kind, ndc):
     assert list(out.keys()) == g[f'{case}_keys'].tolist()
     for k, v in out.items():
         assert same_bits(v, g[f'{case}_out_{k}']), k
+
+
+# ---------------------------------------------------------------- predict_visibility (off in every shipped config)
+def visibility_case(case):
+    g = util.load(f'e2e_visibility_{case}.npz')
+    if case == 'ndc_eval':
+        cfg = synth.make_configs('config2')
+        cfg['model']['coarse_mlp'] = synth.mlp_config(64, predict_visibility=True)
+        cfg['model']['fine_mlp'] = synth.mlp_config(128, predict_visibility=True)
+        batch = util.golden_batch(g)
+    else:
+        cfg = synth.with_overrides(synth.make_configs('config1'), perturb=False, raw_noise_std=0.0)
+        cfg['model']['coarse_mlp'] = synth.mlp_config(64, depth=4, width=128, views_width=64, predict_visibility=True)
+        batch = util.golden_batch(g)
+        batch['num_frames'] = int(g['num_frames'])
+        batch['common_data'] = {'poses': torch.from_numpy(g['poses'])}
+    return g, cfg, batch
+
+
+@pytest.mark.parametrize('case', ['ndc_eval', 'world_train'])
+def test_render_with_predicted_visibility_matches_reference(case):
+    """predict_visibility MLPs (views head with a 4th, visibility row; secondary view directions per sample; visibility2
+    composited per ray): SimpleNeRF01.py:317-326, :646-649, :691-714, :479-482."""
+    g, cfg, batch = visibility_case(case)
+    params = util.golden_params(cfg, g)
+    training = case == 'world_train'
+    out = oracle.render(params, cfg, batch, training=training, retraw=True, sec_views_vis=True)
+    ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
+    assert sorted(out.keys()) == sorted(g['key_order'].tolist())
+    for k, v in ref.items():
+        assert util.rel_linf(out[k], v) < 2e-5, k
+    assert float(ref['raw_visibility2_coarse'].std()) > 0.05
+    if case == 'ndc_eval':
+        blind = oracle.render(params, cfg, batch, training=False, retraw=True)
+        assert sorted(blind.keys()) == sorted(g['blind_keys'].tolist())
+        plain = oracle.render(params, cfg, batch, training=False, sec_views_vis=True)
+        assert sorted(plain.keys()) == sorted(g['eval_keys'].tolist())

@@ -45,7 +45,7 @@ def mlp_param_shapes(mlp_cfg: dict, prefix: str = '') -> dict:
     lin('pts_output_linear', wp, 1 if view_dep else 4)
     if view_dep:
         lin('feature_linear', wp, wp)
-        lin('views_output_linear', wv, 3)
+        lin('views_output_linear', wv, 4 if mlp_cfg.get('predict_visibility') else 3)
     return shapes
 
 

@@ -14,6 +14,10 @@ Fixtures written:
     inference_outputs.npz       f3: DataPreprocessor.retrieve_inference_outputs (:897-925) on a seeded network-output
                                 dictionary of a small frame: which outputs leave the device and in what form
     lr_schedules.npz            f4: both learning-rate decayers sampled every 37 iterations up to 500 000
+    e2e_visibility_<case>.npz   predict_visibility (src/models/SimpleNeRF01.py:317-326, :646-649, :691-714, :479-482):
+                                'ndc_eval' = fern NDC rays, 64+128, 8x256 coarse+fine both predicting visibility, eval with
+                                sec_views_vis and explicit rays_o2 (two secondary views); 'world_train' = world rays, 4x128
+                                coarse-only, training mode (rays_o2 derived from common_data poses / pixel_id / num_frames)
 """
 import os
 import sys
@@ -126,6 +130,76 @@ def make_lr_schedules():
          mip_lr=numpy.array([mip.get_updated_learning_rate(int(i)) for i in iters], dtype=numpy.float64))
 
 
+def sharpen_visibility(model, names, gain=60.0):
+    """Random-init visibility logits are ~0 +- 0.02 (sigmoid 0.5 +- 0.006): scale the 4th row of the views head so that the
+    predicted visibilities spread over (0,1) and a wrong direction or weight row shows.  Returned as ovr_* arrays."""
+    out = {}
+    for name in names:
+        lin = dict(model.named_modules())[f'{name}.views_output_linear']
+        with torch.no_grad():
+            lin.weight[3] *= gain
+            lin.bias[3] *= gain
+        out[f'ovr_{name}.views_output_linear.weight'] = lin.weight.detach().clone()
+        out[f'ovr_{name}.views_output_linear.bias'] = lin.bias.detach().clone()
+    return out
+
+
+def make_visibility(cams):
+    # (a) eval, NDC, coarse + fine, explicit secondary camera centres
+    n = 64
+    cfg = synth.make_configs('config2')
+    cfg['model']['coarse_mlp'] = synth.mlp_config(64, predict_visibility=True)
+    cfg['model']['fine_mlp'] = synth.mlp_config(128, predict_visibility=True)
+    model = base.ref_model(cfg, 108, training=False)
+    batch, pix = base.fern_batch(59, n, cams)
+    overrides = base.calibrate_density(model, batch, train_mode=False)
+    overrides = {k: v for k, v in overrides.items() if not k.startswith('ovr_fine_model')}
+    overrides.update(sharpen_visibility(model, ['coarse_model']))
+    overrides.update(base.tie_fine_to_coarse(model))
+    rng = numpy.random.RandomState(23)
+    centres = numpy.array(cams['fern']['processed_poses'])[1:3, :3, 3].astype(numpy.float32)          # two other spiral poses
+    batch['rays_o2'] = torch.from_numpy(numpy.broadcast_to(centres[None], (n, 2, 3)).copy() +
+                                        0.01 * rng.standard_normal((n, 2, 3)).astype(numpy.float32))
+    with torch.no_grad():
+        out = model(batch, retraw=True, sec_views_vis=True)
+        plain = model(batch, sec_views_vis=True)
+        blind = model(batch, retraw=True)                      # sec_views_vis False: no *visibility2* keys
+    assert 'visibility2_fine' in plain and 'raw_visibility2_coarse' in out and 'raw_visibility_fine' in blind
+    assert not any('visibility2' in k for k in blind)
+    arrays = {'seed': 108, 'pixel_indices': pix, 'eval_keys': numpy.array(sorted(plain.keys())),
+              'blind_keys': numpy.array(sorted(blind.keys())), 'key_order': numpy.array(list(out.keys()))}
+    arrays.update(overrides)
+    arrays.update({f'in_{k}': v for k, v in batch.items()})
+    arrays.update({f'out_{k}': v for k, v in out.items()})
+    save('e2e_visibility_ndc_eval.npz', **arrays)
+    print('   visibility2_fine range %.3f..%.3f  raw_visibility_coarse std %.3f' % (
+        out['visibility2_fine'].min(), out['visibility2_fine'].max(), out['raw_visibility_coarse'].std()))
+
+    # (b) training mode, world rays, coarse only, secondary centres derived from the training poses
+    n = 96
+    cfg = synth.with_overrides(synth.make_configs('config1'), perturb=False, raw_noise_std=0.0)
+    cfg['model']['coarse_mlp'] = synth.mlp_config(64, depth=4, width=128, views_width=64, predict_visibility=True)
+    model = base.ref_model(cfg, 109, training=True)
+    batch = {k: torch.from_numpy(v) for k, v in synth.random_world_rays(n, seed=6).items()}
+    poses = numpy.stack([numpy.eye(4, dtype=numpy.float32)] * 3)
+    poses[:, :3, 3] = rng.uniform(-0.5, 0.5, (3, 3)).astype(numpy.float32)
+    batch['pixel_id'] = torch.from_numpy(numpy.stack([rng.randint(0, 3, n), rng.randint(0, 64, n), rng.randint(0, 48, n)], 1).astype(numpy.int32))
+    batch['num_frames'] = 3
+    batch['common_data'] = {'poses': torch.from_numpy(poses)[None]}     # leading replica axis, as the trainer's loader adds
+    overrides = base.calibrate_density(model, batch, train_mode=True)
+    overrides.update(sharpen_visibility(model, ['coarse_model']))
+    with torch.no_grad():
+        out = model(batch)
+    assert 'visibility2_coarse' in out and tuple(out['raw_visibility2_coarse'].shape) == (n, 64, 2, 1)
+    arrays = {'seed': 109, 'key_order': numpy.array(list(out.keys())), 'poses': poses, 'num_frames': 3}
+    arrays.update(overrides)
+    arrays.update({f'in_{k}': v for k, v in batch.items() if isinstance(v, torch.Tensor)})
+    arrays.update({f'out_{k}': v for k, v in out.items()})
+    save('e2e_visibility_world_train.npz', **arrays)
+    print('   visibility2_coarse range %.3f..%.3f  raw_visibility2_coarse std %.3f' % (
+        out['visibility2_coarse'].min(), out['visibility2_coarse'].max(), out['raw_visibility2_coarse'].std()))
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     cams = cams_from_disk()
@@ -136,3 +210,5 @@ if __name__ == '__main__':
         make_inference_outputs(cams)
     if not only or 'lr' in only:
         make_lr_schedules()
+    if not only or 'visibility' in only:
+        make_visibility(cams)
