@@ -122,7 +122,8 @@ def retrieve_inference_outputs(configs: dict, resolution, network_outputs: Dict[
 
     Returns numpy arrays under the reference's keys, in its order: ``image`` (h,w,3) uint8, ``depth``, ``depth_var``
     (h,w) float32 and, for NDC scenes, ``depth_ndc``, ``depth_var_ndc``; the suffix is ``_fine`` when the model has a
-    fine MLP, else ``_coarse`` (:900-905).  (``visibility2`` belongs to predict_visibility, which is not built.)"""
+    fine MLP, else ``_coarse`` (:900-905); ``visibility2`` (nf-1, h, w) float32 when the outputs carry it
+    (predict_visibility with secondary views, :919-924)."""
     h, w = int(resolution[0]), int(resolution[1])
     if 'fine_mlp' in configs['model']:
         suffix = '_fine'
@@ -136,7 +137,11 @@ def retrieve_inference_outputs(configs: dict, resolution, network_outputs: Dict[
     for name in names:
         out[name] = ops.to_display(network_outputs[f'rgb{suffix}'].reshape(h * w, 3),
                                    network_outputs[f'{name}{suffix}'].reshape(h * w), colour=False)[1].reshape(h, w)
-    return {k: v.cpu().numpy() for k, v in out.items()}
+    result = {k: v.cpu().numpy() for k, v in out.items()}
+    if f'visibility2{suffix}' in network_outputs:
+        vis2 = network_outputs[f'visibility2{suffix}'].reshape(h, w, -1).permute(2, 0, 1).contiguous()
+        result['visibility2'] = vis2.float().cpu().numpy()         # post_process_visibility: a float32 cast (:1116-1119)
+    return result
 
 
 @torch.no_grad()
