@@ -35,7 +35,11 @@ def _dev(t: Optional[Tensor], name: str, shape=None) -> Optional[Tensor]:
         raise RuntimeError(f'{name}: expected float32, got {t.dtype}')
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise RuntimeError(f'{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}')
-    return t.detach().contiguous()
+    # (the common case -- a contiguous tensor outside autograd -- passes through without creating two tensor objects;
+    # this function runs ~100 times per training forward)
+    if t.requires_grad or not t.is_contiguous():
+        return t.detach().contiguous()
+    return t
 
 
 def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
@@ -235,6 +239,14 @@ class PackedMlp:
 
 
 # ---------------------------------------------------------------------------------------------- one-call render ops
+def _row_major_strides(shape):
+    strides, step = [], 1
+    for d in reversed(shape):
+        strides.append(step)
+        step *= d
+    return tuple(reversed(strides))
+
+
 class RenderCall:
     """One ``snerf_render_forward`` (and, for training, its ``snerf_render_backward``): the whole of SimpleNeRF.render_rays
     (src/models/SimpleNeRF01.py:108-270) enqueued by ONE call into the library.  Output tensors are carved out of three
@@ -329,7 +341,7 @@ class RenderCall:
             size = 1
             for d in shape:
                 size *= d
-            t = buf[pos[pool]:pos[pool] + size].view(shape)
+            t = buf.as_strided(shape, _row_major_strides(shape), pos[pool])     # one view op (slice + view would be two)
             pos[pool] += size
             return t
 
