@@ -44,7 +44,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[U]) {
 template <int U>
 __device__ __forceinline__ void load_relu_words(unsigned (&words)[U / 2], const unsigned* __restrict__ masks, int t0, int lane) {
 #pragma unroll
-    for (int p = 0; p < U / 2; ++p) words[p] = masks[((t0 >> 1) + p) * 64 + lane];
+    for (int p = 0; p < U / 2; ++p) words[p] = __builtin_nontemporal_load(masks + ((t0 >> 1) + p) * 64 + lane);   // read once
 }
 template <int U>
 __device__ __forceinline__ void relu_backward(const f32x16 (&acc)[U], const unsigned (&words)[U / 2], float (&dy)[U * 16]) {
@@ -741,11 +741,11 @@ __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float
             for (; c + 8 <= c1; c += 8) {
                 float v[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = p[(long long)(c + k) * stride];
+                for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(p + (long long)(c + k) * stride);   // partial sums: read once
 #pragma unroll
                 for (int k = 0; k < 8; ++k) s += v[k];
             }
-            for (; c < c1; ++c) s += p[(long long)c * stride];
+            for (; c < c1; ++c) s += __builtin_nontemporal_load(p + (long long)c * stride);
         }
         quarter[wave][lane] = s;
         __syncthreads();

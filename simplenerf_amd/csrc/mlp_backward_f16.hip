@@ -29,7 +29,7 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[U]) {
 __device__ __forceinline__ void store_tile_rows_scaled(const f32x16& acc, float* __restrict__ rows, int lane, float k) {
     const int j = lane & 31, half = lane >> 5;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rows[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + j] = acc[r] * k;
+    for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(acc[r] * k, rows + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + j);
 }
 
 // Rescale this sample's gradient vector (U tiles of this lane + the partner lane half) to a maximum in [8, 16).
@@ -90,7 +90,7 @@ __device__ __forceinline__ void store_dy(const f32x16 (&acc)[U], float* __restri
                     const bf16x2 b = __builtin_convertvector(f, bf16x2);
                     v[e] = b[0]; v[e + 1] = b[1];
                 }
-                *reinterpret_cast<bf16x8*>(rows + (2 * u + s) * 512 + slot * 8) = v;
+                __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(rows + (2 * u + s) * 512 + slot * 8));   // read once, by the weight-gradient kernel
             }
     }
 }

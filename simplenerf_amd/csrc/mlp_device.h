@@ -72,7 +72,7 @@ __device__ __forceinline__ void store_acc_tile(const float (&h)[N], float* __res
 #pragma unroll
     for (int n = 0; n < N; ++n) {
         const int f = 32 * (n >> 4) + (n & 3) + 8 * ((n & 15) >> 2) + 4 * half;
-        tile[f * 32 + j] = h[n];
+        __builtin_nontemporal_store(h[n], tile + f * 32 + j);   // saved tiles are written once and read back GBs later
     }
 }
 template <int N>
@@ -101,7 +101,7 @@ template <int N>
 __device__ __forceinline__ void store_relu_masks(const float (&h)[N], unsigned* __restrict__ masks, int t0, int lane) {
 #pragma unroll
     for (int u = 0; u < N / 16; u += 2)
-        masks[((t0 + u) >> 1) * 64 + lane] = relu_bits(h + 16 * u) | (relu_bits(h + 16 * (u + 1)) << 16);
+        __builtin_nontemporal_store(relu_bits(h + 16 * u) | (relu_bits(h + 16 * (u + 1)) << 16), masks + ((t0 + u) >> 1) * 64 + lane);
 }
 // positional-encoding registers -> rows in the reference's encoding order (pads skipped)
 template <int PAIRS, int NREG>
@@ -111,7 +111,7 @@ __device__ __forceinline__ void store_pe_tile(const float (&pe)[NREG], float* __
     for (int n = 0; n < NREG; ++n) {
         const int e0 = snerf::pe_feature(n, 0, PAIRS, 16), e1 = snerf::pe_feature(n, 1, PAIRS, 16);
         const int e = half ? e1 : e0;
-        if (e >= 0) tile[e * 32 + j] = pe[n];
+        if (e >= 0) __builtin_nontemporal_store(pe[n], tile + e * 32 + j);
     }
 }
 

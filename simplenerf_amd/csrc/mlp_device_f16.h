@@ -338,7 +338,7 @@ __device__ __forceinline__ void store_relu_masks(const f32x16* acc, unsigned* __
         unsigned word = 0;
 #pragma unroll
         for (int r = 0; r < 32; ++r) word |= (acc[u + (r >> 4)][r & 15] > 0.0f ? 1u : 0u) << r;
-        masks[((t0 + u) >> 1) * 64 + lane] = word;
+        __builtin_nontemporal_store(word, masks + ((t0 + u) >> 1) * 64 + lane);
     }
 }
 // One tile at a time (the single-product forward calls this right behind each tile's MFMAs, so the compares run in the
@@ -352,14 +352,14 @@ __device__ __forceinline__ void relu_mask_tile(const f32x16& acc, int u, unsigne
     if ((u & 1) == 0) {
         bits = m;
     } else {
-        masks[((t0 + u) >> 1) * 64 + lane] = bits | (m << 16);
+        __builtin_nontemporal_store(bits | (m << 16), masks + ((t0 + u) >> 1) * 64 + lane);
     }
 }
 template <int U>
 __device__ __forceinline__ void apply_relu_masks(f32x16* acc, const unsigned* __restrict__ masks, int t0, int lane) {
 #pragma unroll
     for (int u = 0; u < U; u += 2) {
-        const unsigned word = masks[((t0 + u) >> 1) * 64 + lane];
+        const unsigned word = __builtin_nontemporal_load(masks + ((t0 + u) >> 1) * 64 + lane);
 #pragma unroll
         for (int r = 0; r < 32; ++r) acc[u + (r >> 4)][r & 15] = keep_if_bit(acc[u + (r >> 4)][r & 15], word, r);
     }
@@ -370,7 +370,7 @@ __device__ __forceinline__ void apply_relu_masks(f32x16* acc, const unsigned* __
 template <int U>
 __device__ __forceinline__ void load_relu_words(unsigned (&words)[U / 2], const unsigned* __restrict__ masks, int t0, int lane) {
 #pragma unroll
-    for (int p = 0; p < U / 2; ++p) words[p] = masks[((t0 >> 1) + p) * 64 + lane];
+    for (int p = 0; p < U / 2; ++p) words[p] = __builtin_nontemporal_load(masks + ((t0 >> 1) + p) * 64 + lane);   // read once
 }
 template <int U>
 __device__ __forceinline__ void mask_with_words(f32x16* acc, const unsigned (&words)[U / 2]) {
@@ -389,7 +389,9 @@ __device__ __forceinline__ void store_pieces(const f16x8 (&frag)[NB], _Float16* 
     static_assert(NB >= NKS, "fragment array too short");
     const int slot = 2 * (lane & 31) + (lane >> 5);
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) *reinterpret_cast<f16x8*>(rows + s * 512 + slot * 8) = frag[s];
+    // non-temporal: the saved tensors (GBs per pass) are read back only by the backward kernels, long after they have left
+    // every cache; the plain store policy cost the storing forward 7 % and the backward 9 % (r02, A/B builds)
+    for (int s = 0; s < NKS; ++s) __builtin_nontemporal_store(frag[s], reinterpret_cast<f16x8*>(rows + s * 512 + slot * 8));
 }
 
 // One finished accumulator tile -> rows 32u .. 32u+31 of a [feature][32-sample] fp32 tile (training: saved activations).
@@ -399,7 +401,7 @@ __device__ __forceinline__ void store_tile_rows(const f32x16& acc, float* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-        rows[f * 32 + j] = RELU ? fmaxf(acc[r], 0.0f) : acc[r];
+        __builtin_nontemporal_store(RELU ? fmaxf(acc[r], 0.0f) : acc[r], rows + f * 32 + j);
     }
 }
 
