@@ -278,6 +278,25 @@ __device__ __forceinline__ void tile_bias(f32x16& acc, const float* __restrict__
     }
 }
 
+// Single-product kernels: only the hi operand exists, so the ReLU can follow the conversion as ONE packed fp16 maximum per
+// register pair (relu(fp16(v)) == fp16(relu(v)) bit for bit: rounding is monotone and keeps the sign) instead of one fp32
+// maximum per value before it -- 64 fewer VALU instructions per layer and wave.
+template <bool RELU>
+__device__ __forceinline__ void convert_tile(const f32x16& acc, f16x8& h0, f16x8& h1) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        f16x2 a = __builtin_convertvector(f32x2{acc[j], acc[j + 1]}, f16x2);
+        f16x2 b = __builtin_convertvector(f32x2{acc[8 + j], acc[9 + j]}, f16x2);
+        if (RELU) {
+            const f16x2 zero = {(_Float16)0.0f, (_Float16)0.0f};
+            a = __builtin_elementwise_max(a, zero);
+            b = __builtin_elementwise_max(b, zero);
+        }
+        h0[j] = a[0]; h0[j + 1] = a[1];
+        h1[j] = b[0]; h1[j + 1] = b[1];
+    }
+}
+
 // (ReLU and) split one finished accumulator tile into the two k-steps it feeds in the next layer.
 template <bool RELU>
 __device__ __forceinline__ void split_tile(const f32x16& acc, f16x8& h0, f16x8& l0, f16x8& h1, f16x8& l1) {

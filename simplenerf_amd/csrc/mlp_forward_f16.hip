@@ -163,7 +163,10 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
     }
     if (STORE32) store_relu_masks<WT>(acc, masks, 0, lane);
 #pragma unroll
-    for (int u = 0; u < WT; ++u) split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
+    for (int u = 0; u < WT; ++u) {
+        if constexpr (P == 1) convert_tile<true>(acc[u], xh[2 * u], xh[2 * u + 1]);
+        else split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
+    }
     if (STORE16) { store_pieces<HK>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK); }
 
     // ---- trunk layers 1 .. depth-1 --------------------------------------------------------------------------------
@@ -183,7 +186,10 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         }
         if (STORE32) store_relu_masks<WT>(acc, masks, l * WT, lane);
 #pragma unroll
-        for (int u = 0; u < WT; ++u) split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
+        for (int u = 0; u < WT; ++u) {
+            if constexpr (P == 1) convert_tile<true>(acc[u], xh[2 * u], xh[2 * u + 1]);
+            else split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
+        }
         if (STORE16) { store_pieces<HK>(xh, tile16 + (a.act_h1 + l * a.width) * 32, lane); st.note_vmem(HK); }
     };
     if constexpr (DEPTH > 0) {
@@ -211,7 +217,10 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
             if (STORE32) { store_tile_rows<false>(acc[u], tile + (a.act_feature + 32 * u) * 32, lane); st.note_vmem(16); }
         }
 #pragma unroll
-        for (int u = 0; u < WT; ++u) split_tile<false>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
+        for (int u = 0; u < WT; ++u) {
+            if constexpr (P == 1) convert_tile<false>(acc[u], xh[2 * u], xh[2 * u + 1]);
+            else split_tile<false>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
+        }
         if (STORE16) { store_pieces<HK>(xh, tile16 + a.act_feature * 32, lane); st.note_vmem(HK); }
         // views layer over [feature | rest of the point encoding (points-aug) | view encoding], then the colour head
         const float* bv = consts + (a.views_bias - a.bias_offset);
