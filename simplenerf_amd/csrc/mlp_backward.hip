@@ -702,6 +702,10 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     }
 }
 
+__global__ void __launch_bounds__(256) clear_words_kernel(unsigned* __restrict__ words, int count) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) words[i] = 0u;
+}
+
 // B3: fixed-order sum over chunks, scattered into the reference-layout gradient tensors.  A block owns 64 consecutive
 // output elements; its four waves each fold a quarter of the chunks (coalesced 256-byte rows, eight independent loads
 // in flight per lane -- the small head/encoding jobs have few outputs but up to 512 chunks, so a single serial loop
@@ -971,8 +975,16 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     if (f16) { a.act_rows = plan.act16_rows(); a.grad_rows = plan.grad16_rows(); }
     // partial[0, 64): zero page for padded staging rows; [192, 448): 1 KiB zero page; [448, 448 + 64 x 128): the region
     // maxima |dY| of the f16 modes, in 64 copies (kRegionSlots) of kRegionWords words, indexed by workgroup
-    hipError_t he = hipMemsetAsync(partial, 0, (kRegionTableFloat0 + kRegionSlots * kRegionWords) * sizeof(float), s);
-    if (he != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: memset: %s", hipGetErrorString(he));
+    // (a kernel, not hipMemsetAsync: captured in a HIP graph, the memset node did not clear the table on later replays --
+    // from the third replay on the region maxima only ever grew, and once the true gradients had shrunk by a few powers of
+    // two the fp16 weight-gradient operands lost that many bits: 30 % errors in a graphed fp16 training run, exact again with
+    // this kernel; found by tools/probes/graph_vs_eager.py, r02.  The library uses no memset nodes any more.)
+    hipLaunchKernelGGL(clear_words_kernel, dim3(8), dim3(256), 0, s, reinterpret_cast<unsigned*>(partial),
+                       kRegionTableFloat0 + kRegionSlots * kRegionWords);
+    {
+        const int zrc = snerf::check_launch("mlp_backward(clear)");
+        if (zrc != SNERF_OK) return zrc;
+    }
     int rc;
     const int key = precision != SNERF_PRECISION_FP32 ? -1 : plan.wt * 10 + plan.vt;
     a.dy_max = nullptr;
@@ -1057,9 +1069,11 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
         // predict_visibility: the visibility row of views_output_linear receives no gradient (no shipped loss reads the
         // visibility outputs; they are returned without a gradient path) -- an overwritten tensor holds zeros there
         const int d = plan.depth;
-        hipError_t z = hipMemsetAsync(param_grads[2 * d + 6] + 3LL * plan.views_width, 0, sizeof(float) * plan.views_width, s);
-        if (z == hipSuccess) z = hipMemsetAsync(param_grads[2 * d + 7] + 3, 0, sizeof(float), s);
-        if (z != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_backward: memset: %s", hipGetErrorString(z));
+        hipLaunchKernelGGL(clear_words_kernel, dim3(1), dim3(256), 0, s,
+                           reinterpret_cast<unsigned*>(param_grads[2 * d + 6] + 3LL * plan.views_width), plan.views_width);
+        hipLaunchKernelGGL(clear_words_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned*>(param_grads[2 * d + 7] + 3), 1);
+        const int zrc = snerf::check_launch("mlp_backward(clear visibility row)");
+        if (zrc != SNERF_OK) return zrc;
     }
     GradPointers ptrs;
     for (int i = 0; i < num_params; ++i) ptrs.p[i] = param_grads[i];

@@ -7,6 +7,13 @@
 
 namespace {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) zero_fill_kernel(f32x4_t* __restrict__ dst, long long count) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const f32x4_t zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = zero;
+}
+
 // Launch batching: the stream of one MLP has ~40 segments and ~36 f16x3 stages of a few KB each; one launch per piece
 // made a re-pack (needed after every optimiser step) ~95 tiny GPU operations.  Pieces are grouped into kernarg-sized
 // tables instead (blockIdx.y = piece), ~10 launches per re-pack.
@@ -142,8 +149,11 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
                   num_params);
     for (int i = 0; i < num_params; ++i) SNERF_REQUIRE(params[i], "mlp_pack: parameter %d is NULL", i);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(packed, 0, sizeof(float) * (size_t)plan.total_floats, s);
-    if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_pack: memset: %s", hipGetErrorString(e));
+    // zero fill by a kernel rather than hipMemsetAsync: the re-pack is part of the captured training graph, and memset nodes
+    // proved unreliable on replay (see snerf_mlp_backward); total_floats is a multiple of 64
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(512), dim3(256), 0, s, reinterpret_cast<f32x4_t*>(packed), plan.total_floats / 4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_pack: zero fill: %s", hipGetErrorString(e));
     {
         SegmentTable table;
         int n = 0;

@@ -50,7 +50,7 @@ def main():
     curve = []
     graphed = None
     if os.environ.get('SNERF_GRAPH') == '1':
-        graphed = harness.GraphedTrainStep(model, losses, batcher.get_next_batch(0))
+        graphed = harness.GraphedTrainStep(model, losses, batcher.get_next_batch(0), sub_batch_size=cfg['sub_batch_size'])
         batcher = BatchAssembler(cfg, scene, DEV)       # restart the index stream after the sample batch
     worst = 0.0
     t0 = time.perf_counter()
