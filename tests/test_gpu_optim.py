@@ -138,7 +138,8 @@ def test_graphed_training_pass_equals_eager(precision):
         assert torch.equal(a.grad, b.grad)
 
 
-def test_graphed_sub_batched_iteration_equals_the_eager_trainer_iteration():
+@pytest.mark.parametrize('precision', ['fp32', 'f16'])
+def test_graphed_sub_batched_iteration_equals_the_eager_trainer_iteration(precision):
     """GraphedTrainStep(sub_batch_size=...) replays the reference's iteration exactly (two sub-batches, in-kernel gradient
     accumulation, per-sub-batch draws): parameters after three optimiser steps are bit-identical to
     harness.train_one_iter's, device draws included."""
@@ -146,7 +147,7 @@ def test_graphed_sub_batched_iteration_equals_the_eager_trainer_iteration():
     from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
     from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
     from simplenerf_amd.models.ModelFactory import get_model
-    cfg = synth.training_configs('fp32', num_rays=192, num_sparse=64)
+    cfg = synth.training_configs(precision, num_rays=192, num_sparse=64)
     cfg['sub_batch_size'] = 128
     scene = synth.training_scene(0, 3, 48, 64, sparse_fraction=0.05)
     models = []
