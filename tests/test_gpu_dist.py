@@ -1,0 +1,88 @@
+"""Two ranks sharing the one GPU of the test box (gloo between them; RCCL refuses two ranks on one device): the
+row-sharded training iteration of SURVEY 8e with the real kernels -- batch rows split over ranks by BatchAssembler, draws
+keyed by global rows, ONE all-reduce of the flattened gradients -- reproduces the single-process run."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _setup(precision):
+    from simplenerf_amd import synth
+    cfg = synth.training_configs(precision, num_rays=256, num_sparse=128)
+    cfg['sub_batch_size'] = 384            # overwritten per world size below
+    cfg['losses'] = synth.loss_configs(iter_weighted=False)
+    cfg['seed'] = 3
+    scene = synth.training_scene(0, 3, 48, 64, sparse_fraction=0.5)
+    return cfg, scene
+
+
+def _train(rank, world, precision, iterations, group=None):
+    from simplenerf_amd import harness, optim, synth
+    from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
+    from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
+    from simplenerf_amd.models.ModelFactory import get_model
+    cfg, scene = _setup(precision)
+    dev = torch.device('cuda', 0)
+    model = get_model(cfg, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 9, 200.0, 8.0).items()})
+    model = model.to(dev).train()
+    batcher = BatchAssembler(cfg, scene, dev, rank=rank, world_size=world)
+    losses = LossComputer(cfg)
+    # Adam turns a rounding-level difference in a near-zero gradient into a full +-lr step, so the runs are compared on
+    # the (all-reduced) gradients of each iteration, with the parameters held still by lr = 0
+    opt = optim.Adam(list(model.parameters()), lr=0.0)
+    # the reference's two sub-batches (all pixel rows, then all sparse rows) keep their composition on every rank
+    sub = 256 // world
+    grads = []
+    for it in range(iterations):
+        batch = batcher.get_next_batch(it)
+        assert batch['rays_o'].shape[0] == (256 + 128) // world
+        harness.train_one_iter(model, losses, opt, batch, sub, world, group)
+        grads.append({k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()})
+    return grads
+
+
+def _worker(rank, world, port, precision, iterations, path):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        state = _train(rank, world, precision, iterations)
+        if rank == 0:
+            torch.save(state, path)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('precision', ['fp32'])
+def test_two_rank_training_reproduces_the_single_process_run(tmp_path, precision):
+    """Three iterations: rank r holds half of the pixel rows and half of the sparse rows of every batch (what
+    BatchAssembler(rank, world) hands out), draws its jitter / noise by global row, and the gradients are averaged by one
+    all-reduce.  Every shipped loss normalises by a count that does not depend on the split (pixel rows, sparse rows), so
+    the averaged gradient is the single-process gradient up to summation order: 2e-5 of each tensor's largest entry."""
+    path = str(tmp_path / 'rank0.pt')
+    mp.spawn(_worker, args=(2, _free_port(), precision, 3, path), nprocs=2, join=True)
+    sharded = torch.load(path)
+    single = _train(0, 1, precision, 3)
+    assert len(sharded) == len(single) == 3
+    for it, (a, b) in enumerate(zip(sharded, single)):
+        assert a.keys() == b.keys()
+        for k in b:
+            scale = float(b[k].abs().max())
+            assert scale > 0 and torch.isfinite(a[k]).all(), (it, k)
+            assert float((a[k] - b[k]).abs().max()) <= 2e-5 * scale, (it, k, float((a[k] - b[k]).abs().max()) / scale)
+    # the three iterations saw three different batches
+    first = next(iter(single[0]))
+    assert not torch.equal(single[0][first], single[1][first])
