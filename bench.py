@@ -199,7 +199,7 @@ TRAIN_WORKLOAD = ('config 5: 2048 pixel + 2048 sparse-depth rows per GPU in two 
 TRAIN_DTYPE = {'fp32': 'f32', 'f16x3': 'f16x3', 'f16': 'f16 (bf16 layer gradients)'}
 
 
-def time_training(precision, device, steps, warmup, single_pass=False):
+def time_training(precision, device, steps, warmup, single_pass=False, board_seconds=0.0):
     """Config 5 on one GPU: (ms per iteration, ms of MLP forward launches, ms of MLP backward calls) from ``steps`` timed
     iterations after ``warmup``."""
     _, ops, _, _ = _pkg()
@@ -216,6 +216,16 @@ def time_training(precision, device, steps, warmup, single_pass=False):
     fwd, _ = ops.profile_collect(ops.PROFILE_MLP_FORWARD)
     bwd, _ = ops.profile_collect(ops.PROFILE_MLP_BACKWARD)
     ops.profile_enable(0)
+    time_training.board = None
+    if board_seconds > 0:      # the same iteration for about a second with the board's power / clock sensors sampled
+        sampler = BoardSampler(device.index or 0)
+        with sampler:
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < board_seconds:
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+        time_training.board = sampler.summary()
     return elapsed / steps * 1e3, sum(fwd) / steps, sum(bwd) / steps, rows
 
 
@@ -230,9 +240,10 @@ def training_record(device, steps=10, warmup=3):
     out = {'workload': TRAIN_WORKLOAD, 'rows_per_gpu': 4096, 'steps': steps, 'warmup': warmup, 'modes': {}}
     # (f16x3 issues three fp16 MFMA passes per algorithmic product: its ceiling is a third of the fp16 peak)
     for precision, peak in (('fp32', PEAK_FP32_MFMA_TFLOPS), ('f16x3', PEAK_FP16_MFMA_TFLOPS / 3), ('f16', PEAK_FP16_MFMA_TFLOPS)):
-        ms, fwd_ms, bwd_ms, rows = time_training(precision, device, steps, warmup)
+        ms, fwd_ms, bwd_ms, rows = time_training(precision, device, steps, warmup, board_seconds=1.0)
         tflops = rows * TRAIN_FLOP_PER_RAY / (ms * 1e-3) / 1e12
         out['modes'][precision] = {
+            'board': time_training.board,
             'dtype': TRAIN_DTYPE[precision], 'ms_per_step': ms, 'value': rows / (ms * 1e-3), 'unit': 'rays/s',
             'algorithmic_tflops': tflops, 'peak_tflops': peak, 'frac_of_peak': tflops / peak,
             'mlp_forward_ms_per_step': fwd_ms, 'mlp_backward_ms_per_step': bwd_ms,
@@ -374,6 +385,70 @@ def main():
             dist.destroy_process_group()
 
 
+class BoardSampler:
+    """Board power and shader clock of THIS process's GPU while a measurement runs (sysfs hwmon, one reading every 20 ms;
+    no privileges needed).  The fp16 modes run the board at its power cap with the clock throttled below the 2.4 GHz the
+    nominal peaks assume, so the line carries what the board did next to each fraction.  All fields None when the sensors
+    are not readable."""
+
+    def __init__(self, device_index=0):
+        import glob
+        import threading
+        self._threading = threading
+        self.paths = None
+        try:
+            props = torch.cuda.get_device_properties(device_index)
+            want = '%04x:%02x:%02x' % (getattr(props, 'pci_domain_id', 0), props.pci_bus_id, getattr(props, 'pci_device_id', 0))
+        except Exception:
+            return
+        for hw in glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'):
+            if want not in os.path.realpath(os.path.join(hw, '..', '..')):
+                continue
+            paths = {k: os.path.join(hw, f) for k, f in (('power', 'power1_average'), ('power', 'power1_input'),
+                                                          ('cap', 'power1_cap'), ('sclk', 'freq1_input'))
+                     if os.path.exists(os.path.join(hw, f))}
+            if 'power' in paths or 'sclk' in paths:
+                self.paths = paths
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def __enter__(self):
+        self.rows, self._on = [], True
+        if self.paths:
+            def loop():
+                while self._on:
+                    self.rows.append({k: self._read(p) for k, p in self.paths.items() if k != 'cap'})
+                    time.sleep(0.02)
+            self._thread = self._threading.Thread(target=loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._on = False
+        if self.paths:
+            self._thread.join()
+
+    def summary(self):
+        """mean over the last three quarters of the readings (the first quarter is the ramp)"""
+        if not self.paths or len(self.rows) < 4:
+            return {'power_w': None, 'power_cap_w': None, 'sclk_mhz': None, 'readings': len(getattr(self, 'rows', []))}
+        rows = self.rows[len(self.rows) // 4:]
+
+        def mean(key):
+            vals = [r[key] for r in rows if r.get(key) is not None]
+            return sum(vals) / len(vals) if vals else None
+        power, sclk = mean('power'), mean('sclk')
+        cap = self._read(self.paths['cap']) if 'cap' in self.paths else None
+        return {'power_w': None if power is None else power / 1e6, 'power_cap_w': None if cap is None else cap / 1e6,
+                'sclk_mhz': None if sclk is None else sclk / 1e6, 'readings': len(rows)}
+
+
 def render_bench(args, rank, world, device, dist):
     harness, ops, synth, _ = _pkg()
     configs = synth.make_configs('headline')
@@ -470,13 +545,31 @@ def render_bench(args, rank, world, device, dist):
             alt_ms, alt_samples = ops.profile_collect(ops.PROFILE_MLP_FORWARD)
             ops.profile_enable(0)
             alt_tf = sum(alt_samples) * FLOP_PER_SAMPLE / (sum(alt_ms) * 1e-3) / 1e12
+            measure.kernel_share = sum(alt_ms) / (alt_elapsed * 1e3)
             return alt_elapsed, alt_tf
+
+        def board_state(precision, achieved_tflops, nominal_peak, seconds=1.2):
+            """the same step back to back for ~1.2 s with the board's sensors sampled: power, cap, shader clock, and the
+            fraction of the peak AT THAT CLOCK (the nominal peaks are quoted at 2.4 GHz)"""
+            alt_model = model if precision == 'fp32' else synthetic_model(configs, 7, device, precision)
+            sampler = BoardSampler(device.index or 0)
+            with torch.no_grad(), sampler:
+                t0 = time.perf_counter()
+                while time.perf_counter() - t0 < seconds:
+                    for _ in range(25):
+                        alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
+                    torch.cuda.synchronize()
+            state = sampler.summary()
+            if state['sclk_mhz']:
+                state['frac_of_peak_at_this_clock'] = achieved_tflops / (nominal_peak * state['sclk_mhz'] / 2400.0)
+            return state
 
         sustained_steps = 300       # ~1 s of device time: long enough for the clocks to settle under the load
         s_elapsed, s_tf = measure('fp32', sustained_steps)
         result['sustained'] = {'steps': sustained_steps, 'value': RAYS_PER_GPU * sustained_steps / s_elapsed, 'unit': 'rays/s',
                                'ms_per_step': s_elapsed / sustained_steps * 1e3, 'achieved': s_tf,
-                               'frac': s_tf / PEAK_FP32_MFMA_TFLOPS, 'timed_region_s': s_elapsed}
+                               'frac': s_tf / PEAK_FP32_MFMA_TFLOPS, 'timed_region_s': s_elapsed,
+                               'board': board_state('fp32', s_tf, PEAK_FP32_MFMA_TFLOPS)}
         alt_elapsed, alt_tf = measure('f16x3', args.steps)
         result['also_measured'] = {
             'precision': 'f16x3 (fp16 hi/lo split, 3 MFMA passes per product, fp32 accumulate; same parity tests)',
@@ -485,14 +578,18 @@ def render_bench(args, rank, world, device, dist):
                          'frac': alt_tf / (PEAK_FP16_MFMA_TFLOPS / 3), 'frac_of_fp16_peak': alt_tf / PEAK_FP16_MFMA_TFLOPS,
                          'note': 'peak = fp16 dense MFMA peak / 3: the kernel issues three fp16 MFMA passes per algorithmic '
                                  'product, achieved counts algorithmic FLOPs',
-                         'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false,false,3>'}}
+                         'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false,false,3>',
+                         'kernel_share_of_step': measure.kernel_share},
+            'board': board_state('f16x3', alt_tf, PEAK_FP16_MFMA_TFLOPS / 3)}
         alt_elapsed, alt_tf = measure('f16', args.steps)
         result['also_measured_16bit'] = {
             'precision': 'f16 (one fp16 MFMA pass per product, fp32 accumulate; OUTSIDE the fp32 parity bar -- colour ~1e-4, '
                          'depth ~6e-4 from the fp32 path, tests/test_gpu_f16.py; BASELINE config 5 names this mode for training)',
             'value': RAYS_PER_GPU * args.steps / alt_elapsed, 'unit': 'rays/s', 'ms_per_step': alt_elapsed / args.steps * 1e3,
             'roofline': {'bound': 'mfma', 'achieved': alt_tf, 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': alt_tf / PEAK_FP16_MFMA_TFLOPS, 'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false,false,1>'}}
+                         'frac': alt_tf / PEAK_FP16_MFMA_TFLOPS, 'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false,false,1>',
+                         'kernel_share_of_step': measure.kernel_share},
+            'board': board_state('f16', alt_tf, PEAK_FP16_MFMA_TFLOPS)}
         result['also_measured_train'] = training_record(device)
     if world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(configs, camera, first)
