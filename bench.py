@@ -501,12 +501,12 @@ def render_bench(args, rank, world, device, dist):
         note = 'fp32 MFMA: one pass per algorithmic FLOP'
     elif args.precision == 'f16x3':
         peak, dtype, kernel_name = PEAK_FP16_MFMA_TFLOPS, 'f16x3 (fp16 hi/lo split, fp32 accumulate)', \
-            'mlp_forward_f16x3_kernel<8,4,true,false,false,3>'
+            'mlp_forward_m16_kernel<3,8>'
         note = ('achieved counts ALGORITHMIC FLOPs; the kernel issues 3 fp16 MFMA passes per product, so its ceiling is '
                 'peak/3 = 833 TFLOP/s and MFMA-pipe utilisation = 3 x frac')
     else:
         peak, dtype, kernel_name = PEAK_FP16_MFMA_TFLOPS, 'f16 (fp16 MFMA, fp32 accumulate)', \
-            'mlp_forward_f16x3_kernel<8,4,true,false,false,1>'
+            'mlp_forward_m16_kernel<1,8>'
         note = 'one fp16 MFMA pass per product; NOT within the fp32 parity bar (sigma ~1e-3 relative)'
 
     result = {
@@ -578,7 +578,7 @@ def render_bench(args, rank, world, device, dist):
                          'frac': alt_tf / (PEAK_FP16_MFMA_TFLOPS / 3), 'frac_of_fp16_peak': alt_tf / PEAK_FP16_MFMA_TFLOPS,
                          'note': 'peak = fp16 dense MFMA peak / 3: the kernel issues three fp16 MFMA passes per algorithmic '
                                  'product, achieved counts algorithmic FLOPs',
-                         'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false,false,3>',
+                         'kernel': 'mlp_forward_m16_kernel<3,8>',
                          'kernel_share_of_step': measure.kernel_share},
             'board': board_state('f16x3', alt_tf, PEAK_FP16_MFMA_TFLOPS / 3)}
         alt_elapsed, alt_tf = measure('f16', args.steps)
@@ -587,7 +587,7 @@ def render_bench(args, rank, world, device, dist):
                          'depth ~6e-4 from the fp32 path, tests/test_gpu_f16.py; BASELINE config 5 names this mode for training)',
             'value': RAYS_PER_GPU * args.steps / alt_elapsed, 'unit': 'rays/s', 'ms_per_step': alt_elapsed / args.steps * 1e3,
             'roofline': {'bound': 'mfma', 'achieved': alt_tf, 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': alt_tf / PEAK_FP16_MFMA_TFLOPS, 'kernel': 'mlp_forward_f16x3_kernel<8,4,true,false,false,1>',
+                         'frac': alt_tf / PEAK_FP16_MFMA_TFLOPS, 'kernel': 'mlp_forward_m16_kernel<1,8>',
                          'kernel_share_of_step': measure.kernel_share},
             'board': board_state('f16', alt_tf, PEAK_FP16_MFMA_TFLOPS)}
         result['also_measured_train'] = training_record(device)

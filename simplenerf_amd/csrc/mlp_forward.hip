@@ -22,10 +22,13 @@
 //
 // Bound: MFMA (fp32, 256 FLOP/clk/CU).  Algorithmic work 2*MAC of the Linear layers: 1 186 816 FLOP per sample for
 // the 8x256 view-dependent MLP.  HBM traffic per sample: 4 B depth read + 16 B written; weights (2.4 MB) stay in L2.
+#include <cstdlib>
+
 #include "mlp_device.h"
 
 namespace snerf {
 int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, int products, hipStream_t stream);  // mlp_forward_f16.hip
+int mlp_forward_m16(const MlpPlan& plan, const MlpArgs& m, int products, hipStream_t stream);  // mlp_forward_m16.hip; -1 = layout not built there
 }
 
 namespace {
@@ -241,6 +244,14 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     a.act_feature = plan.act_feature(); a.act_hv = plan.act_hv(); a.act_mask = plan.act_mask();
     hipStream_t s = (hipStream_t)stream;
     snerf::ProfileScope timed(SNERF_PROFILE_MLP_FORWARD, s, a.total);
+    if (precision != SNERF_PRECISION_FP32 && !train) {
+        // rendering with the fp16 modes: the 16x16x32 MFMA layout where it is built (more work per joule)
+        static const bool m16 = !(getenv("SNERF_M16") && getenv("SNERF_M16")[0] == '0');   // A/B switch for probes
+        if (m16) {
+            const int st16 = snerf::mlp_forward_m16(plan, a, precision == SNERF_PRECISION_F16X3 ? 3 : 1, s);
+            if (st16 != -1) return st16;
+        }
+    }
     if (precision == SNERF_PRECISION_F16X3) return snerf::mlp_forward_f16x3(plan, a, train, 3, s);
     if (precision == SNERF_PRECISION_F16) {
         a.act_rows = plan.act16_rows();  // 16-bit pieces: same row numbers, rows of 64 bytes (mlp_plan.h)

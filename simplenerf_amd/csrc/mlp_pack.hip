@@ -26,6 +26,7 @@ constexpr int kStagesPerLaunch = 8;
 struct StageTable {
     const float* w[kStagesPerLaunch][3];
     snerf::MlpPlan::HalfStage stage[kStagesPerLaunch];
+    int m16[kStagesPerLaunch];   // 1: fragment layout of the 16x16x32 MFMA (mlp_forward_m16.hip)
 };
 constexpr int kCopiesPerLaunch = 16;
 struct CopyTable {
@@ -87,17 +88,30 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
     const long long stride = (long long)gridDim.x * blockDim.x;
     _Float16* dst16 = reinterpret_cast<_Float16*>(packed + st.dst);
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const int j = (int)(idx & 7);
+        int j = (int)(idx & 7);
         const int lane = (int)((idx >> 3) & 63);
         const long long uk = idx >> 9;
         int ks = (int)(uk % unit_ks);
         const int u = (int)(uk / unit_ks);
         const int ks_unit = ks;
+        int h = lane >> 5, row = 32 * u + (lane & 31);
+        const int slot = j;
+        if (table.m16[blockIdx.y]) {
+            // Fragment f = 2c + r: rows 16r + (lane & 15) of the out tile, k-block c (32 inputs).  Lane group g = lane >> 4
+            // holds in slot t the input at position p = (t < 4 ? 4g + t : 16 + 4g + t - 4) of the block -- the order in which
+            // the four 16x16 accumulator tiles (row half t / 4) of the previous layer's out tile become this operand.
+            // Position p is k-step 2c + p / 16, lane half (p % 16) / 8, element p % 8 of the 32x32x16 layout below.
+            const int c = ks >> 1, r = ks & 1, g = lane >> 4;
+            const int p = slot < 4 ? 4 * g + slot : 16 + 4 * g + (slot - 4);
+            row = 32 * u + 16 * r + (lane & 15);
+            ks = 2 * c + (p >> 4);
+            h = (p & 15) >> 3;
+            j = p & 7;
+        }
         int si = 0;
         while (si + 1 < st.nseg && ks >= st.seg[si].ksteps) { ks -= st.seg[si].ksteps; ++si; }
         const snerf::MlpPlan::HalfSegment& sg = st.seg[si];
         const float* w = si == 0 ? w0 : (si == 1 ? w1 : w2);
-        const int h = lane >> 5, row = 32 * u + (lane & 31);
         int col = -1;
         if (sg.transposed) {
             // dgrad operand: tile row = IN feature, k = OUT feature in accumulator order
@@ -105,11 +119,12 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
             float tv = 0.0f;
             if (out < sg.out_dim && row < sg.feat_hi) tv = w[(long long)out * sg.ld + sg.col_offset + row];
             const _Float16 thi = (_Float16)tv;
-            out_store(dst16, u, unit_ks, ks_unit, lane, j, thi, (_Float16)(tv - (float)thi));
+            out_store(dst16, u, unit_ks, ks_unit, lane, slot, thi, (_Float16)(tv - (float)thi));
             continue;
         }
         if (sg.kind == snerf::SEG_ACC) {
-            col = sg.col_offset + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+            col = table.m16[blockIdx.y] ? sg.col_offset + 16 * ks + 8 * h + j      // (position p in natural feature order)
+                                        : sg.col_offset + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
         } else if (sg.kind == snerf::SEG_POINTS_PE) {
             const int e = snerf::pe_feature(8 * ks + j, h, snerf::kPointsPairs, sg.degree);
             if (e >= sg.feat_lo && e < sg.feat_hi) col = sg.col_offset + (e - sg.feat_lo);
@@ -121,7 +136,7 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
         if (row < sg.out_dim && col >= 0 && col < sg.ld) v = w[(long long)row * sg.ld + col];
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
-        out_store(dst16, u, unit_ks, ks_unit, lane, j, hi, lo);
+        out_store(dst16, u, unit_ks, ks_unit, lane, slot, hi, lo);
     }
 }
 
@@ -184,10 +199,11 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
             n = 0;
             most = 0;
         };
-        for (const std::vector<snerf::MlpPlan::HalfStage>* list : {&plan.half_stages, &plan.half_dgrad_stages}) {
+        for (const std::vector<snerf::MlpPlan::HalfStage>* list : {&plan.half_stages, &plan.half_dgrad_stages, &plan.m16_stages}) {
             for (const snerf::MlpPlan::HalfStage& st : *list) {
                 for (int k = 0; k < 3; ++k) table.w[n][k] = params[st.seg[k < st.nseg ? k : 0].param];
                 table.stage[n] = st;
+                table.m16[n] = list == &plan.m16_stages ? 1 : 0;
                 most = std::max(most, (long long)st.tiles * (st.unit_floats / 512) * 512);
                 if (++n == kStagesPerLaunch) flush();
             }

@@ -45,6 +45,10 @@ struct MlpPlan {
     long long half_offset = 0;       // start of the f16x3 stream inside the packed buffer
     std::vector<HalfStage> half_dgrad_stages;  // W^T stream of the f16x3 backward chain (views, feature, trunk depth-1 .. 1)
     long long half_dgrad_offset = 0;
+    // The forward stages once more in the fragment layout of v_mfma_f32_16x16x32_f16 (mlp_forward_m16.hip, inference): same
+    // units and sizes, fragment f = 2c + r of a unit = rows 16r .. 16r+15 of the out tile x the 32 inputs of k-block c.
+    std::vector<HalfStage> m16_stages;
+    long long m16_offset = 0;
     long long total_floats = 0;
 
     // ---- saved-activation / gradient tiles of one 32-sample wave block (backward only) -----------------------
@@ -245,6 +249,13 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
             tstage(2 * l, plan.width + (skip_in ? plan.pts_in : 0), plan.width, hk, skip_in ? plan.pts_in : 0);
         }
         hoff += 24 * 512;
+        plan.m16_offset = hoff;
+        for (MlpPlan::HalfStage st : plan.half_stages) {
+            st.dst = hoff;
+            hoff += (long long)st.tiles * st.unit_floats;
+            plan.m16_stages.push_back(st);
+        }
+        hoff += 24 * 512;  // prefetch runway
         off = hoff;
     }
     plan.total_floats = (off + 63) / 64 * 64;

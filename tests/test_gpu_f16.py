@@ -66,7 +66,13 @@ def test_f16_mlp_against_oracle(layout, size):
     dev = [t.to(DEV) for t in inputs]
     sigma_eval, rgb_eval = mlp.forward(*dev, F16)
     sigma, rgb, saved = mlp.forward_train(*dev, F16)
-    assert torch.equal(sigma, sigma_eval) and torch.equal(rgb, rgb_eval)
+    # the storing forward and the inference forward are the same arithmetic; for the main 8x256 layout inference runs on the
+    # 16x16x32 MFMA (mlp_forward_m16.hip), whose fp32 accumulation order differs: equal within this mode's own tolerance there
+    if layout == 'main' and size == (8, 256, 128):
+        assert util.rel_linf(sigma, sigma_eval) < 5e-3 and util.linf(rgb, rgb_eval) < 2e-4
+        assert util.rel_linf(sigma_eval, ref['sigma']) < 5e-3 and util.linf(rgb_eval, ref['rgb']) < 2e-4
+    else:
+        assert torch.equal(sigma, sigma_eval) and torch.equal(rgb, rgb_eval)
     assert util.rel_linf(sigma, ref['sigma']) < 5e-3 and util.linf(rgb, ref['rgb']) < 2e-4
     shapes = [tuple(p.shape) for p in plist]
     grads = mlp.backward(saved, sigma, rgb, g_sigma.to(DEV), g_rgb.to(DEV), shapes, F16)

@@ -77,6 +77,10 @@ def check_outputs(out, ref, strict_fine, tag=''):
         assert tuple(out[k].shape) == tuple(v.shape), k
         assert out[k].dtype == torch.float32 and out[k].device.type == 'cuda', k
         assert torch.isfinite(out[k]).all(), k
+    moved_rays = numpy.zeros(next(iter(ref.values())).shape[0], dtype=bool)
+    if 'z_vals_fine' in ref:
+        zr = ref['z_vals_fine']
+        moved_rays = (numpy.abs(out['z_vals_fine'].cpu().numpy() - zr) > 1e-5 * float(numpy.abs(zr).max())).any(1)
     for k, v in ref.items():
         level = 'fine' if k.endswith('_fine') else 'coarse'
         acc_key = next(c for c in (f'{p}acc_{level}' for p in ('points_augmentation_', 'views_augmentation_', ''))
@@ -91,7 +95,12 @@ def check_outputs(out, ref, strict_fine, tag=''):
         elif per_sample:
             continue  # not index-aligned unless the fine depths are bit-identical: see test_fine_pass_on_reference_samples
         elif strict_fine and not world_depth:
-            assert not bad.any(), (tag, k, int(bad.sum()), util.linf(out[k], v))
+            # every ray within tolerance, except rays on which a resampled fine depth itself moved: sample_pdf's
+            # `denom < 1e-5` branch (src/models/SimpleNeRF01.py:357) flips on a last-bit difference of the coarse weights
+            # (DESIGN 4), and which rays sit on it depends on the kernel's rounding, not on its correctness -- with the
+            # reference's fine depths pinned these rays agree to 1e-7 (test_fine_pass_on_reference_samples)
+            assert not (bad & ~moved_rays).any(), (tag, k, int((bad & ~moved_rays).sum()), util.linf(out[k], v))
+            assert bad.mean() <= MAX_OUTLIER_RAYS, (tag, k, float(bad.mean()))
         else:
             assert bad.mean() <= MAX_OUTLIER_RAYS, (tag, k, float(bad.mean()))
     assert util.linf(out['z_vals_coarse'], ref['z_vals_coarse']) == 0.0
