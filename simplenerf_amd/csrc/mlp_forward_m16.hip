@@ -76,32 +76,37 @@ __device__ __forceinline__ void seg3_m16(Tile16& t, const float*& p, int unit_ks
     }
     p += 2 * NB * 256;
 }
-// P = 1: one product per fragment and sample half; fragments requested four ahead (as seg_mfma1).
+// P = 1: one product per fragment and sample half.  Fragments are handled in PAIRS (the two row halves of a k-block): the
+// pair after next is requested before the wait for this one -- one counted wait per four MFMAs.
+__device__ __forceinline__ void lds_pair_landed(f16x8& a, f16x8& b, int newer) {   // `newer` folds to a constant
+    if (newer >= 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b)::"memory");
+    else if (newer == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b)::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+}
 template <int NB, typename Stream>
 __device__ __forceinline__ void seg1_m16(Tile16& t, const float*& p, const f16x8 (&bh)[NB][2], Stream& st) {
-    constexpr int AHEAD = 4, NF = 2 * NB;
     const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
-    f16x8 a[AHEAD + 1];
+    f16x8 a[3][2];   // k-blocks c, c+1, c+2 in rotation
 #pragma unroll
-    for (int i = 0; i < AHEAD; ++i)
-        if (i < NF) a[i] = lds_read_f16x8(base, i * 1024);
+    for (int c = 0; c < 2 && c < NB; ++c)
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        if (f + AHEAD < NF) a[(f + AHEAD) % (AHEAD + 1)] = lds_read_f16x8(base, (f + AHEAD) * 1024);
-        constexpr int kLast = NF - 1;
-        const int newer = kLast - f < AHEAD ? kLast - f : AHEAD;
-        f16x8& cur = a[f % (AHEAD + 1)];
-        if (newer == 4) lds_wait_all_but<4>(cur);
-        else if (newer == 3) lds_wait_all_but<3>(cur);
-        else if (newer == 2) lds_wait_all_but<2>(cur);
-        else if (newer == 1) lds_wait_all_but<1>(cur);
-        else lds_wait_all_but<0>(cur);
-        const int c = f >> 1, r = f & 1;
-        t[r][0] = mfma16(cur, bh[c][0], t[r][0]);
-        t[r][1] = mfma16(cur, bh[c][1], t[r][1]);
-        if ((f & (Stream::kWaves - 1)) == 0) st.fetch_piece();
+        for (int r = 0; r < 2; ++r) a[c][r] = lds_read_f16x8(base, (2 * c + r) * 1024);
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        if (c + 2 < NB) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) a[(c + 2) % 3][r] = lds_read_f16x8(base, (2 * (c + 2) + r) * 1024);
+        }
+        const int newer = 2 * ((NB - 1 - c) < 2 ? (NB - 1 - c) : 2);   // fragment reads issued after this pair's
+        lds_pair_landed(a[c % 3][0], a[c % 3][1], newer);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            t[r][0] = mfma16(a[c % 3][r], bh[c][0], t[r][0]);
+            t[r][1] = mfma16(a[c % 3][r], bh[c][1], t[r][1]);
+        }
+        if (((2 * c) & (Stream::kWaves - 1)) == 0) st.fetch_piece();
     }
-    p += NF * 256;
+    p += 2 * NB * 256;
 }
 template <int P, int NB, typename Stream>
 __device__ __forceinline__ void seg_m16(Tile16& t, const float*& p, int unit_ks, const f16x8 (&bh)[NB][2], const f16x8 (&bl)[NB][2],
