@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: rays/sec of the ray-marching hot path (coarse+fine, 128+128 samples, 8x256 MLPs).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (--train: BASELINE config 5 instead, see train_bench)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py --frame re10k [--gpus N]      BASELINE config 4: ONE full frame strong-scaled over N ranks + gather
+    python bench.py --train [--precision f16]     BASELINE config 5: the training iteration (see train_bench)
 
 ``--gpus N`` with N > 1 needs no wrapper: when no launcher has set WORLD_SIZE, bench.py starts N fresh rank processes
 itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment) BEFORE anything in
@@ -15,13 +17,29 @@ compositing (eval mode, every reference output incl. alpha), and -- for N > 1 --
 colour/depth to rank 0.  Inputs (camera, weights) are resident in HBM before the timed region.  Weak scaling: each
 rank renders its own 1024-ray block; `value` is the whole-job rays/s = N*1024*K / max-over-ranks time.
 
+Timing protocol (every mode, every precision; ``timed_steps``):
+  settle    the step's device work back to back for >= 0.6 s, untimed -- a fresh GPU lease starts from idle clocks, an
+            empty allocator and cold code paths, which a handful of 3-ms warm-up steps does not absorb (round 2's driver
+            run lost 22 ms of a 88-ms timed region that way)
+  warm-up   W steps of the full step (incl. the collective), untimed, with the library's event hooks already on
+  timed     barrier + synchronize, EXACTLY K steps, barrier + synchronize; `value` = work / that whole wall time.  Every
+            step also gets one event on the launch stream and one host stamp after its enqueue, reported as
+            ``step_ms {p50, p90, max, first, argmax}`` (device time between consecutive end-of-step events),
+            ``enqueue_ms`` (host time per step) and ``idle_ms_per_step`` (wall per step minus the event-timed fused
+            PE+MLP launches: device idle + the ~1 % of small kernels), so that a one-off stall is visible and attributable
+            to the host or the device; ``step_trace_ms`` holds the raw per-step device times when K <= 64
+
 Printed JSON (rank 0, one line) also carries
   roofline      fp32-MFMA roofline of the dominant kernel (fused PE+MLP forward): algorithmic FLOPs of its launches
                 inside the timed region / their HIP-event durations, against 157.3 TFLOP/s (MI355X_MICROARCH.md)
   cpu_baseline  the oracle (torch CPU fp32 restatement of the reference path, reference chunking) timed on this
-                host on the same 1024-ray batch, best of 5 after one warm-up
-  collective    (N > 1) backend and number of ranks torch.distributed reports
+                host on the same 1024-ray batch, best of 9 after one warm-up
+  collective    (N > 1) backend, number of ranks and bytes per rank and step torch.distributed moves
   also_measured*        the same step in the other two arithmetic modes (N = 1)
+  also_measured_frame   BASELINE configs 2 and 4 as whole frames: raygen -> render -> display conversion -> D2H of the five
+                        display outputs (Tester.predict_frame), wall time per frame.  N = 1: fern 1008x756 (reference-native),
+                        fern 504x378 (as BASELINE names it), RE10K camera at 1008x756, fp32 and f16x3.  N > 1: the RE10K frame
+                        strong-scaled over the N ranks incl. the gather (= ``--frame re10k``)
   also_measured_train   BASELINE config 5 (the reference's training iteration, 4096 rows per GPU) in fp32 and in the
                         16-bit mode: ms per iteration, algorithmic TFLOP/s, fraction of the matching MFMA peak
   sustained     the headline step repeated for ~1 s of device time (the K timed steps alone are ~65 ms)
@@ -50,6 +68,29 @@ PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md, "Peak FP32 (matrix)
 PEAK_FP16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
 WORKLOAD = ('headline: 1024 rays/GPU x (128 coarse + 128 fine -> 256 merged) samples, 8x256 coarse+fine MLPs, '
             'LLFF fern NDC rays, eval')
+SETTLE_SECONDS = 0.6
+METRIC = 'rays/sec (coarse+fine, 128+128 samples)'
+
+# per-precision constants of the headline kernel: (ceiling in algorithmic TFLOP/s, dtype string, kernel, note)
+PRECISION_INFO = {
+    'fp32': (PEAK_FP32_MFMA_TFLOPS, 'f32', 'mlp_forward_kernel<8,4,true,false,false>', 'fp32 MFMA: one pass per algorithmic FLOP'),
+    'f16x3': (PEAK_FP16_MFMA_TFLOPS / 3, 'f16x3 (fp16 hi/lo split, fp32 accumulate)', 'mlp_forward_m16_kernel<3,8>',
+              'peak = fp16 dense MFMA peak / 3: the kernel issues three fp16 MFMA passes per algorithmic product, achieved '
+              'counts algorithmic FLOPs'),
+    'f16': (PEAK_FP16_MFMA_TFLOPS, 'f16 (fp16 MFMA, fp32 accumulate)', 'mlp_forward_m16_kernel<1,8>',
+            'one fp16 MFMA pass per product; NOT within the fp32 parity bar (sigma ~1e-3 relative)'),
+}
+
+# whole-frame workloads (BASELINE configs 2 and 4; SURVEY 8d resolves the resolutions): name -> (scene, camera kwargs, text)
+FRAMES = {
+    'fern': ('fern', {}, 'config 2, reference-native frame: LLFF fern 1008x756'),
+    'fern504': ('fern', {'downscale': 2}, 'config 2 as BASELINE names it: LLFF fern 504x378'),
+    're10k': ('re10k', {'resolution': (756, 1008)}, 'config 4 as BASELINE names it: RealEstate-10K camera at 1008x756'),
+    're10k_native': ('re10k', {}, "config 4, the scene's own frame size: RealEstate-10K 1024x576"),
+}
+FRAME_SAMPLES = 64 + 192              # config 2 / 4 evaluate 64 coarse + 192 merged fine samples per ray
+FRAME_DISPLAY_BYTES = 3 + 4 * 4       # uint8 colour + depth, depth_var, depth_ndc, depth_var_ndc per pixel leave the device
+FRAME_GATHER_BYTES = 4 * (3 + 4)      # fp32 colour + the four depth columns per ray cross xGMI to rank 0
 
 
 def launch_ranks(num_ranks: int) -> int:
@@ -159,6 +200,219 @@ def pmc_traffic(precision):
     return None
 
 
+# ---------------------------------------------------------------------------------------------- timing protocol
+class _Mark:
+    """A point on the launch stream: a HIP event on torch's current stream (the stream every library call of this
+    process is enqueued on), or a host clock reading for the GPU-less stand-in."""
+
+    def __init__(self, gpu: bool):
+        self.event = torch.cuda.Event(enable_timing=True) if gpu else None
+        self.host = 0.0
+
+    def record(self):
+        if self.event is not None:
+            self.event.record()
+        self.host = time.perf_counter()
+
+    def ms_until(self, later: '_Mark') -> float:
+        if self.event is not None:
+            return self.event.elapsed_time(later.event)
+        return (later.host - self.host) * 1e3
+
+
+def settle(run, seconds=None, gpu=True, chunk=8):
+    """Untimed: ``run`` (the step's device work, no collective: ranks run different counts) back to back for at least
+    ``seconds`` (default: SETTLE_SECONDS).  -> (runs, seconds spent)"""
+    seconds = SETTLE_SECONDS if seconds is None else seconds
+    t0 = time.perf_counter()
+    runs = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(chunk):
+            run()
+        runs += chunk
+        if gpu:
+            torch.cuda.synchronize()
+    return runs, time.perf_counter() - t0
+
+
+def timed_steps(step, steps, fence, gpu=True):
+    """EXACTLY ``steps`` steps bracketed by ``fence()`` (barrier + synchronize) on both sides.  -> (elapsed seconds over
+    the whole region, per-step device milliseconds between consecutive end-of-step marks, per-step host enqueue ms)."""
+    marks = [_Mark(gpu) for _ in range(steps + 1)]
+    # nothing may run for the first time inside the region (on a fresh lease a first call can fault its code in from a
+    # lazily loaded image): one throw-away pair of marks is recorded and read before the opening fence
+    dry = [_Mark(gpu), _Mark(gpu)]
+    dry[0].record()
+    dry[1].record()
+    fence()
+    dry[0].ms_until(dry[1])
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        step()
+        marks[i + 1].record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    device_ms = [marks[i].ms_until(marks[i + 1]) for i in range(steps)]
+    enqueue_ms = [(marks[i + 1].host - marks[i].host) * 1e3 for i in range(steps)]
+    return elapsed, device_ms, enqueue_ms
+
+
+def _quantiles(values):
+    s = sorted(values)
+    pick = lambda q: s[min(len(s) - 1, int(round(q * (len(s) - 1))))]
+    return {'p50': pick(0.5), 'p90': pick(0.9), 'max': s[-1], 'first': values[0], 'argmax': values.index(s[-1])}
+
+
+def step_summary(elapsed, device_ms, enqueue_ms, kernel_ms_total=None):
+    """The attribution fields of a timed region (see the module docstring)."""
+    steps = len(device_ms)
+    out = {'step_ms': _quantiles(device_ms), 'enqueue_ms': _quantiles(enqueue_ms),
+           'idle_ms_per_step': None if kernel_ms_total is None else (elapsed * 1e3 - kernel_ms_total) / steps}
+    if steps <= 64:
+        out['step_trace_ms'] = [round(v, 4) for v in device_ms]
+    return out
+
+
+def headline_line(world, steps, warmup, precision, elapsed, device_ms, enqueue_ms, launch_ms, launch_samples,
+                  dropped=0, settle_info=None, data='synthetic'):
+    """The bench line of the headline metric from one timed region's measurements (pure: tests build it from fake
+    numbers).  `value` = all rays of the K steps / the whole elapsed time -- no step is left out."""
+    peak, dtype, kernel_name, note = PRECISION_INFO[precision]
+    kernel_ms = float(sum(launch_ms))
+    line = {
+        'metric': METRIC,
+        'value': world * RAYS_PER_GPU * steps / elapsed,
+        'unit': 'rays/s',
+        'n_gpus': world, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': elapsed / steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': dtype, 'data': data,
+        'config': {'workload': WORKLOAD, 'rays_per_gpu': RAYS_PER_GPU, 'samples': '128+128',
+                   'parallelism': f'ray-shard x{world}' + (' + 1 gather/step' if world > 1 else '')},
+    }
+    if launch_ms:
+        achieved = sum(launch_samples) * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12
+        line['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                            'traffic': pmc_traffic(precision), 'kernel': kernel_name, 'note': note, 'launches': len(launch_ms),
+                            'avg_launch_ms': kernel_ms / len(launch_ms), 'kernel_share_of_step': kernel_ms / (elapsed * 1e3),
+                            'launches_not_timed': int(dropped),
+                            'step_frac': world * RAYS_PER_GPU * steps * (128 + 256) * FLOP_PER_SAMPLE / elapsed / 1e12 / peak / world}
+    line['timing'] = step_summary(elapsed, device_ms, enqueue_ms, kernel_ms if launch_ms else None)
+    if settle_info is not None:
+        line['timing']['settle'] = {'runs': settle_info[0], 'seconds': settle_info[1]}
+    return line
+
+
+# ---------------------------------------------------------------------------------------------- renderers
+class HipRenderer:
+    """The product path for one rank: the drop-in model on this rank's GPU."""
+    gpu = True
+
+    def __init__(self, precision, device, rank, world, kind='headline'):
+        harness, ops, synth, _ = _pkg()
+        self.harness, self.ops, self.synth = harness, ops, synth
+        self.precision, self.device, self.rank, self.world = precision, device, rank, world
+        self.configs = synth.with_overrides(synth.make_configs(kind), hip_precision=precision)
+        self.model = synthetic_model(synth.make_configs(kind), 7, device, precision)
+        self.camera = synth.camera('fern', 0)
+        h, w = self.camera['resolution']
+        # rank r renders pixels [base + r*1024, base + (r+1)*1024) from the middle of the frame
+        self.first = (h // 2) * w + rank * RAYS_PER_GPU
+
+    def local(self):
+        batch = self.harness.frame_batch(self.camera, True, self.device, self.first, RAYS_PER_GPU)
+        out = self.model(batch)
+        return {'rgb_fine': out['rgb_fine'], 'depth_fine': out['depth_fine']}
+
+    def step(self):
+        local = self.local()
+        if self.world > 1:
+            return self.harness.gather_rays(local, self.world * RAYS_PER_GPU, self.rank, self.world)
+        return local
+
+    def frame_camera(self, name):
+        scene, kwargs, _ = FRAMES[name]
+        return self.synth.camera(scene, 0, **kwargs)
+
+    def frame(self, name):
+        """Tester.predict_frame for this rank's block of the frame; the five display outputs as host arrays on rank 0."""
+        return self.harness.predict_frame(self.model, self.configs, self.frame_camera(name), self.device, self.rank, self.world)
+
+    def frame_block(self, name, rays=65536):
+        cam = self.frame_camera(name)
+        self.model(self.harness.frame_batch(cam, True, self.device, 0, min(rays, cam['resolution'][0] * cam['resolution'][1])))
+
+    def profile(self, capacity):
+        self.ops.profile_enable(capacity)
+
+    def profile_reset(self):
+        self.ops.profile_reset()
+
+    def profile_collect(self):
+        ms, samples = self.ops.profile_collect(self.ops.PROFILE_MLP_FORWARD)
+        return ms, samples, self.ops.profile_dropped()
+
+
+class StandInRenderer:
+    """SNERF_BENCH_STANDIN=1 (tests/test_dist_gloo.py only): the renderer replaced by a CPU stand-in whose outputs are a
+    function of the global ray index, so that the launcher, rendezvous, settle / warm-up / timed protocol, per-rank
+    blocks, gathers, max-over-ranks timing and the JSON lines of BOTH bench modes run without GPUs and every gathered
+    frame can be checked exactly.  The lines say ``"data": "stand-in"``; they are not measurements."""
+    gpu = False
+    FRAME = (37, 41)      # rays = 1517: ragged over 2, 3 and 8 ranks
+
+    def __init__(self, precision, device, rank, world, kind='headline'):
+        from simplenerf_amd import harness
+        self.harness, self.rank, self.world = harness, rank, world
+        self.first = rank * RAYS_PER_GPU
+
+    @staticmethod
+    def _outputs(first, count):
+        idx = torch.arange(first, first + count, dtype=torch.float32)
+        return {'rgb_fine': torch.stack([idx, 2 * idx, 3 * idx], 1), 'depth_fine': idx + 0.5}
+
+    def local(self):
+        return self._outputs(self.first, RAYS_PER_GPU)
+
+    def step(self):
+        local = self.local()
+        if self.world > 1:
+            full = self.harness.gather_rays(local, self.world * RAYS_PER_GPU, self.rank, self.world)
+        else:
+            full = local
+        if self.rank == 0:
+            ref = self._outputs(0, self.world * RAYS_PER_GPU)
+            assert all(torch.equal(full[k], ref[k]) for k in ref)
+        return full
+
+    def frame_camera(self, name):
+        return {'resolution': self.FRAME}
+
+    def frame(self, name):
+        n = self.FRAME[0] * self.FRAME[1]
+        first, count = self.harness.shard_range(n, self.rank, self.world)
+        local = self._outputs(first, count)
+        full = self.harness.gather_rays(local, n, self.rank, self.world) if self.world > 1 else local
+        if self.rank != 0:
+            return None
+        ref = self._outputs(0, n)
+        assert all(torch.equal(full[k], ref[k]) for k in ref)
+        return {'image': full['rgb_fine'].numpy(), 'depth': full['depth_fine'].numpy()}
+
+    def frame_block(self, name, rays=65536):
+        self._outputs(0, 64)
+
+    def profile(self, capacity):
+        pass
+
+    def profile_reset(self):
+        pass
+
+    def profile_collect(self):
+        return [], [], 0
+
+
 # ---------------------------------------------------------------------------------------------- config 5 (training)
 def training_step(precision, rank, world, device, single_pass=False):
     """BASELINE config 5: a callable running ONE iteration of the reference's training loop (Trainer.train_one_iter,
@@ -200,23 +454,24 @@ TRAIN_DTYPE = {'fp32': 'f32', 'f16x3': 'f16x3', 'f16': 'f16 (bf16 layer gradient
 
 
 def time_training(precision, device, steps, warmup, single_pass=False, board_seconds=0.0):
-    """Config 5 on one GPU: (ms per iteration, ms of MLP forward launches, ms of MLP backward calls) from ``steps`` timed
-    iterations after ``warmup``."""
+    """Config 5 on one GPU: (ms per iteration, ms of MLP forward launches, ms of MLP backward calls, rows, timing summary)
+    from ``steps`` timed iterations after a settle phase and ``warmup`` iterations."""
     _, ops, _, _ = _pkg()
     step, rows = training_step(precision, 0, 1, device, single_pass)
+    settle(step, None, chunk=2)
+    ops.profile_enable(64 * (steps + warmup))
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    ops.profile_enable(64 * steps)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    ops.profile_reset()
+    elapsed, device_ms, enqueue_ms = timed_steps(step, steps, torch.cuda.synchronize)
     fwd, _ = ops.profile_collect(ops.PROFILE_MLP_FORWARD)
     bwd, _ = ops.profile_collect(ops.PROFILE_MLP_BACKWARD)
+    dropped = ops.profile_dropped()
     ops.profile_enable(0)
     time_training.board = None
+    time_training.timing = step_summary(elapsed, device_ms, enqueue_ms, None)
+    time_training.timing['launches_not_timed'] = dropped
     if board_seconds > 0:      # the same iteration for about a second with the board's power / clock sensors sampled
         sampler = BoardSampler(device.index or 0)
         with sampler:
@@ -247,7 +502,8 @@ def training_record(device, steps=10, warmup=3):
             'dtype': TRAIN_DTYPE[precision], 'ms_per_step': ms, 'value': rows / (ms * 1e-3), 'unit': 'rays/s',
             'algorithmic_tflops': tflops, 'peak_tflops': peak, 'frac_of_peak': tflops / peak,
             'mlp_forward_ms_per_step': fwd_ms, 'mlp_backward_ms_per_step': bwd_ms,
-            'mlp_share_of_step': (fwd_ms + bwd_ms) / ms, 'dominant_kernels': dominant[precision]}
+            'mlp_share_of_step': (fwd_ms + bwd_ms) / ms, 'dominant_kernels': dominant[precision],
+            'timing': time_training.timing}
     return out
 
 
@@ -260,14 +516,12 @@ def train_bench(args, rank, world, device, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):       # (the all-reduce keeps the ranks in step: the settle phase counts steps here)
         step()
     fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    if world == 1:
+        settle(step, None, chunk=2)
+    elapsed, device_ms, enqueue_ms = timed_steps(step, args.steps, fence)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -280,69 +534,236 @@ def train_bench(args, rank, world, device, dist):
             'vs_baseline': None, 'dtype': TRAIN_DTYPE[args.precision], 'data': 'synthetic',
             'config': {'workload': TRAIN_WORKLOAD, 'rows_per_gpu': per_gpu, 'single_pass': bool(args.single_pass),
                        'parallelism': f'row-shard x{world}' + (' + 1 gradient all-reduce/step' if world > 1 else '')},
-            'algorithmic_tflops': per_gpu * TRAIN_FLOP_PER_RAY * world * args.steps / elapsed / 1e12}
+            'algorithmic_tflops': per_gpu * TRAIN_FLOP_PER_RAY * world * args.steps / elapsed / 1e12,
+            'timing': step_summary(elapsed, device_ms, enqueue_ms, None)}
         if world > 1:
             line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size()}
         print(json.dumps(line), flush=True)
 
 
-# ---------------------------------------------------------------------------------------------- stand-in (tests only)
-def standin_bench(args, rank, world, dist):
-    """SNERF_BENCH_STANDIN=1 (tests/test_dist_gloo.py only): the launcher, rendezvous, per-rank block, gather, barrier,
-    max-over-ranks timing and JSON line of the render bench with the renderer replaced by a CPU stand-in, so that the
-    N > 1 path is exercised without GPUs.  The line says so (``"data": "stand-in"``); it is not a measurement."""
-    from simplenerf_amd import harness
-    first = rank * RAYS_PER_GPU
-
-    def step():
-        idx = torch.arange(first, first + RAYS_PER_GPU, dtype=torch.float32)
-        local = {'rgb_fine': torch.stack([idx, 2 * idx, 3 * idx], 1), 'depth_fine': idx + 0.5}
-        return harness.gather_rays(local, world * RAYS_PER_GPU, rank, world) if world > 1 else local
-
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
+# ---------------------------------------------------------------------------------------------- whole frames (configs 2, 4)
+def time_frames(renderer, name, frames, warmup, fence, world, dist=None, device=None):
+    """``frames`` whole frames through Tester.predict_frame's path on this rank's share of the pixels, each rank's wall
+    time fenced on both sides; -> (max-over-ranks seconds for all frames, rays per frame, last frame's outputs on rank 0)."""
+    cam = renderer.frame_camera(name)
+    rays = int(cam['resolution'][0]) * int(cam['resolution'][1])
+    if world == 1:
+        settle(lambda: renderer.frame_block(name), None, renderer.gpu, chunk=1)
+    out = None
+    for _ in range(warmup):
+        out = renderer.frame(name)
+    fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        full = step()
-    if world > 1:
-        dist.barrier()
+    for _ in range(frames):
+        out = renderer.frame(name)
+    fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if rank == 0:
-        ref = torch.arange(world * RAYS_PER_GPU, dtype=torch.float32)
-        assert torch.equal(full['depth_fine'], ref + 0.5) and torch.equal(full['rgb_fine'][:, 2], 3 * ref)
-        line = {'metric': 'rays/sec (coarse+fine, 128+128 samples)', 'value': world * RAYS_PER_GPU * args.steps / elapsed,
-                'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                'dtype': 'none', 'data': 'stand-in', 'config': {'workload': 'launcher rehearsal, no renderer'}}
+    return elapsed, rays, out
+
+
+def frame_entry(name, precision, elapsed, rays, frames, world):
+    peak = PRECISION_INFO[precision][0]
+    tflops = rays * FRAME_SAMPLES * FLOP_PER_SAMPLE * frames / elapsed / 1e12
+    return {'frame': name, 'workload': FRAMES[name][2], 'rays': rays, 'samples': '64+128 (192 merged)', 'precision': precision,
+            'frames': frames, 'ms_per_frame': elapsed / frames * 1e3, 'value': rays * frames / elapsed, 'unit': 'rays/s',
+            'algorithmic_tflops': tflops, 'peak_tflops': peak * world, 'frac_of_peak': tflops / (peak * world)}
+
+
+FRAME_PATH = ('on-device ray generation per 65536-ray block -> coarse+fine render -> display conversion (uint8 colour, '
+              'clipped depths) -> D2H of the five display outputs (Tester.predict_frame, src/Tester01.py:57-66); wall time')
+
+
+def frame_records_single(make_renderer, fence):
+    """N = 1 part of ``also_measured_frame``: configs 2 and 4 as whole frames, fp32 and f16x3."""
+    entries = []
+    for precision in ('fp32', 'f16x3'):
+        renderer = make_renderer(precision, 'config2')
+        for name in ('fern', 'fern504', 're10k'):
+            frames = 1 if precision == 'fp32' and name != 'fern504' else 2
+            elapsed, rays, _ = time_frames(renderer, name, frames, 1 if precision != 'fp32' else 0, fence, 1)
+            entries.append(frame_entry(name, precision, elapsed, rays, frames, 1))
+    return {'path': FRAME_PATH, 'n_gpus': 1, 'entries': entries}
+
+
+def frame_records_sharded(make_renderer, fence, rank, world, dist, device, name='re10k'):
+    """N > 1 part: ONE frame strong-scaled over the ranks (block shard of the pixels, one gather to rank 0)."""
+    entries = []
+    for precision in ('fp32', 'f16x3'):
+        renderer = make_renderer(precision, 'config2')
+        elapsed, rays, _ = time_frames(renderer, name, 3, 1, fence, world, dist, device)
+        entries.append(frame_entry(name, precision, elapsed, rays, 3, world))
+    per = -(-rays // world)
+    return {'path': FRAME_PATH, 'n_gpus': world, 'scaling': 'strong', 'entries': entries,
+            'collective': {'backend': dist.get_backend(), 'ranks': world, 'bytes_per_rank_and_frame': per * FRAME_GATHER_BYTES,
+                           'pattern': 'one gather of the five per-ray outputs to rank 0 per frame'}}
+
+
+def frame_bench(args, rank, world, device, dist, make_renderer, data):
+    """--frame NAME: the frame is the unit of work (BASELINE config 4: 'full-frame render, ray-batch shard across 8 GPUs +
+    RCCL gather').  STRONG scaling: the frame's rays are block-sharded over the N ranks (harness.shard_range), every rank
+    generates and renders its own block, rank 0 receives the frame through one gather, converts and copies it to the host.
+    `value` = frame rays x K frames / max-over-ranks wall time."""
+    def fence():
         if world > 1:
-            line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size()}
-        print(json.dumps(line), flush=True)
+            dist.barrier()
+        if data == 'synthetic':
+            torch.cuda.synchronize()
+
+    renderer = make_renderer(args.precision, 'config2')
+    elapsed, rays, out = time_frames(renderer, args.frame, args.steps, args.warmup, fence, world, dist, device)
+    if rank != 0:
+        return
+    assert out is not None and all(numpy.asarray(v).size > 0 for v in out.values())
+    entry = frame_entry(args.frame, args.precision, elapsed, rays, args.steps, world)
+    per = -(-rays // world)
+    line = {'metric': 'rays/sec, full frame (64+128 samples, 8x256 coarse+fine) incl. raygen, gather and display output',
+            'value': entry['value'], 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': entry['ms_per_frame'], 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': PRECISION_INFO[args.precision][1] if data == 'synthetic' else 'none', 'data': data,
+            'config': {'workload': FRAMES[args.frame][2] + ': one frame per step, ' + FRAME_PATH, 'rays_per_frame': rays,
+                       'rays_per_gpu': per, 'samples': '64+128', 'parallelism': f'ray-shard x{world}' + (' + 1 gather/frame' if world > 1 else '')},
+            'roofline': {'bound': 'mfma', 'achieved': entry['algorithmic_tflops'], 'peak': entry['peak_tflops'], 'unit': 'TFLOP/s',
+                         'frac': entry['frac_of_peak'], 'traffic': None,
+                         'note': 'whole-frame wall time (not a kernel time): algorithmic FLOPs of the frame / wall, against N x the per-GPU peak'}}
+    if world > 1:
+        line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
+                              'bytes': per * FRAME_GATHER_BYTES, 'pattern': 'one gather of the five per-ray outputs to rank 0 per frame'}
+    print(json.dumps(line), flush=True)
 
 
 # ---------------------------------------------------------------------------------------------- headline
+def measure_headline(renderer, steps, warmup, fence, world, do_settle=True):
+    """settle -> warm-up (event hooks on) -> timed region.  -> dict of raw measurements for ``headline_line``."""
+    with torch.no_grad():
+        settle_info = settle(renderer.local, None, renderer.gpu) if do_settle else None
+        renderer.profile(4 * (steps + warmup) + 16)
+        for _ in range(warmup):
+            renderer.step()
+        fence()
+        renderer.profile_reset()
+        elapsed, device_ms, enqueue_ms = timed_steps(renderer.step, steps, fence, renderer.gpu)
+    launch_ms, launch_samples, dropped = renderer.profile_collect()
+    renderer.profile(0)
+    return {'elapsed': elapsed, 'device_ms': device_ms, 'enqueue_ms': enqueue_ms, 'launch_ms': launch_ms,
+            'launch_samples': launch_samples, 'dropped': dropped, 'settle_info': settle_info}
+
+
+def render_bench(args, rank, world, device, dist, make_renderer, data):
+    gpu = data == 'synthetic'
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        if gpu:
+            torch.cuda.synchronize()
+
+    renderer = make_renderer(args.precision, 'headline')
+    m = measure_headline(renderer, args.steps, args.warmup, fence, world)
+    if world > 1:
+        t = torch.tensor([m['elapsed']], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        m['elapsed'] = float(t.item())
+    result = None
+    if rank == 0:
+        result = headline_line(world, args.steps, args.warmup, args.precision, m['elapsed'], m['device_ms'], m['enqueue_ms'],
+                               m['launch_ms'], m['launch_samples'], m['dropped'], m['settle_info'], data)
+        if not gpu:
+            result['dtype'] = 'none'
+            result['config'] = {'workload': 'launcher rehearsal, no renderer'}
+        if world > 1:
+            result['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
+                                    'bytes': RAYS_PER_GPU * 16, 'pattern': 'one gather of (rgb, depth) = 16 B/ray to rank 0 per step'}
+    alt = args.precision == 'fp32' and not args.no_alt
+    if world > 1 and alt:
+        frames = frame_records_sharded(make_renderer, fence, rank, world, dist, device)     # every rank takes part
+        if rank == 0:
+            result['also_measured_frame'] = frames
+    if rank != 0:
+        return
+    if world == 1 and alt and gpu:
+        harness, ops, synth, _ = _pkg()
+
+        def board_state(r, achieved_tflops, nominal_peak, seconds=1.2):
+            """the same step back to back for ~1.2 s with the board's sensors sampled: power, cap, shader clock, and the
+            fraction of the peak AT THAT CLOCK (the nominal peaks are quoted at 2.4 GHz; the sysfs clock is the firmware's
+            average, in-kernel clock reads can be lower -- tools/probes/clock_stamp.py measures that)"""
+            sampler = BoardSampler(device.index or 0)
+            with torch.no_grad(), sampler:
+                t0 = time.perf_counter()
+                while time.perf_counter() - t0 < seconds:
+                    for _ in range(25):
+                        r.local()
+                    torch.cuda.synchronize()
+            state = sampler.summary()
+            if state['sclk_mhz']:
+                state['frac_of_peak_at_this_clock'] = achieved_tflops / (nominal_peak * state['sclk_mhz'] / 2400.0)
+            return state
+
+        def tflops(meas):
+            return sum(meas['launch_samples']) * FLOP_PER_SAMPLE / (sum(meas['launch_ms']) * 1e-3) / 1e12
+
+        sustained_steps = 300       # ~1 s of device time
+        s = measure_headline(renderer, sustained_steps, args.warmup, fence, 1, do_settle=False)
+        s_tf = tflops(s)
+        result['sustained'] = {'steps': sustained_steps, 'value': RAYS_PER_GPU * sustained_steps / s['elapsed'], 'unit': 'rays/s',
+                               'ms_per_step': s['elapsed'] / sustained_steps * 1e3, 'achieved': s_tf,
+                               'frac': s_tf / PEAK_FP32_MFMA_TFLOPS, 'timed_region_s': s['elapsed'],
+                               'timing': step_summary(s['elapsed'], s['device_ms'], s['enqueue_ms'], sum(s['launch_ms'])),
+                               'board': board_state(renderer, s_tf, PEAK_FP32_MFMA_TFLOPS)}
+        for key, precision, text in (
+                ('also_measured', 'f16x3', 'f16x3 (fp16 hi/lo split, 3 MFMA passes per product, fp32 accumulate; same parity tests)'),
+                ('also_measured_16bit', 'f16', 'f16 (one fp16 MFMA pass per product, fp32 accumulate; OUTSIDE the fp32 parity bar -- '
+                 'colour ~1e-4, depth ~6e-4 from the fp32 path, tests/test_gpu_f16.py; BASELINE config 5 names this mode for training)')):
+            r = make_renderer(precision, 'headline')
+            a = measure_headline(r, args.steps, args.warmup, fence, 1)
+            line = headline_line(1, args.steps, args.warmup, precision, a['elapsed'], a['device_ms'], a['enqueue_ms'],
+                                 a['launch_ms'], a['launch_samples'], a['dropped'], a['settle_info'])
+            if precision == 'f16x3':
+                line['roofline']['frac_of_fp16_peak'] = line['roofline']['achieved'] / PEAK_FP16_MFMA_TFLOPS
+            result[key] = {'precision': text, 'value': line['value'], 'unit': 'rays/s', 'ms_per_step': line['ms_per_step'],
+                           'roofline': line['roofline'], 'timing': line['timing'],
+                           'board': board_state(r, line['roofline']['achieved'], PRECISION_INFO[precision][0])}
+            del r
+        result['also_measured_frame'] = frame_records_single(make_renderer, fence)
+        result['also_measured_train'] = training_record(device)
+    if world == 1 and gpu and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(renderer.configs, renderer.camera, renderer.first)
+    print(json.dumps(result), flush=True)
+
+
 def main():
+    global SETTLE_SECONDS
     ap = argparse.ArgumentParser()
     ap.add_argument('--train', action='store_true',
                     help='measure BASELINE config 5 (training iteration) instead of the headline render metric')
+    ap.add_argument('--frame', choices=sorted(FRAMES), default=None,
+                    help='measure whole frames of that camera, strong-scaled over the ranks (BASELINE config 2 / 4), instead '
+                         'of the headline step; --steps counts frames (default 5)')
     ap.add_argument('--single-pass', action='store_true',
                     help='--train: one model forward/backward over the whole batch, losses still normalised per sub-batch '
                          '(harness.train_one_iter single_pass)')
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default 50; 5 frames with --frame)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed warm-up steps (default 5; 1 frame with --frame)')
+    ap.add_argument('--settle-seconds', type=float, default=None,
+                    help=f'untimed settle phase before the warm-up steps (default {SETTLE_SECONDS}; 0 reproduces the cold start)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-alt', action='store_true', help='skip the secondary measurements (other precisions, training, sustained)')
+    ap.add_argument('--no-alt', action='store_true', help='skip the secondary measurements (other precisions, frames, training, sustained)')
     ap.add_argument('--precision', choices=('fp32', 'f16x3', 'f16'), default='fp32',
                     help="arithmetic of the fused MLP kernel: fp32 MFMA; fp16 hi/lo split with 3 MFMAs per product "
                          "(fp32-grade results, same parity tests); or f16 = one fp16 MFMA per product with 16-bit saved "
                          "tensors (BASELINE config 5's 16-bit training mode, own tolerances: tests/test_gpu_f16.py)")
     args = ap.parse_args()
+    if args.settle_seconds is not None:
+        SETTLE_SECONDS = max(0.0, args.settle_seconds)
+    if args.steps is None:
+        args.steps = 5 if args.frame else 50
+    if args.warmup is None:
+        args.warmup = 1 if args.frame else 5
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))       # nothing above this line touches the GPU
@@ -365,20 +786,26 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # RCCL ('nccl') on a multi-GPU node; SNERF_DIST_BACKEND=gloo lets the same code path be rehearsed with several
-        # ranks sharing one GPU (RCCL refuses two ranks on one device) or, with the stand-in step, on the CPU
+        # ranks sharing one GPU (RCCL refuses two ranks on one device) or, with the stand-in renderer, on the CPU
         backend = os.environ.get('SNERF_DIST_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    def make_renderer(precision, kind):
+        return (StandInRenderer if standin else HipRenderer)(precision, device, rank, world, kind)
+
+    data = 'stand-in' if standin else 'synthetic'
     try:
-        if standin:
-            standin_bench(args, rank, world, dist)
-        elif args.train:
+        if args.train:
+            if standin:
+                raise SystemExit('--train has no stand-in')
             train_bench(args, rank, world, device, dist)
+        elif args.frame:
+            frame_bench(args, rank, world, device, dist, make_renderer, data)
         else:
-            render_bench(args, rank, world, device, dist)
+            render_bench(args, rank, world, device, dist, make_renderer, data)
     finally:
         if world > 1:
             dist.barrier()
@@ -447,153 +874,6 @@ class BoardSampler:
         cap = self._read(self.paths['cap']) if 'cap' in self.paths else None
         return {'power_w': None if power is None else power / 1e6, 'power_cap_w': None if cap is None else cap / 1e6,
                 'sclk_mhz': None if sclk is None else sclk / 1e6, 'readings': len(rows)}
-
-
-def render_bench(args, rank, world, device, dist):
-    harness, ops, synth, _ = _pkg()
-    configs = synth.make_configs('headline')
-    camera = synth.camera('fern', 0)
-    h, w = camera['resolution']
-    model = synthetic_model(configs, 7, device, args.precision)
-    # rank r renders pixels [base + r*1024, base + (r+1)*1024) from the middle of the frame
-    base = (h // 2) * w
-    first = base + rank * RAYS_PER_GPU
-    keys = ('rgb_fine', 'depth_fine')
-
-    def step():
-        batch = harness.frame_batch(camera, True, device, first, RAYS_PER_GPU)
-        out = model(batch)
-        local = {k: out[k] for k in keys}
-        if world > 1:
-            return harness.gather_rays(local, world * RAYS_PER_GPU, rank, world)
-        return local
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        fence()
-        # the library brackets every fused PE+MLP launch with HIP events on the launch stream (snerf_profile_enable)
-        ops.profile_enable(4 * args.steps + 16)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        elapsed = time.perf_counter() - t0
-    launch_ms, launch_samples = ops.profile_collect(ops.PROFILE_MLP_FORWARD)
-    ops.profile_enable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank != 0:
-        return
-
-    kernel_ms = sum(launch_ms)
-    kernel_flop = sum(launch_samples) * FLOP_PER_SAMPLE
-    achieved = kernel_flop / (kernel_ms * 1e-3) / 1e12
-    if args.precision == 'fp32':
-        peak, dtype, kernel_name = PEAK_FP32_MFMA_TFLOPS, 'f32', 'mlp_forward_kernel<8,4,true,false,false>'
-        note = 'fp32 MFMA: one pass per algorithmic FLOP'
-    elif args.precision == 'f16x3':
-        peak, dtype, kernel_name = PEAK_FP16_MFMA_TFLOPS, 'f16x3 (fp16 hi/lo split, fp32 accumulate)', \
-            'mlp_forward_m16_kernel<3,8>'
-        note = ('achieved counts ALGORITHMIC FLOPs; the kernel issues 3 fp16 MFMA passes per product, so its ceiling is '
-                'peak/3 = 833 TFLOP/s and MFMA-pipe utilisation = 3 x frac')
-    else:
-        peak, dtype, kernel_name = PEAK_FP16_MFMA_TFLOPS, 'f16 (fp16 MFMA, fp32 accumulate)', \
-            'mlp_forward_m16_kernel<1,8>'
-        note = 'one fp16 MFMA pass per product; NOT within the fp32 parity bar (sigma ~1e-3 relative)'
-
-    result = {
-        'metric': 'rays/sec (coarse+fine, 128+128 samples)',
-        'value': world * RAYS_PER_GPU * args.steps / elapsed,
-        'unit': 'rays/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': elapsed / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': dtype, 'data': 'synthetic',
-        'config': {'workload': WORKLOAD, 'rays_per_gpu': RAYS_PER_GPU, 'samples': '128+128',
-                   'parallelism': f'ray-shard x{world}' + (' + 1 gather/step' if world > 1 else '')},
-        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                     'frac': achieved / peak, 'traffic': pmc_traffic(args.precision),
-                     'kernel': kernel_name, 'note': note, 'launches': len(launch_ms),
-                     'avg_launch_ms': kernel_ms / max(1, len(launch_ms)),
-                     'kernel_share_of_step': kernel_ms / (elapsed * 1e3)},
-    }
-    if world > 1:
-        result['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
-                                'pattern': 'one gather of (rgb, depth) = 16 B/ray to rank 0 per step'}
-    if world == 1 and args.precision == 'fp32' and not args.no_alt:
-        # the same step with the other two arithmetic modes of the fused MLP kernel, as secondary measurements
-        def measure(precision, steps):
-            alt_model = model if precision == 'fp32' else synthetic_model(configs, 7, device, precision)
-            with torch.no_grad():
-                for _ in range(args.warmup):
-                    alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
-                torch.cuda.synchronize()
-                ops.profile_enable(4 * steps + 16)
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
-                torch.cuda.synchronize()
-                alt_elapsed = time.perf_counter() - t0
-            alt_ms, alt_samples = ops.profile_collect(ops.PROFILE_MLP_FORWARD)
-            ops.profile_enable(0)
-            alt_tf = sum(alt_samples) * FLOP_PER_SAMPLE / (sum(alt_ms) * 1e-3) / 1e12
-            measure.kernel_share = sum(alt_ms) / (alt_elapsed * 1e3)
-            return alt_elapsed, alt_tf
-
-        def board_state(precision, achieved_tflops, nominal_peak, seconds=1.2):
-            """the same step back to back for ~1.2 s with the board's sensors sampled: power, cap, shader clock, and the
-            fraction of the peak AT THAT CLOCK (the nominal peaks are quoted at 2.4 GHz)"""
-            alt_model = model if precision == 'fp32' else synthetic_model(configs, 7, device, precision)
-            sampler = BoardSampler(device.index or 0)
-            with torch.no_grad(), sampler:
-                t0 = time.perf_counter()
-                while time.perf_counter() - t0 < seconds:
-                    for _ in range(25):
-                        alt_model(harness.frame_batch(camera, True, device, first, RAYS_PER_GPU))
-                    torch.cuda.synchronize()
-            state = sampler.summary()
-            if state['sclk_mhz']:
-                state['frac_of_peak_at_this_clock'] = achieved_tflops / (nominal_peak * state['sclk_mhz'] / 2400.0)
-            return state
-
-        sustained_steps = 300       # ~1 s of device time: long enough for the clocks to settle under the load
-        s_elapsed, s_tf = measure('fp32', sustained_steps)
-        result['sustained'] = {'steps': sustained_steps, 'value': RAYS_PER_GPU * sustained_steps / s_elapsed, 'unit': 'rays/s',
-                               'ms_per_step': s_elapsed / sustained_steps * 1e3, 'achieved': s_tf,
-                               'frac': s_tf / PEAK_FP32_MFMA_TFLOPS, 'timed_region_s': s_elapsed,
-                               'board': board_state('fp32', s_tf, PEAK_FP32_MFMA_TFLOPS)}
-        alt_elapsed, alt_tf = measure('f16x3', args.steps)
-        result['also_measured'] = {
-            'precision': 'f16x3 (fp16 hi/lo split, 3 MFMA passes per product, fp32 accumulate; same parity tests)',
-            'value': RAYS_PER_GPU * args.steps / alt_elapsed, 'unit': 'rays/s', 'ms_per_step': alt_elapsed / args.steps * 1e3,
-            'roofline': {'bound': 'mfma', 'achieved': alt_tf, 'peak': PEAK_FP16_MFMA_TFLOPS / 3, 'unit': 'TFLOP/s',
-                         'frac': alt_tf / (PEAK_FP16_MFMA_TFLOPS / 3), 'frac_of_fp16_peak': alt_tf / PEAK_FP16_MFMA_TFLOPS,
-                         'note': 'peak = fp16 dense MFMA peak / 3: the kernel issues three fp16 MFMA passes per algorithmic '
-                                 'product, achieved counts algorithmic FLOPs',
-                         'kernel': 'mlp_forward_m16_kernel<3,8>',
-                         'kernel_share_of_step': measure.kernel_share},
-            'board': board_state('f16x3', alt_tf, PEAK_FP16_MFMA_TFLOPS / 3)}
-        alt_elapsed, alt_tf = measure('f16', args.steps)
-        result['also_measured_16bit'] = {
-            'precision': 'f16 (one fp16 MFMA pass per product, fp32 accumulate; OUTSIDE the fp32 parity bar -- colour ~1e-4, '
-                         'depth ~6e-4 from the fp32 path, tests/test_gpu_f16.py; BASELINE config 5 names this mode for training)',
-            'value': RAYS_PER_GPU * args.steps / alt_elapsed, 'unit': 'rays/s', 'ms_per_step': alt_elapsed / args.steps * 1e3,
-            'roofline': {'bound': 'mfma', 'achieved': alt_tf, 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': alt_tf / PEAK_FP16_MFMA_TFLOPS, 'kernel': 'mlp_forward_m16_kernel<1,8>',
-                         'kernel_share_of_step': measure.kernel_share},
-            'board': board_state('f16', alt_tf, PEAK_FP16_MFMA_TFLOPS)}
-        result['also_measured_train'] = training_record(device)
-    if world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(configs, camera, first)
-    print(json.dumps(result), flush=True)
 
 
 if __name__ == '__main__':

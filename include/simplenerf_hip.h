@@ -30,7 +30,7 @@ enum snerf_status {
 
 /* ABI version of this header; bumped on any signature change (new enum values such as SNERF_PRECISION_F16 extend a
  * version without changing it: older callers never pass them). */
-#define SNERF_ABI_VERSION 6
+#define SNERF_ABI_VERSION 7
 int snerf_abi_version(void);
 const char* snerf_last_error(void);
 
@@ -314,12 +314,16 @@ int snerf_to_display(const float* rgb, const float* depth, long long num_rays, u
  *   snerf_profile_enable(capacity)   create `capacity` event pairs and start recording; capacity <= 0 stops and frees
  *   snerf_profile_collect(kind, ms, samples, capacity)   waits for the recorded events of that kind and writes each
  *        launch's duration in milliseconds and its number of samples (rays x samples); returns how many, or < 0
- *   snerf_profile_reset()            forget the recorded launches, keep recording
- * Process-wide, off by default (one relaxed atomic load on the launch path).  Do not enable during graph capture. */
+ *   snerf_profile_reset()            forget the recorded launches (and the dropped count), keep recording
+ *   snerf_profile_dropped()          launches since enable / reset that were NOT timed because all `capacity` pairs were in
+ *                                    use -- a measurement whose count is not zero under-counts kernel time and FLOPs
+ * Process-wide, off by default (one relaxed atomic load on the launch path).  Launches enqueued on a stream that is being
+ * captured into a graph are never timed (hipStreamIsCapturing), so the hooks may stay enabled across a capture. */
 enum snerf_profile_kind { SNERF_PROFILE_MLP_FORWARD = 0, SNERF_PROFILE_MLP_BACKWARD = 1 };
 int snerf_profile_enable(int capacity);
 int snerf_profile_collect(int kind, float* milliseconds, long long* samples, int capacity);
 int snerf_profile_reset(void);
+long long snerf_profile_dropped(void);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_s
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsimplenerf_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class MlpDesc(ctypes.Structure):
@@ -107,6 +107,7 @@ SIGNATURES = {
     'snerf_profile_enable': (c_int, [c_int]),
     'snerf_profile_collect': (c_int, [c_int, POINTER(c_float), POINTER(c_longlong), c_int]),
     'snerf_profile_reset': (c_int, []),
+    'snerf_profile_dropped': (c_longlong, []),
     'snerf_render_workspace_floats': (c_size_t, [POINTER(RenderConfig), c_longlong]),
     'snerf_render_forward': (c_int, [POINTER(RenderConfig), POINTER(RenderMlp), POINTER(RenderRays), c_longlong,
                                      POINTER(RenderOutputs), _FP, c_void_p]),

@@ -15,7 +15,9 @@ extern "C" const char* snerf_last_error(void) { return snerf::error_buffer(); }
 // Opt-in timing of the dominant kernels (bench.py's roofline leg): while enabled, every snerf_mlp_forward[_train]
 // launch (kind 0) and every snerf_mlp_backward call (kind 1) is bracketed by a pair of HIP events recorded on the
 // stream it is enqueued on -- also when it is issued from inside snerf_render_forward / _backward.  Off by default;
-// the hot path then pays one relaxed atomic load.  Not for use during graph capture (the records would be captured).
+// the hot path then pays one relaxed atomic load.  A launch enqueued while its stream is being captured into a graph
+// is not timed (an event record would become a graph node and the pre-created events would be reused by every replay);
+// launches that find the event table full are counted (snerf_profile_dropped) instead of vanishing silently.
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -26,13 +28,16 @@ struct ProfileEntry { hipEvent_t start, stop; long long samples; int kind; };
 std::mutex g_profile_mutex;
 std::vector<ProfileEntry> g_profile;     // pre-created event pairs
 int g_profile_used = 0;
+long long g_profile_dropped = 0;         // launches seen while enabled that got no event pair (table full)
 std::atomic<int> g_profile_on{0};
 }  // namespace
 
 int profile_begin(int kind, hipStream_t stream, long long samples) {
     if (!g_profile_on.load(std::memory_order_relaxed)) return -1;
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone) return -1;
     std::lock_guard<std::mutex> lock(g_profile_mutex);
-    if (g_profile_used >= (int)g_profile.size()) return -1;
+    if (g_profile_used >= (int)g_profile.size()) { ++g_profile_dropped; return -1; }
     const int slot = g_profile_used++;
     g_profile[slot].samples = samples;
     g_profile[slot].kind = kind;
@@ -54,6 +59,7 @@ extern "C" int snerf_profile_enable(int capacity) {
     for (ProfileEntry& e : g_profile) { (void)hipEventDestroy(e.start); (void)hipEventDestroy(e.stop); }
     g_profile.clear();
     g_profile_used = 0;
+    g_profile_dropped = 0;
     if (capacity <= 0) return SNERF_OK;
     g_profile.resize((size_t)capacity);
     for (ProfileEntry& e : g_profile) {
@@ -85,5 +91,11 @@ extern "C" int snerf_profile_collect(int kind, float* milliseconds, long long* s
 extern "C" int snerf_profile_reset(void) {
     std::lock_guard<std::mutex> lock(snerf::g_profile_mutex);
     snerf::g_profile_used = 0;
+    snerf::g_profile_dropped = 0;
     return SNERF_OK;
+}
+
+extern "C" long long snerf_profile_dropped(void) {
+    std::lock_guard<std::mutex> lock(snerf::g_profile_mutex);
+    return snerf::g_profile_dropped;
 }

@@ -61,6 +61,11 @@ def profile_reset() -> None:
     _lib.check(_lib.load().snerf_profile_reset(), 'snerf_profile_reset')
 
 
+def profile_dropped() -> int:
+    """Launches since the last enable / reset that found the event table full and were therefore not timed."""
+    return int(_lib.load().snerf_profile_dropped())
+
+
 def profile_collect(kind: int, capacity: int = 65536):
     """-> (milliseconds, samples): per recorded launch of ``kind`` its duration and its number of (ray, sample) rows.
     Waits for the events."""

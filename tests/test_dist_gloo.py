@@ -142,28 +142,57 @@ def test_two_rank_training_iteration_equals_single_process(tmp_path):
     assert open(marker).read() == 'ok'
 
 
-@pytest.mark.parametrize('ranks', [2, 3])
-def test_bench_self_launches_its_ranks(ranks):
-    """``python bench.py --gpus N`` with no launcher around it (how the driver calls it): bench.py starts its N rank
-    processes itself, they rendezvous over torch.distributed (gloo here, RCCL on a GPU node), every rank contributes its
-    1024-ray block to the gather, and the parent relays ONE JSON line whose ``collective`` object reports the ranks.  The
-    renderer is replaced by the CPU stand-in (SNERF_BENCH_STANDIN=1) -- what is exercised is the launcher and the N > 1
-    protocol, which needs no GPU."""
+def _run_bench(ranks, *flags):
     import json
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(SNERF_BENCH_STANDIN='1', SNERF_DIST_BACKEND='gloo')
-    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', str(ranks), '--steps', '3', '--warmup', '1'],
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', str(ranks), *flags],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout
-    line = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('ranks', [2, 3])
+def test_bench_self_launches_its_ranks(ranks):
+    """``python bench.py --gpus N`` with no launcher around it (how the driver calls it): bench.py starts its N rank
+    processes itself, they rendezvous over torch.distributed (gloo here, RCCL on a GPU node), every rank contributes its
+    1024-ray block to the gather, and the parent relays ONE JSON line whose ``collective`` object reports the ranks.  The
+    renderer is replaced by the CPU stand-in (SNERF_BENCH_STANDIN=1) -- what is exercised is the launcher and the N > 1
+    protocol (settle, warm-up, fenced timed region with per-step stamps, max over ranks), which needs no GPU.  The default
+    N > 1 line also carries BASELINE config 4's frame, strong-scaled over the same ranks (``also_measured_frame``)."""
+    line = _run_bench(ranks, '--steps', '3', '--warmup', '1')
     assert line['n_gpus'] == ranks and line['steps'] == 3 and line['warmup'] == 1 and line['scaling'] == 'weak'
-    assert line['collective'] == {'backend': 'gloo', 'ranks': ranks}
+    assert line['collective']['backend'] == 'gloo' and line['collective']['ranks'] == ranks
+    assert line['collective']['bytes'] == 1024 * 16
     assert line['data'] == 'stand-in' and line['value'] > 0
+    timing = line['timing']
+    assert set(timing['step_ms']) == {'p50', 'p90', 'max', 'first', 'argmax'} and len(timing['step_trace_ms']) == 3
+    assert timing['settle']['seconds'] >= 0.5 and timing['settle']['runs'] > 0
+    frames = line['also_measured_frame']
+    assert frames['n_gpus'] == ranks and frames['scaling'] == 'strong' and frames['collective']['ranks'] == ranks
+    rays = 37 * 41
+    assert [e['rays'] for e in frames['entries']] == [rays, rays] and all(e['value'] > 0 for e in frames['entries'])
+    assert frames['collective']['bytes_per_rank_and_frame'] == -(-rays // ranks) * 28
+
+
+@pytest.mark.parametrize('ranks', [1, 2, 3])
+def test_bench_frame_mode_strong_scales_one_frame(ranks):
+    """``python bench.py --gpus N --frame re10k`` (BASELINE config 4: one full frame, rays block-sharded over the ranks, one
+    gather to rank 0): the stand-in frame has 1517 rays -- ragged over 2 and 3 ranks -- and rank 0 checks every gathered
+    frame element by element inside bench.py."""
+    line = _run_bench(ranks, '--frame', 're10k', '--steps', '2', '--warmup', '1')
+    rays = 37 * 41
+    assert line['n_gpus'] == ranks and line['steps'] == 2 and line['scaling'] == 'strong' and line['data'] == 'stand-in'
+    assert line['config']['rays_per_frame'] == rays and line['config']['rays_per_gpu'] == -(-rays // ranks)
+    assert line['value'] == pytest.approx(rays / (line['ms_per_step'] * 1e-3), rel=1e-9)
+    if ranks > 1:
+        assert line['collective'] == {'backend': 'gloo', 'ranks': ranks, 'bytes': -(-rays // ranks) * 28,
+                                      'pattern': 'one gather of the five per-ray outputs to rank 0 per frame'}
 
 
 def test_bench_self_launch_reports_a_failing_rank():

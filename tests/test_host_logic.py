@@ -253,3 +253,61 @@ def test_bench_board_sampler_without_sensors():
         pass
     state = sampler.summary()
     assert state['power_w'] is None and state['sclk_mhz'] is None and state['power_cap_w'] is None
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(REPO, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_line_carries_the_attribution_fields():
+    """The headline line is built from one timed region's raw measurements: `value` is ALL the work over the WHOLE elapsed
+    time (a stalled step is not left out), and the per-step fields make such a stall visible and attributable (round 2's
+    driver run lost 22 ms in a 88-ms region and the line could not say where)."""
+    bench = _bench_module()
+    steps = 20
+    device_ms = [3.27] * steps
+    device_ms[4] = 25.3                      # one stalled step
+    enqueue_ms = [0.4] * steps
+    enqueue_ms[4] = 22.4                     # ... during which the host did not enqueue
+    elapsed = sum(device_ms) * 1e-3
+    launch_ms = [1.07, 2.18] * steps
+    samples = [131072, 262144] * steps
+    line = bench.headline_line(1, steps, 5, 'fp32', elapsed, device_ms, enqueue_ms, launch_ms, samples, dropped=0,
+                               settle_info=(184, 0.61))
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'timing'):
+        assert key in line, key
+    assert line['value'] == pytest.approx(1024 * steps / elapsed) and line['ms_per_step'] == pytest.approx(elapsed / steps * 1e3)
+    timing = line['timing']
+    assert timing['step_ms']['max'] == 25.3 and timing['step_ms']['argmax'] == 4 and timing['step_ms']['p50'] == 3.27
+    assert timing['step_ms']['first'] == 3.27 and timing['enqueue_ms']['max'] == 22.4 and timing['enqueue_ms']['argmax'] == 4
+    assert timing['idle_ms_per_step'] == pytest.approx((elapsed * 1e3 - sum(launch_ms)) / steps)
+    assert timing['step_trace_ms'] == [round(v, 4) for v in device_ms] and timing['settle'] == {'runs': 184, 'seconds': 0.61}
+    roof = line['roofline']
+    assert roof['launches'] == 2 * steps and roof['launches_not_timed'] == 0 and roof['bound'] == 'mfma' and roof['peak'] == 157.3
+    assert roof['achieved'] == pytest.approx(sum(samples) * 2 * 593408 / (sum(launch_ms) * 1e-3) / 1e12)
+    assert roof['kernel_share_of_step'] == pytest.approx(sum(launch_ms) / (elapsed * 1e3))
+    # step-level fraction: every algorithmic FLOP of the K steps over the whole wall time
+    assert roof['step_frac'] == pytest.approx(1024 * steps * 384 * 2 * 593408 / elapsed / 1e12 / 157.3)
+    # long regions keep the quantiles and drop the raw trace
+    long = bench.step_summary(1.0, [3.0] * 300, [0.3] * 300, 900.0)
+    assert 'step_trace_ms' not in long and long['idle_ms_per_step'] == pytest.approx(100.0 / 300)
+
+
+def test_bench_timed_region_protocol_on_the_cpu():
+    """settle() runs for at least the asked time; timed_steps() runs EXACTLY K steps between two fences and returns one
+    device interval and one host interval per step."""
+    import time
+    bench = _bench_module()
+    calls = []
+    runs, spent = bench.settle(lambda: calls.append('s'), 0.05, gpu=False, chunk=4)
+    assert runs == len(calls) and runs % 4 == 0 and spent >= 0.05
+    log = []
+    elapsed, device_ms, enqueue_ms = bench.timed_steps(lambda: (log.append('step'), time.sleep(0.002)), 5, lambda: log.append('fence'), gpu=False)
+    assert log == ['fence'] + ['step'] * 5 + ['fence']      # (the dry marks run before the opening fence)
+    assert len(device_ms) == len(enqueue_ms) == 5 and all(v >= 2.0 for v in device_ms) and elapsed >= 0.01
+    assert sum(device_ms) <= elapsed * 1e3 + 1e-6
