@@ -22,8 +22,6 @@
 //
 // Bound: MFMA (fp32, 256 FLOP/clk/CU).  Algorithmic work 2*MAC of the Linear layers: 1 186 816 FLOP per sample for
 // the 8x256 view-dependent MLP.  HBM traffic per sample: 4 B depth read + 16 B written; weights (2.4 MB) stay in L2.
-#include <cstdlib>
-
 #include "mlp_device.h"
 
 namespace snerf {
@@ -246,11 +244,11 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     snerf::ProfileScope timed(SNERF_PROFILE_MLP_FORWARD, s, a.total);
     if (precision != SNERF_PRECISION_FP32 && !train) {
         // rendering with the fp16 modes: the 16x16x32 MFMA layout where it is built (more work per joule)
-        static const bool m16 = !(getenv("SNERF_M16") && getenv("SNERF_M16")[0] == '0');   // A/B switch for probes
-        if (m16) {
-            const int st16 = snerf::mlp_forward_m16(plan, a, precision == SNERF_PRECISION_F16X3 ? 3 : 1, s);
-            if (st16 != -1) return st16;
-        }
+        // (A/B probes build with -DSNERF_PROBE_NO_M16; no run-time switch decides which kernel renders)
+#ifndef SNERF_PROBE_NO_M16
+        const int st16 = snerf::mlp_forward_m16(plan, a, precision == SNERF_PRECISION_F16X3 ? 3 : 1, s);
+        if (st16 != -1) return st16;
+#endif
     }
     if (precision == SNERF_PRECISION_F16X3) return snerf::mlp_forward_f16x3(plan, a, train, 3, s);
     if (precision == SNERF_PRECISION_F16) {

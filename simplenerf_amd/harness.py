@@ -199,7 +199,7 @@ def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch
     summed -- with ONE model forward/backward over the whole batch instead of one per sub-batch.  The reference cuts the
     batch because of device memory; the renderer treats rays independently, so evaluating them together changes nothing
     but the number of launches and the gradient-accumulation adds (4096 rows: 10.2 -> 9.1 ms in the 16-bit mode).  Only
-    the random draws differ from the sub-batched run (they are keyed by the training call, of which there is now one)."""
+    the rounding of the sums differs from the sub-batched run (the draws are keyed by iteration and global row)."""
     optimizer.zero_grad(set_to_none=True)
     n = input_batch['rays_o'].shape[0]
     sub = int(sub_batch_size or n)
@@ -321,7 +321,8 @@ class GraphedTrainStep:
         for start in range(0, self.n, self.sub):
             count = min(self.sub, self.n - start)
             part = rows[start:start + count] if isinstance(rows, torch.Tensor) else rows + start
-            self.model.draw_training_randomness(count, part, self.device, out={k: v[start:start + count] for k, v in self.draws.items()})
+            self.model.draw_training_randomness(count, part, self.device, out={k: v[start:start + count] for k, v in self.draws.items()},
+                                                iter_num=batch.get('iter_num'))
 
     def _capture(self):
         side = torch.cuda.Stream(device=self.device)
@@ -340,17 +341,27 @@ class GraphedTrainStep:
     def __call__(self, batch: Dict[str, object]) -> Dict[str, Tensor]:
         rows = batch['rays_o'].shape[0]
         if rows != self.n:
-            # a short batch at the end of an epoch (the reference's slicing, DataPreprocessor01.py:559-563): same pass,
-            # launched directly, accumulating into the (zeroed) static gradient buffers so their addresses survive
+            # a short batch at the end of an epoch (the reference's slicing, DataPreprocessor01.py:559-563): the same
+            # sub-batched pass as train_one_iter (ceil(rows / sub) model -> losses -> backward rounds, the sub-batch
+            # totals summed, draws per sub-batch), launched directly, accumulating into the (zeroed) static gradient
+            # buffers so that their addresses survive
             for p in self.model.parameters():
                 if p.grad is not None:
                     p.grad.zero_()
-            self.model.set_random_draws(self.model.draw_training_randomness(rows, self._rows(batch, rows), self.device))
-            piece = dict(batch)
-            piece['common_data'] = dict(batch.get('common_data', {}))
-            losses = self.losses.compute_losses(piece, self.model(piece))
-            losses['TotalLoss'].backward()
-            return {name: (entry['loss_value'] if isinstance(entry, dict) else entry).detach() for name, entry in losses.items()}
+            all_rows = self._rows(batch, rows)
+            totals: Dict[str, Tensor] = {}
+            for start in range(0, rows, self.sub):
+                count = min(self.sub, rows - start)
+                part = all_rows[start:start + count] if isinstance(all_rows, torch.Tensor) else all_rows + start
+                self.model.set_random_draws(self.model.draw_training_randomness(count, part, self.device, iter_num=batch.get('iter_num')))
+                piece = {k: (v[start:start + count] if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+                piece['common_data'] = dict(batch.get('common_data', {}))
+                losses = self.losses.compute_losses(piece, self.model(piece))
+                losses['TotalLoss'].backward()
+                for name, entry in losses.items():
+                    value = (entry['loss_value'] if isinstance(entry, dict) else entry).detach()
+                    totals[name] = totals[name] + value if name in totals else value
+            return totals
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
                 self.static[k].copy_(v)

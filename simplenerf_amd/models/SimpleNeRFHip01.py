@@ -18,9 +18,11 @@ Differences from the reference that a caller can observe:
     results do not depend on chunking;
   * training-mode randomness (stratified jitter, inverse-CDF ``u``, density noise) is drawn on the device by the
     library's counter-based Philox4x32-10 (snerf_random_uniform / snerf_random_normal) instead of on the CPU
-    generator: element (ray, sample) of a draw is a function of (``configs['seed']``, number of training forwards so
-    far, kind of draw, GLOBAL row of the ray, sample) only, so a rank that holds a part of a batch draws what a single
-    process would for those rows.  The global rows come from ``input_batch['global_rows']`` (int64 (n,), emitted by
+    generator: element (ray, sample) of a draw is a function of (``configs['seed']``, training iteration
+    ``input_batch['iter_num']``, kind of draw, GLOBAL row of the ray, sample) only, so a rank that holds a part of a
+    batch -- or a trainer that cuts it into any number of sub-batches -- draws what a single process would for those rows
+    (a batch without ``iter_num`` falls back to the number of training forwards this module has run, which is only
+    shard-invariant when every process makes the same number of calls).  The global rows come from ``input_batch['global_rows']`` (int64 (n,), emitted by
     ``BatchAssembler``; a per-row tensor, because a rank's rows are a pixel-ray shard followed by a sparse-depth shard of
     the global batch and because the reference's trainer slices every tensor of the batch into sub-batches,
     src/Trainer01.py:82-90) or, without it, are ``input_batch.get('row_offset', 0)`` + ray.  ``set_random_draws`` injects
@@ -223,7 +225,7 @@ class SimpleNeRFHip(torch.nn.Module):
         self._packed: Dict[str, tuple] = {}
         self._draws: Optional[dict] = None
         self.seed = int(configs.get('seed', 0))
-        self._train_calls = 0   # training-mode forwards so far: selects the Philox stream of each draw
+        self._train_calls = 0   # training-mode forwards so far: the Philox stream of a batch that carries no 'iter_num'
         # False (default): the backward kernels write / accumulate parameter gradients straight into ``p.grad``;
         # True: they are returned to autograd (torch.autograd.grad, hooks), which then accumulates them itself
         self.return_param_grads = bool(mcfg.get('hip_return_param_grads', False))
@@ -267,12 +269,13 @@ class SimpleNeRFHip(torch.nn.Module):
                         shapes[f'noise_{prefix[:-1]}_fine'] = (n, s_c + s_f, 1)
         return shapes
 
-    def draw_training_randomness(self, n: int, row_offset, device, out: Optional[Dict[str, Tensor]] = None
-                                 ) -> Dict[str, Tensor]:
+    def draw_training_randomness(self, n: int, row_offset, device, out: Optional[Dict[str, Tensor]] = None,
+                                 iter_num: Optional[int] = None) -> Dict[str, Tensor]:
         """The draws the next training-mode forward would make itself, produced up front (and counted as that forward's):
         pass the result to ``set_random_draws``.  ``row_offset``: the first global row (int) or the batch's
-        ``global_rows`` tensor.  ``out`` supplies pre-allocated tensors to fill (static graph inputs)."""
-        call = self._train_calls
+        ``global_rows`` tensor.  ``out`` supplies pre-allocated tensors to fill (static graph inputs).  ``iter_num``: the
+        batch's training iteration (what ``forward`` keys the draws by); None = this module's call counter."""
+        call = self._train_calls if iter_num is None else int(iter_num)
         self._train_calls += 1
         noise_std = float(self.configs['model']['raw_noise_std'])
         first, rows = (0, row_offset) if isinstance(row_offset, torch.Tensor) else (int(row_offset), None)
@@ -331,7 +334,9 @@ class SimpleNeRFHip(torch.nn.Module):
         noise_std = float(mcfg['raw_noise_std'])
         perturb = bool(mcfg['perturb'] > 0.) and training
         first_row, rows = global_rows(batch, n) if training else (0, None)
-        call_index = self._train_calls
+        # the Philox stream: the batch's training iteration (shard- and sub-batch-invariant together with the global
+        # rows); a batch without one falls back to this module's count of training forwards
+        call_index = self._train_calls if batch.get('iter_num') is None else int(batch['iter_num'])
         if training and injected is None:
             self._train_calls += 1
 

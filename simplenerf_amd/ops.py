@@ -321,6 +321,7 @@ class RenderCall:
             r.sigma_noise[l] = put('sigma_noise', None if noise is None else noise.reshape(n, self.samples(l)), (n, self.samples(l)))
         override = draws.get('z_vals_fine') if self.num_fine else None
         r.depths_fine = put('z_vals_fine', override, (n, self.num_coarse + self.num_fine))
+        fine_in = held[-1]        # the validated (contiguous fp32) override, or None: returned as z_vals_fine below
         # predict_visibility: secondary camera centres (n, K, 3), K = num_frames - 1 (sec_views_vis)
         rays_o2 = rays.get('rays_o2') if any(self.mlps[l].desc.predict_visibility for l in self.levels) else None
         k_other = 0 if rays_o2 is None else int(rays_o2.shape[1])
@@ -355,7 +356,7 @@ class RenderCall:
         o.depths_coarse = z_coarse.data_ptr()
         z_fine = None
         if self.num_fine:
-            z_fine = held[-1] if override is not None else carve('big', 'z', (n, self.num_coarse + self.num_fine))
+            z_fine = fine_in if override is not None else carve('big', 'z', (n, self.num_coarse + self.num_fine))
             o.depths_fine = 0 if override is not None else z_fine.data_ptr()
         out: Dict[int, Dict[str, Tensor]] = {}
         for l in range(_lib.RENDER_LEVELS):

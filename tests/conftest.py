@@ -15,3 +15,12 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Observed parity figures next to their gates (tests/util.observe), printed whatever the verbosity."""
+    from tests import util
+    if util.OBSERVED:
+        terminalreporter.write_sep('-', 'observed parity figures (gate in brackets)')
+        for tag, text in util.OBSERVED:
+            terminalreporter.write_line(f'{tag}: {text}')

@@ -175,5 +175,20 @@ def test_two_rank_assembler_batches_draw_what_a_single_process_draws():
         cut = {k: (v[40:100] if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
         part = whole_model(cut)
     assert torch.equal(part['z_vals_coarse'], ref['z_vals_coarse'][40:100]) and torch.equal(part['raw_sigma_fine'], ref['raw_sigma_fine'][40:100])
-    u = ops.random_uniform(9, 4, 0, (128, 5), DEV, rows=batch['global_rows'].flip(0))
+    # ... whatever the NUMBER of cuts: the draws are keyed by (seed, iteration, kind, global row), not by how many forwards
+    # a process has run -- two ranks that each make ONE call draw what a single process draws in TWO sub-batch calls
+    # (with a per-process call counter rows 64.. of the second sub-batch came from another stream)
+    for h in halves:
+        h.get_next_batch(2)                 # (the assemblers are cursors over one index stream: keep the ranks in step)
+    batch = one.get_next_batch(3)
+    parts = [h.get_next_batch(3) for h in halves]
+    with torch.no_grad():
+        subs = [whole_model({k: (v[lo:lo + 64] if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}) for lo in (0, 64)]
+        outs = [m(p) for m, p in zip(rank_models, parts)]
+    rows = torch.cat([p['global_rows'] for p in parts])
+    # (this batch happens to be a SHORT one -- the sparse-depth candidates run out: 96 + 23 rows -- so the cut is 64 + 55)
+    assert torch.equal(torch.sort(rows)[0], batch['global_rows']) and batch['global_rows'].shape[0] > 64
+    for k in keys:
+        assert torch.equal(torch.cat([o[k] for o in outs])[torch.argsort(rows)], torch.cat([o[k] for o in subs])), k
+    u = ops.random_uniform(9, 4, 0, (128, 5), DEV, rows=torch.arange(128, device=DEV).flip(0))
     assert torch.equal(u.flip(0), ops.random_uniform(9, 4, 0, (128, 5), DEV))

@@ -5,9 +5,15 @@ reference's own call signature ``model(input_batch[, retraw])``.
 What is gated how:
   * coarse-pass outputs and both augmented models (which run on the coarse samples): every ray, every profile;
   * fine-pass outputs of the 'consistent' profile (fine MLP = coarse MLP, i.e. both passes see one geometry, as in
-    a trained model): every ray;
-  * fine-pass outputs when coarse and fine MLPs are two INDEPENDENT random fields ('plain', 'dense'): at most 5 %
-    of rays may exceed the bound.  Cause: the reference's sample_pdf replaces ``denom < 1e-5`` by 1
+    a trained model): every ray in the fp32 mode.  In the f16x3 mode (whose coarse weights differ from the fp32 kernel's
+    in the last bits: another accumulation order) a ray whose resampled fine depth ITSELF moved is exempt -- which rays
+    sit on sample_pdf's threshold depends on the rounding, not on correctness -- and every other ray is gated;
+  * fine-pass outputs when coarse and fine MLPs are two INDEPENDENT random fields: at most 2 % of rays may exceed the
+    bound for the 'plain' fields and 5 % for the 'dense' ones (density head boosted until the frame is opaque -- the
+    adversarial case: measured 4.5 % of 4096 fern rays against the oracle on the same host, 0.1 % on the RE10K camera), AND
+    every such ray must be one whose resampled depths moved: rays whose fine depths agree with the reference's are gated
+    at the full tolerance (<= 0.1 % of them may exceed it: a sample that moves by less than the 1e-5 "moved" threshold
+    inside a density spike).  The observed fractions are printed in pytest's summary (util.observe).  Cause: the reference's sample_pdf replaces ``denom < 1e-5`` by 1
     (src/models/SimpleNeRF01.py:357) and the pdf of an EMPTY coarse bin is 0.9994e-5 -- within half an ulp of the
     running fp32 cumsum of that threshold -- so which empty bins collapse to their left edge is decided by the last
     bit of the reference's own sequential cumsum (SURVEY 8a row 8 measured 0.26 % of samples moving a full bin
@@ -20,7 +26,8 @@ What is gated how:
     intervention test, which feeds the reference's own fine depths to the kernels;
   * world-space depth/depth_var of NDC scenes multiply every weight by 1/(1 - z) (up to 1e3): one low-weight far
     sample that moves shifts them past 1e-3 on a few rays even with consistent geometry, so for the fine pass they
-    are gated outlier-tolerantly (<= 5 % of rays) while depth_ndc / depth_var_ndc are gated on every ray;
+    are gated outlier-tolerantly (<= 5 % of rays; observed up to 4 rays of 128) while depth_ndc / depth_var_ndc are gated
+    like the colour;
   * depth = sum(w z)/(acc + 1e-6) is only gated on rays with acc > 1e-2: for an almost-empty ray the reference's own
     alpha = 1 - exp(-1e-5) has ~1e-3 relative rounding noise.
 """
@@ -37,7 +44,10 @@ from tests.test_gpu_kernels import abi_param_list
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 RGB_TOL, DEPTH_TOL = 1e-4, 1e-3
-MAX_OUTLIER_RAYS = 0.05
+MAX_OUTLIER_RAYS = 0.02          # fine colour / acc / NDC depth over tolerance; observed <= 0.8 % ('plain', 'consistent')
+MAX_OUTLIER_RAYS_DENSE = 0.05    # ... for two independent OPAQUE random fields ('dense'); observed 4.5 % (config 2, 4096 rays)
+MAX_OUTLIER_RAYS_WORLD = 0.05    # world-space depth / depth_var of NDC scenes (weights x 1/(1-z) <= 1e3); observed <= 3.1 %
+MAX_UNMOVED_OVER = 0.001         # ... of which on rays whose fine depths agree with the reference's to 1e-5; observed <= 1/4096
 
 
 def build(configs, golden, precision='fp32'):
@@ -71,7 +81,7 @@ def per_ray_violation(key, got, ref, acc_ref):
     return None  # z_vals_*: checked separately
 
 
-def check_outputs(out, ref, strict_fine, tag=''):
+def check_outputs(out, ref, strict_fine, tag='', precision='fp32', dense=False):
     assert sorted(out.keys()) == sorted(ref.keys()), sorted(set(out) ^ set(ref))
     for k, v in ref.items():
         assert tuple(out[k].shape) == tuple(v.shape), k
@@ -81,6 +91,7 @@ def check_outputs(out, ref, strict_fine, tag=''):
     if 'z_vals_fine' in ref:
         zr = ref['z_vals_fine']
         moved_rays = (numpy.abs(out['z_vals_fine'].cpu().numpy() - zr) > 1e-5 * float(numpy.abs(zr).max())).any(1)
+    worst_key, worst_frac, strict_bad = '', 0.0, 0
     for k, v in ref.items():
         level = 'fine' if k.endswith('_fine') else 'coarse'
         acc_key = next(c for c in (f'{p}acc_{level}' for p in ('points_augmentation_', 'views_augmentation_', ''))
@@ -89,26 +100,40 @@ def check_outputs(out, ref, strict_fine, tag=''):
         if bad is None:
             continue
         per_sample = v.ndim >= 2 and v.shape[1] > 3
-        world_depth = k in ('depth_fine', 'depth_var_fine')
+        world_depth = k.replace('points_augmentation_', '').replace('views_augmentation_', '') in ('depth_fine', 'depth_var_fine')
         if level == 'coarse':
             assert not bad.any(), (tag, k, int(bad.sum()), util.linf(out[k], v))
         elif per_sample:
             continue  # not index-aligned unless the fine depths are bit-identical: see test_fine_pass_on_reference_samples
         elif strict_fine and not world_depth:
-            # every ray within tolerance, except rays on which a resampled fine depth itself moved: sample_pdf's
-            # `denom < 1e-5` branch (src/models/SimpleNeRF01.py:357) flips on a last-bit difference of the coarse weights
-            # (DESIGN 4), and which rays sit on it depends on the kernel's rounding, not on its correctness -- with the
-            # reference's fine depths pinned these rays agree to 1e-7 (test_fine_pass_on_reference_samples)
-            assert not (bad & ~moved_rays).any(), (tag, k, int((bad & ~moved_rays).sum()), util.linf(out[k], v))
-            assert bad.mean() <= MAX_OUTLIER_RAYS, (tag, k, float(bad.mean()))
+            if precision == 'f16x3':
+                # every ray within tolerance, except rays on which a resampled fine depth itself moved: sample_pdf's
+                # `denom < 1e-5` branch (src/models/SimpleNeRF01.py:357) flips on a last-bit difference of the coarse
+                # weights, and the 16x16x32 kernel accumulates in another order than the fp32 one -- with the
+                # reference's fine depths pinned these rays agree to 1e-7 (test_fine_pass_on_reference_samples)
+                assert not (bad & ~moved_rays).any(), (tag, k, int((bad & ~moved_rays).sum()), util.linf(out[k], v))
+                assert bad.mean() <= MAX_OUTLIER_RAYS, (tag, k, float(bad.mean()))
+            else:
+                assert not bad.any(), (tag, k, int(bad.sum()), util.linf(out[k], v))       # fp32: every ray
+            strict_bad = max(strict_bad, int(bad.sum()))
         else:
-            assert bad.mean() <= MAX_OUTLIER_RAYS, (tag, k, float(bad.mean()))
+            bound = MAX_OUTLIER_RAYS_WORLD if world_depth else (MAX_OUTLIER_RAYS_DENSE if dense else MAX_OUTLIER_RAYS)
+            assert bad.mean() <= bound, (tag, k, float(bad.mean()))
+            # ... and the outliers are rays whose resampled depths moved, not rays the kernels got wrong
+            assert (bad & ~moved_rays).mean() <= MAX_UNMOVED_OVER, (tag, k, int((bad & ~moved_rays).sum()))
+            if float(bad.mean()) > worst_frac:
+                worst_key, worst_frac = k, float(bad.mean())
     assert util.linf(out['z_vals_coarse'], ref['z_vals_coarse']) == 0.0
     if 'z_vals_fine' in ref:
         zr = ref['z_vals_fine']
-        assert util.outlier_fraction(out['z_vals_fine'], zr, 1e-5 * float(numpy.abs(zr).max())) < 0.01
+        moved = util.outlier_fraction(out['z_vals_fine'], zr, 1e-5 * float(numpy.abs(zr).max()))
+        assert moved < 0.01
         z = out['z_vals_fine']
         assert torch.all(z[:, 1:] >= z[:, :-1])
+        n = zr.shape[0]
+        util.observe(tag, f'fine depths moved {moved:.5f} of samples [0.01], rays with a moved depth {int(moved_rays.sum())}/{n}; '
+                          + (f'strict fine gate: {strict_bad} rays over tolerance [{"only moved rays" if precision == "f16x3" else "0"}]'
+                             if strict_fine else f'rays over tolerance, worst fine key {worst_key or "-"}: {worst_frac:.4f} [{MAX_OUTLIER_RAYS_DENSE if dense else MAX_OUTLIER_RAYS}; world depth {MAX_OUTLIER_RAYS_WORLD}]'))
 
 
 EVAL_CASES = [(k, p) for k in ('config1', 'config2', 'headline', 'headline_world') for p in ('plain', 'dense', 'consistent')
@@ -127,7 +152,8 @@ def test_eval_forward_matches_reference(kind, profile, precision):
         out = model(batch, retraw=True)
         plain = model(batch)
     ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
-    check_outputs(out, ref, strict_fine=(profile == 'consistent'), tag=f'{kind}/{profile}/{precision}')
+    check_outputs(out, ref, strict_fine=(profile == 'consistent'), tag=f'{kind}/{profile}/{precision}', precision=precision,
+                  dense=(profile == 'dense'))
     assert sorted(plain.keys()) == sorted(g['eval_keys'].tolist())
     assert all(torch.equal(plain[k], out[k]) for k in plain)
     assert list(batch.keys()) == list(before.keys()) and all(torch.equal(batch[k], before[k]) for k in batch)
@@ -151,7 +177,7 @@ def test_train_forward_matches_reference(variant, profile):
     with torch.no_grad():
         out = model(batch)
     ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
-    check_outputs(out, ref, strict_fine=(profile == 'consistent'), tag=f'train/{variant}/{profile}')
+    check_outputs(out, ref, strict_fine=(profile == 'consistent'), tag=f'train/{variant}/{profile}', dense=(profile == 'dense'))
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
@@ -167,7 +193,7 @@ def test_train_forward_with_fine_augmentation_mlps_matches_reference(precision):
     # the main fine model shares the coarse weights ('consistent'), but the fine AUGMENTATION fields are independent
     # random MLPs: a resampled depth that sits in another bin than the reference's (sample_pdf discontinuity, DESIGN.md
     # section 4) can land in their dense geometry, so fine-level outputs are gated per ray with the outlier allowance
-    check_outputs(out, ref, strict_fine=False, tag=f'train/config3f/{precision}')
+    check_outputs(out, ref, strict_fine=False, tag=f'train/config3f/{precision}', precision=precision, dense=True)
 
 
 @pytest.mark.parametrize('kind,profile', [('config2', 'dense'), ('headline', 'dense'), ('headline_world', 'dense'),
@@ -409,6 +435,52 @@ def test_config4_re10k_full_frame_properties_and_eight_way_shards(resolution):
     assert numpy.array_equal(frame['image'].reshape(-1, 3), ref_img) and numpy.array_equal(frame['depth'].reshape(-1), ref_depth)
 
 
+_ORACLE_SLICES = {}
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
+@pytest.mark.parametrize('kind,profile', [('config2', 'dense'), ('config2', 'consistent'), ('config4', 'dense'), ('config4', 'consistent')])
+def test_frame_slice_against_the_oracle_on_this_host(kind, profile, precision):
+    """A 4096-ray slice out of the middle of the BASELINE config 2 (fern 1008x756) and config 4 (RE10K camera at 1008x756)
+    frames, rays generated on the device, against the oracle evaluated on THIS box's CPU (no fixture: 40x more rays than the
+    goldens hold).  Gates: coarse outputs on every ray; fine colour / acc / NDC depth on all but <= 5 % of rays for the two
+    independent opaque fields ('dense'; observed 4.5 % on the fern rays, 0.1 % on the RE10K ones) and <= 2 % with consistent
+    geometry (observed 0.1 %), and in every case on (all but 0.1 % of) the rays whose resampled depths did not move -- the
+    outliers are sample_pdf's threshold, not the kernels.  The observed fractions are printed in the summary for
+    both parity precisions."""
+    from simplenerf_amd import harness
+    g = util.load(f'e2e_{kind}_{profile}.npz')
+    cfg = synth.make_configs(kind)
+    cam = synth.camera('fern', 0) if kind == 'config2' else synth.camera('re10k', 0, resolution=(756, 1008))
+    h, w = cam['resolution']
+    first, count = (h // 2) * w + 37, 4096
+    model = build(cfg, g, precision).eval()
+    batch = harness.frame_batch(cam, True, DEV, first, count)
+    with torch.no_grad():
+        out = model(batch, retraw=True)
+    if (kind, profile) not in _ORACLE_SLICES:
+        params = util.golden_params(cfg, g)
+        with torch.no_grad():
+            _ORACLE_SLICES[(kind, profile)] = oracle.render(params, cfg, {k: v.cpu() for k, v in batch.items()}, training=False, retraw=True)
+    ref = {k: v.numpy() for k, v in _ORACLE_SLICES[(kind, profile)].items()}
+    assert float(ref['acc_fine'].mean()) > 0.05, 'the slice must not be empty space'
+    acc = {lvl: ref[f'acc_{lvl}'].astype(numpy.float64) for lvl in ('coarse', 'fine')}
+    for k in ('rgb_coarse', 'acc_coarse', 'depth_ndc_coarse', 'alpha_coarse', 'weights_coarse'):
+        bad = per_ray_violation(k, out[k], ref[k], acc['coarse'])
+        assert not bad.any(), (k, int(bad.sum()), util.linf(out[k], ref[k]))
+    zr = ref['z_vals_fine']
+    moved_rays = (numpy.abs(out['z_vals_fine'].cpu().numpy() - zr) > 1e-5).any(1)
+    over = numpy.zeros(count, dtype=bool)
+    for k in ('rgb_fine', 'acc_fine', 'depth_ndc_fine'):
+        over |= per_ray_violation(k, out[k], ref[k], acc['fine'])
+    bound = MAX_OUTLIER_RAYS_DENSE if profile == 'dense' else MAX_OUTLIER_RAYS
+    util.observe(f'slice/{kind}/{profile}/{precision}', f'rays_over_tol / rays = {int(over.sum())}/{count} = {over.mean():.5f} '
+                 f'[{bound}], of them on rays whose fine depths did not move: {int((over & ~moved_rays).sum())} '
+                 f'[{"0" if profile == "consistent" else int(MAX_UNMOVED_OVER * count)}]; rays with a moved fine depth {int(moved_rays.sum())}')
+    assert over.mean() <= bound, float(over.mean())
+    assert (over & ~moved_rays).sum() <= (0 if profile == 'consistent' else MAX_UNMOVED_OVER * count), int((over & ~moved_rays).sum())
+
+
 def oracle_display(rgb, depth):
     from oracle import raygen_oracle
     return raygen_oracle.to_display(rgb, depth)
@@ -457,6 +529,9 @@ def test_predicted_visibility_matches_reference(case):
             plain = model(dev_batch, sec_views_vis=True)
         for k in ('raw_visibility_fine', 'raw_visibility2_fine', 'visibility2_fine'):
             assert util.linf(pinned[k], ref[k]) <= RGB_TOL, (k, util.linf(pinned[k], ref[k]))
+        # the injected fine depths come back as z_vals_fine (with secondary views the model returned rays_o2 here)
+        assert tuple(pinned['z_vals_fine'].shape) == tuple(ref['z_vals_fine'].shape)
+        assert util.linf(pinned['z_vals_fine'], ref['z_vals_fine']) == 0.0
         assert sorted(blind.keys()) == sorted(g['blind_keys'].tolist())
         assert sorted(plain.keys()) == sorted(g['eval_keys'].tolist())
     else:

@@ -169,6 +169,21 @@ def test_graphed_sub_batched_iteration_equals_the_eager_trainer_iteration(precis
         assert float(got['TotalLoss']) == float(ref['TotalLoss']), it
     for (name, a), b in zip(eager.named_parameters(), graphed.parameters()):
         assert torch.equal(a, b), name
+    # a SHORT batch (end of an epoch; 200 of 256 rows = sub-batches of 128 + 72) takes the same sub-batched pass without the
+    # graph: two model -> losses -> backward rounds whose totals are summed, one draw set per sub-batch (it used
+    # to run as one whole-batch pass -- another objective scale and other draws from then on)
+    cut = lambda b: {k: (v[:200] if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    ref = harness.train_one_iter(eager, losses, opt_e, cut(batch_e.get_next_batch(20003)), 128)
+    got = step(cut(batch_g.get_next_batch(20003)))
+    opt_g.step()
+    assert float(got['TotalLoss']) == float(ref['TotalLoss'])
+    assert sorted(got) == sorted(ref) and all(float(got[k]) == float(ref[k]) for k in ref)
+    ref = harness.train_one_iter(eager, losses, opt_e, batch_e.get_next_batch(20004), 128)      # and the replays go on exactly
+    got = step(batch_g.get_next_batch(20004))
+    opt_g.step()
+    assert float(got['TotalLoss']) == float(ref['TotalLoss'])
+    for (name, a), b in zip(eager.named_parameters(), graphed.parameters()):
+        assert torch.equal(a, b), name
 
 
 @pytest.mark.parametrize('precision', ['f16x3', 'f16'])

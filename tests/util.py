@@ -81,6 +81,15 @@ def golden_batch(golden: dict) -> dict:
     return {k[3:]: torch.from_numpy(v) for k, v in golden.items() if k.startswith('in_')}
 
 
+# observed parity figures of the GPU tests, printed in pytest's terminal summary (tests/conftest.py) so that the test
+# record shows how far the gates are from what was measured: [(tag, text)]
+OBSERVED = []
+
+
+def observe(tag: str, text: str) -> None:
+    OBSERVED.append((tag, text))
+
+
 def linf(a, b):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else numpy.asarray(a)
     b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else numpy.asarray(b)
