@@ -25,7 +25,9 @@ enum snerf_status {
     SNERF_OK = 0,
     SNERF_E_INVALID = -1,     /* bad argument (null pointer, non-positive size, ...) */
     SNERF_E_UNSUPPORTED = -2, /* configuration outside what the kernels are built for */
-    SNERF_E_HIP = -3          /* HIP runtime error (message carries hipGetErrorString) */
+    SNERF_E_HIP = -3,         /* HIP runtime error (message carries hipGetErrorString) */
+    SNERF_E_RANGE = -4        /* an EARLIER fp16-mode launch on this device met a value outside the fp16 range (see
+                                 snerf_range_status): its results are wrong; reported once by the next fp16-mode call */
 };
 
 /* ABI version of this header; bumped on any signature change (new enum values such as SNERF_PRECISION_F16 extend a
@@ -104,9 +106,22 @@ enum snerf_precision {
                                   agree with the fp32 path to ~1e-3 (tests/test_gpu_f16.py states the tolerances) */
 };
 /* Range: both fp16 modes hold hidden activations and weights as fp16 numbers (pairs), so their magnitudes must stay
- * below 65504 -- far above what a NeRF MLP on encoded inputs produces (trained hidden units are O(1..100)); beyond it
- * the affected samples come out non-finite.  Gradients have no such limit (renormalised by powers of two).  The fp32
- * mode has the full fp32 range. */
+ * below 65504 -- far above what a NeRF MLP on encoded inputs produces (trained hidden units are O(1..100)).  Exceeding it
+ * is DETECTED, not silent: an operand beyond the range converts to +-inf, which makes every pre-activation of the next layer
+ * non-finite for that sample, so every fp16-mode forward kernel checks one pre-activation per sample and layer before its
+ * ReLU could mask it (one instruction per layer; csrc/mlp_device_f16.h, RangeWatch), and snerf_mlp_pack checks the weights;
+ * a launch that met a non-finite operand raises a per-device flag in pinned host memory when it finishes.  Launches are asynchronous, so the
+ * flag is reported like an asynchronous HIP error: the NEXT fp16-mode call on that device (snerf_mlp_forward[_train],
+ * snerf_mlp_backward, the render ops) fails with SNERF_E_RANGE before enqueuing anything and clears it; after a
+ * synchronisation snerf_range_status tells at once.  Outputs of a flagged launch must be discarded (an overflowed unit can
+ * be masked by a later ReLU, so they may look finite).  Gradients have no such limit (renormalised by powers of two).  The
+ * fp32 mode has the full fp32 range and never raises the flag.
+ *   snerf_range_status(clear)   bit 0: an activation / encoded input left the fp16 range; bit 1: a weight did (set by
+ *                               snerf_mlp_pack, which cannot know the precision it packs for: only fp16-mode calls report it);
+ *                               0 = clean; < 0 = error.  `clear` != 0 resets the flag of the current device.
+ * The first fp16-mode call (or snerf_mlp_pack) of a process allocates the 256-byte flag table with hipHostMalloc: make it
+ * outside of a graph capture. */
+int snerf_range_status(int clear);
 
 /*   origins, dirs   device (num_rays,3): the rays the depths are measured along (NDC rays when ndc)
  *   view_dirs       device (num_rays,3) or NULL when !use_view_dirs

@@ -108,6 +108,7 @@ SIGNATURES = {
     'snerf_profile_collect': (c_int, [c_int, POINTER(c_float), POINTER(c_longlong), c_int]),
     'snerf_profile_reset': (c_int, []),
     'snerf_profile_dropped': (c_longlong, []),
+    'snerf_range_status': (c_int, [c_int]),
     'snerf_render_workspace_floats': (c_size_t, [POINTER(RenderConfig), c_longlong]),
     'snerf_render_forward': (c_int, [POINTER(RenderConfig), POINTER(RenderMlp), POINTER(RenderRays), c_longlong,
                                      POINTER(RenderOutputs), _FP, c_void_p]),
@@ -166,7 +167,15 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+class Fp16RangeError(RuntimeError):
+    """SNERF_E_RANGE: an earlier fp16-mode launch on this device met an activation, encoded input or weight outside the fp16
+    range (|v| > 65504); its outputs are invalid.  Reported once, by the next fp16-mode call (include/simplenerf_hip.h)."""
+
+
 def check(status: int, what: str) -> None:
+    if status == -4:
+        msg = load().snerf_last_error()
+        raise Fp16RangeError(msg.decode() if msg else f'{what}: fp16 range exceeded')
     if status != 0:
         msg = load().snerf_last_error()
         raise RuntimeError(f'{what} failed ({status}): {msg.decode() if msg else "unknown error"}')

@@ -99,3 +99,53 @@ extern "C" long long snerf_profile_dropped(void) {
     std::lock_guard<std::mutex> lock(snerf::g_profile_mutex);
     return snerf::g_profile_dropped;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp16 range flag: one int per device ordinal in pinned (host-coherent, device-mapped) memory.  Kernels store to it with a
+// system-scope atomic when they met a non-finite fp16 operand; the host reads it without synchronising.
+namespace snerf {
+namespace {
+std::mutex g_range_mutex;
+int* g_range_table = nullptr;      // 64 ints
+constexpr int kRangeDevices = 64;
+}  // namespace
+
+int* range_flag() {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kRangeDevices) {
+        (void)fail(SNERF_E_HIP, "range flag: no current HIP device (or ordinal >= %d)", kRangeDevices);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_range_mutex);
+    if (!g_range_table) {
+        void* p = nullptr;
+        const hipError_t e = hipHostMalloc(&p, kRangeDevices * sizeof(int), hipHostMallocPortable | hipHostMallocMapped);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)fail(SNERF_E_HIP, "range flag: hipHostMalloc: %s (the first fp16-mode call of a process must not be inside "
+                                    "a graph capture)", hipGetErrorString(e));
+            return nullptr;
+        }
+        g_range_table = static_cast<int*>(p);
+        for (int i = 0; i < kRangeDevices; ++i) g_range_table[i] = 0;
+    }
+    return g_range_table + device;
+}
+
+int report_range(const char* what) {
+    int* flag = range_flag();
+    if (!flag) return SNERF_E_HIP;
+    const int bits = __atomic_exchange_n(flag, 0, __ATOMIC_ACQ_REL);
+    if (bits == 0) return SNERF_OK;
+    return fail(SNERF_E_RANGE, "%s: an earlier fp16-mode launch on this device met %s%s%s outside the fp16 range (|v| > 65504): "
+                               "its results are invalid -- use hip_precision 'fp32' for this model", what,
+                (bits & kRangeActivation) ? "a hidden activation or encoded input" : "", (bits & kRangeActivation) && (bits & kRangeWeight) ? " and " : "",
+                (bits & kRangeWeight) ? "a weight" : "");
+}
+}  // namespace snerf
+
+extern "C" int snerf_range_status(int clear) {
+    int* flag = snerf::range_flag();
+    if (!flag) return SNERF_E_HIP;
+    return clear ? __atomic_exchange_n(flag, 0, __ATOMIC_ACQ_REL) : __atomic_load_n(flag, __ATOMIC_ACQUIRE);
+}

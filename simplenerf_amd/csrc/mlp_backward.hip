@@ -951,6 +951,10 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3 && precision != SNERF_PRECISION_F16)
         return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: precision %d not built", precision);
     const bool f16 = precision == SNERF_PRECISION_F16;   // saved_acts must come from forward_train at the same precision
+    if (precision != SNERF_PRECISION_FP32) {   // the forward that saved these activations may have left the fp16 range
+        const int range = snerf::report_range("mlp_backward");
+        if (range != SNERF_OK) return range;
+    }
     const long long total = num_rays * num_samples;
     if ((total + 127) / 128 > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many samples");
     hipStream_t s = (hipStream_t)stream;

@@ -30,6 +30,7 @@ struct MlpArgs {
     const float* view_dirs2;  // (total, num_other, 3) or NULL
     float* visibility2;       // (total, num_other)
     int num_other;
+    int* range_flag;          // fp16 modes: pinned host word, OR-ed with kRangeActivation when an operand left the fp16 range
 };
 
 // Arguments of the backward chain kernels (fp32: mlp_backward.hip, f16x3: mlp_backward_f16.hip)

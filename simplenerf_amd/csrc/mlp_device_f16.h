@@ -143,6 +143,32 @@ struct UnitStreamT {
 };
 using UnitStream = UnitStreamT<3>;
 
+// fp16 range watch (include/simplenerf_hip.h, "Range").  An activation (or encoded input) beyond 65504 converts to +-inf
+// (v_cvt_pk_f16_f32 rounds to nearest), and an infinite operand k makes EVERY pre-activation of the next layer non-finite
+// for that sample: y_j = sum_k w_jk x_k holds inf . w_jk = +-inf, or NaN where w_jk == 0, for every unit j.  So it is enough
+// to look at ONE pre-activation per sample and layer, before its ReLU can mask it: `probe` keeps a NaN-propagating maximum
+// of their magnitudes (v_maximum3_f32 with |x| modifiers: one instruction per layer and sample slot, where watching every
+// converted operand cost 32-64 and 2-5 % of the kernel).  Conversions nothing downstream multiplies (the views layer's
+// activations, which only the training forward converts -- to save them) are watched directly with `see`.
+// `report` runs once per wave at the end of the kernel: a non-finite probe ORs kRangeActivation into the device's pinned
+// host word (system-scope atomic, executed by offending lanes only).
+struct RangeWatch {
+    float worst = 0.0f;
+    __device__ __forceinline__ void probe(float pre_activation) {
+        worst = __builtin_elementwise_maximum(worst, __builtin_fabsf(pre_activation));
+        asm volatile("" : "+v"(worst));   // evaluated here, not sunk to the end of the kernel with its operand kept alive
+    }
+    __device__ __forceinline__ void see(const f16x8& converted) {
+        float m = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m = __builtin_elementwise_maximum(m, __builtin_fabsf((float)converted[i]));
+        probe(m);
+    }
+    __device__ __forceinline__ void report(int* flag) const {
+        if (!(worst <= 3.0e38f) && flag) __hip_atomic_fetch_or(flag, snerf::kRangeActivation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+};
+
 // Converts accumulator registers (2i, 2i+1) of a finished tile -- ReLU optional -- into the fp16 hi/lo pair they form
 // in the next layer's operand: registers 8s..8s+7 are the 8 elements of k-step s.
 template <bool RELU>

@@ -143,6 +143,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
     // AGPRs and every MFMA then paid v_accvgpr_read moves -- slower overall.)
     f32x16 acc[WT];
     unsigned mask_bits = 0;
+    RangeWatch watch;   // one pre-activation per layer for this lane's sample (mlp_device_f16.h)
     auto heads_from = [&](const f32x16& t, int u) {
         head[0] += tile_dot_relu(t, wout + 32 * u, half);
         if (!VIEWDEP) {
@@ -157,6 +158,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         const float* unit = next_unit();
         tile_bias(acc[u], bias + 32 * u, half);
         seg_product<P, 4>(acc[u], unit, 4, pe_h, pe_l, st);
+        if (u == 0) watch.probe(acc[0][0]);       // non-finite iff an encoded input left the fp16 range
         if (single) heads_from(acc[u], u);
         if (STORE32) { store_tile_rows<true>(acc[u], tile + (a.act_h1 + 32 * u) * 32, lane); st.note_vmem(16); }
         if (STORE16) { relu_mask_tile(acc[u], u, mask_bits, masks, 0, lane); st.note_vmem(u & 1); }
@@ -180,6 +182,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
             const int unit_ks = l == 5 ? 4 + HK : HK;
             if (l == 5) seg_product<P, 4>(acc[u], unit, unit_ks, pe_h, pe_l, st);  // skip connection [encoding | h]
             seg_product<P, HK>(acc[u], unit, unit_ks, xh, xl, st);
+            if (u == 0) watch.probe(acc[0][0]);   // non-finite iff an activation of layer l-1 left the fp16 range
             if (last) heads_from(acc[u], u);
             if (STORE32) { store_tile_rows<true>(acc[u], tile + (a.act_h1 + l * a.width + 32 * u) * 32, lane); st.note_vmem(16); }
             if (STORE16) { relu_mask_tile(acc[u], u, mask_bits, masks, l * WT, lane); st.note_vmem(u & 1); }
@@ -214,6 +217,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
             const float* unit = next_unit();
             tile_bias(acc[u], bf + 32 * u, half);
             seg_product<P, HK>(acc[u], unit, HK, xh, xl, st);
+            if (u == 0) watch.probe(acc[0][0]);
             if (STORE32) { store_tile_rows<false>(acc[u], tile + (a.act_feature + 32 * u) * 32, lane); st.note_vmem(16); }
         }
 #pragma unroll
@@ -234,10 +238,12 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
             seg_product<P, HK>(acc[u], unit, kViewsKs, xh, xl, st);
             if (SIGMA_PE) seg_product<P, 4>(acc[u], unit, kViewsKs, pe_h, pe_l, st);
             seg_product<P, 2>(acc[u], unit, kViewsKs, pev_h, pev_l, st);
+            if (u == 0) watch.probe(acc[0][0]);   // the feature vector and the view encoding
             if (STORE32) { store_tile_rows<true>(acc[u], tile + (a.act_hv + 32 * u) * 32, lane); st.note_vmem(16); }
             if (STORE16) {
                 f16x8 vh[2], vl[2];
                 split_tile<true>(acc[u], vh[0], vl[0], vh[1], vl[1]);
+                watch.see(vh[0]); watch.see(vh[1]);      // saved for the weight gradients only: nothing downstream multiplies them
                 store_pieces<2>(vh, tile16 + (a.act_hv + 32 * u) * 32, lane);
                 relu_mask_tile(acc[u], u, mask_bits, masks, depth * WT, lane);
                 st.note_vmem(2 + (u & 1));
@@ -250,6 +256,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoidf((col[c] + __shfl_xor(col[c], 32, 64)) + bo[c]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    watch.report(a.range_flag);
     if (live && half == 0) {
         a.sigma[first] = sigma;
         a.rgb[first * 3 + 0] = rgb[0];

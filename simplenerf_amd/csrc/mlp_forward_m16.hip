@@ -270,6 +270,8 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
     f16x8 xh[HB][2], xl[HB][2];
     Tile16 acc[WT];
     float head[2] = {0.0f, 0.0f};
+    RangeWatch watch;   // one pre-activation per layer for each of this lane's two samples (mlp_device_f16.h)
+    auto probe_tile = [&](const Tile16& t) __attribute__((always_inline)) { watch.probe(t[0][0][0]); watch.probe(t[0][1][0]); };
 
     // ---- trunk layer 0: encoding -> h ---------------------------------------------------------------------------------
 #pragma unroll
@@ -277,6 +279,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         const float* unit = next_unit();
         tile_bias16(acc[u], bias + 32 * u, grp);
         seg_m16<P, 2>(acc[u], unit, 4, pe_h, pe_l, st);
+        if (u == 0) probe_tile(acc[0]);           // non-finite iff an encoded input left the fp16 range
     }
 #pragma unroll
     for (int u = 0; u < WT; ++u) tile_to_operand16<true, P>(acc[u], xh[u], xl[u]);
@@ -291,6 +294,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
             const int unit_ks = l == 5 ? 4 + 2 * HB : 2 * HB;
             if (l == 5) seg_m16<P, 2>(acc[u], unit, unit_ks, pe_h, pe_l, st);   // skip connection [encoding | h]
             seg_m16<P, HB>(acc[u], unit, unit_ks, xh, xl, st);
+            if (u == 0) probe_tile(acc[0]);       // non-finite iff an activation of layer l-1 left the fp16 range
             if (l == DEPTH - 1) tile_dot_relu16(acc[u], wout + 32 * u, grp, head);
         }
 #pragma unroll
@@ -305,6 +309,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         const float* unit = next_unit();
         tile_bias16(acc[u], bf + 32 * u, grp);
         seg_m16<P, HB>(acc[u], unit, 2 * HB, xh, xl, st);
+        if (u == 0) probe_tile(acc[0]);
     }
 #pragma unroll
     for (int u = 0; u < WT; ++u) tile_to_operand16<false, P>(acc[u], xh[u], xl[u]);
@@ -319,10 +324,12 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         tile_bias16(acc[u], bv + 32 * u, grp);
         seg_m16<P, HB>(acc[u], unit, kViewsKs, xh, xl, st);
         seg_m16<P, 1>(acc[u], unit, kViewsKs, pev_h, pev_l, st);
+        if (u == 0) probe_tile(acc[0]);           // the feature vector and the view encoding
 #pragma unroll
         for (int c = 0; c < 3; ++c) tile_dot_relu16(acc[u], wv + c * VT * 32 + 32 * u, grp, col[c]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a wave never ends with LDS-DMA in flight)
+    watch.report(a.range_flag);
 
     // ---- outputs: the four lane groups hold partial sums over their rows ----------------------------------------------------
 #pragma unroll

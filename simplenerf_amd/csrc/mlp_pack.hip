@@ -27,6 +27,7 @@ struct StageTable {
     const float* w[kStagesPerLaunch][3];
     snerf::MlpPlan::HalfStage stage[kStagesPerLaunch];
     int m16[kStagesPerLaunch];   // 1: fragment layout of the 16x16x32 MFMA (mlp_forward_m16.hip)
+    int* range_flag;             // pinned host word: kRangeWeight is OR-ed in when a weight does not fit fp16
 };
 constexpr int kCopiesPerLaunch = 16;
 struct CopyTable {
@@ -120,6 +121,7 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
             if (out < sg.out_dim && row < sg.feat_hi) tv = w[(long long)out * sg.ld + sg.col_offset + row];
             const _Float16 thi = (_Float16)tv;
             out_store(dst16, u, unit_ks, ks_unit, lane, slot, thi, (_Float16)(tv - (float)thi));
+            if (!(fabsf(tv) <= 65504.0f)) __hip_atomic_fetch_or(table.range_flag, snerf::kRangeWeight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             continue;
         }
         if (sg.kind == snerf::SEG_ACC) {
@@ -137,6 +139,8 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         out_store(dst16, u, unit_ks, ks_unit, lane, slot, hi, lo);
+        // (NaN included; reported by the next fp16-mode call only -- an fp32-mode model may hold such weights legitimately)
+        if (!(fabsf(v) <= 65504.0f)) __hip_atomic_fetch_or(table.range_flag, snerf::kRangeWeight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -191,6 +195,8 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
     }
     {
         StageTable table;
+        table.range_flag = snerf::range_flag();
+        if (!table.range_flag) return SNERF_E_HIP;
         int n = 0;
         long long most = 0;
         auto flush = [&]() {

@@ -50,6 +50,13 @@ inline int raise_dynamic_lds(DeviceOnce& once, const void* kernel, int bytes, co
     });
 }
 
+// fp16 range flag (api.hip; include/simplenerf_hip.h "Range"): device-visible pointer to the CURRENT device's word of a
+// pinned host table (NULL + error message when it cannot be allocated), and the report every fp16-mode entry point makes
+// before enqueuing: SNERF_E_RANGE (flag cleared) if an earlier launch on this device raised it.
+constexpr int kRangeActivation = 1, kRangeWeight = 2;
+int* range_flag();
+int report_range(const char* what);
+
 // Grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8 blocks, never more than the work.
 inline unsigned stride_grid(long long work, int block) {
     long long blocks = (work + block - 1) / block;

@@ -373,6 +373,11 @@ class GraphedTrainStep:
             self._capture()                    # records the work (on these inputs); nothing is computed until the replay
             self.weights_key = key
         self.graph.replay()
+        # a replay bypasses the entry points that report an fp16 range violation of an earlier launch: ask here (a host read
+        # of a pinned word, no synchronisation -- like the entry points it sees launches that have finished)
+        if self.model.precision != ops.PRECISION_FP32 and ops.range_status(clear=True):
+            raise ops.Fp16RangeError("GraphedTrainStep: an earlier replay met a value outside the fp16 range (|v| > 65504); its "
+                                     "gradients are invalid -- use hip_precision 'fp32' for this model")
         return self.totals
 
 

@@ -46,6 +46,21 @@ def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+# ---------------------------------------------------------------------------------------------- fp16 range flag
+Fp16RangeError = _lib.Fp16RangeError
+RANGE_ACTIVATION, RANGE_WEIGHT = 1, 2
+
+
+def range_status(clear: bool = False) -> int:
+    """The current device's fp16 range flag (snerf_range_status): 0 = clean, bit 0 = an activation / encoded input of an
+    fp16-mode launch left the fp16 range, bit 1 = a weight did.  Launches are asynchronous: synchronise first to be sure
+    every enqueued launch has reported.  (Without a query the flag surfaces as Fp16RangeError from the next fp16-mode call.)"""
+    status = _lib.load().snerf_range_status(int(bool(clear)))
+    if status < 0:
+        _lib.check(status, 'snerf_range_status')
+    return status
+
+
 # ---------------------------------------------------------------------------------------------- measurement hook
 PROFILE_MLP_FORWARD, PROFILE_MLP_BACKWARD = 0, 1
 

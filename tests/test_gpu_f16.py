@@ -239,3 +239,90 @@ def test_both_inference_kernels_agree():
             # (the synthetic density head has gain 300: few-ulp differences of the 256-term dot products are amplified)
             assert util.rel_linf(sigma, sigma_t) < (5e-3 if f16_mode else 5e-5), (n, s, prec)
             assert util.linf(rgb, rgb_t) < (2e-4 if f16_mode else 5e-6), (n, s, prec)
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'f16'])
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_leaving_the_fp16_range_is_detected_not_silent(precision, mode):
+    """both fp16 modes hold hidden activations as fp16 numbers; a hidden unit past 65504 used to come out as a
+    non-finite -- or, masked by a later ReLU, a finite but wrong -- sample without any signal.  Now every fp16-mode forward
+    kernel watches the operands it converts and raises the device's range flag: visible through ops.range_status() after a
+    synchronisation, and as Fp16RangeError from the NEXT fp16-mode call (launches are asynchronous).  The fp32 mode renders the
+    same model without complaint."""
+    cfg = synth.with_overrides(synth.make_configs('config2'), hip_precision=precision)
+    model = get_model(cfg, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()}
+    model.load_state_dict(sd)
+    model = model.to(DEV).train(mode == 'train')
+    cam = synth.camera('fern', 0)
+    batch = harness.frame_batch(cam, True, DEV, 200000, 64)
+    ops.range_status(clear=True)
+    with torch.no_grad():
+        good = model(batch)
+    torch.cuda.synchronize()
+    assert ops.range_status() == 0 and torch.isfinite(good['rgb_fine']).all()
+    # one hidden unit of the third trunk layer driven past the fp16 maximum (its bias: 1e5 > 65504)
+    with torch.no_grad():
+        model.coarse_model.pts_linears[2].bias[17] = 1.0e5
+        out = model(batch)
+    torch.cuda.synchronize()
+    assert ops.range_status() & ops.RANGE_ACTIVATION
+    with pytest.raises(ops.Fp16RangeError, match='fp16 range'):
+        with torch.no_grad():
+            model(batch)
+    assert ops.range_status() == 0                      # reported once; the refused call enqueued nothing
+    # the same weights in the fp32 mode: finite, no flag
+    ref_model = get_model(synth.make_configs('config2'), None)
+    ref_model.load_state_dict(model.state_dict())
+    ref_model = ref_model.to(DEV).train(mode == 'train')
+    with torch.no_grad():
+        ref = ref_model(batch)
+    torch.cuda.synchronize()
+    assert ops.range_status() == 0 and all(torch.isfinite(v).all() for v in ref.values())
+    # the flagged launch's outputs are wrong where they are finite at all -- which is why they must not be used
+    assert not torch.isfinite(out['rgb_coarse']).all() or float((out['rgb_coarse'] - ref['rgb_coarse']).abs().max()) > 1e-3
+    # a weight outside the range is caught when the stream is packed
+    # (by the pack kernel of the same call: depending on how quickly it finishes, the flag is reported by that very call's
+    # forward or stays set for the next one)
+    with torch.no_grad():
+        model.coarse_model.pts_linears[2].bias[17] = 0.0
+        model.coarse_model.pts_linears[3].weight[5, 9] = -7.0e4
+        try:
+            model(batch)
+            torch.cuda.synchronize()
+            caught = bool(ops.range_status(clear=True) & ops.RANGE_WEIGHT)
+        except ops.Fp16RangeError as error:
+            caught = 'a weight' in str(error)
+            torch.cuda.synchronize()
+            ops.range_status(clear=True)
+    assert caught
+    with torch.no_grad():
+        model.coarse_model.pts_linears[3].weight[5, 9] = 0.01
+        again = model(batch)
+    torch.cuda.synchronize()
+    assert ops.range_status() == 0 and torch.isfinite(again['rgb_fine']).all()
+
+
+def test_graphed_training_step_reports_a_range_violation():
+    """A graph replay bypasses the entry points that report the flag: GraphedTrainStep asks after every replay."""
+    cfg = synth.training_configs('f16', num_rays=192, num_sparse=64)
+    cfg['losses'] = synth.loss_configs(iter_weighted=False)
+    scene = synth.training_scene(0, 3, 48, 64, sparse_fraction=0.05)
+    model = get_model(cfg, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 9, 200.0, 8.0).items()})
+    model = model.to(DEV).train()
+    batcher = BatchAssembler(cfg, scene, DEV)
+    step = harness.GraphedTrainStep(model, LossComputer(cfg), batcher.get_next_batch(0))
+    ops.range_status(clear=True)
+    step(batcher.get_next_batch(0))
+    torch.cuda.synchronize()
+    assert ops.range_status() == 0
+    with torch.no_grad():
+        model.fine_model.pts_linears[1].bias[3] = 2.0e5
+    step(batcher.get_next_batch(1))
+    torch.cuda.synchronize()
+    with pytest.raises(ops.Fp16RangeError):
+        step(batcher.get_next_batch(2))
+    ops.range_status(clear=True)
