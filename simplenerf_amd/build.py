@@ -40,16 +40,18 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ_DIR, exist_ok=True)
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), output: str = LIB, obj_dir: str = OBJ_DIR) -> str:
+    """``extra_flags`` / ``output`` / ``obj_dir``: diagnostic variants (tools/probes/build_variant.py) -- the shipped library is
+    always built with FLAGS alone."""
+    os.makedirs(obj_dir, exist_ok=True)
     headers = _headers()
     jobs = []
     objs = []
     for src in _sources():
-        obj = os.path.join(OBJ_DIR, src[:-4] + '.o')
+        obj = os.path.join(obj_dir, src[:-4] + '.o')
         objs.append(obj)
         if force or _stale(obj, [os.path.join(CSRC, src)] + headers):
-            jobs.append([HIPCC, *FLAGS, '-c', os.path.join(CSRC, src), '-o', obj])
+            jobs.append([HIPCC, *FLAGS, *extra_flags, '-c', os.path.join(CSRC, src), '-o', obj])
 
     def run(cmd):
         if verbose:
@@ -63,11 +65,45 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
             list(pool.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB])
-    return LIB
+    if jobs or force or _stale(output, objs):
+        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', output])
+    return output
+
+
+TORCH_EXT_DIR = os.path.join(HERE, 'csrc_torch')
+TORCH_EXT_NAME = 'snerf_torch_ext'
+TORCH_EXT = os.path.join(TORCH_EXT_DIR, 'build', TORCH_EXT_NAME + '.so')
+
+
+def build_torch_extension(force: bool = False, verbose: bool = False) -> str:
+    """The TORCH_LIBRARY binding (csrc_torch/snerf_torch.cpp: torch.ops.snerf.render + its C++ autograd node) through
+    torch.utils.cpp_extension, in-tree: simplenerf_amd/csrc_torch/build/snerf_torch_ext.so.  Host compiler only -- the file is
+    glue over the C ABI and links against libsimplenerf_hip.so ($ORIGIN-relative rpath), which must exist first."""
+    import torch
+    from torch.utils import cpp_extension
+    if not os.path.exists(LIB):
+        raise RuntimeError(f'{LIB} must be built first (build_library)')
+    source = os.path.join(TORCH_EXT_DIR, 'snerf_torch.cpp')
+    deps = [source, os.path.join(INCLUDE, 'simplenerf_hip.h')]
+    if not force and not _stale(TORCH_EXT, deps):
+        return TORCH_EXT
+    build_dir = os.path.dirname(TORCH_EXT)
+    os.makedirs(build_dir, exist_ok=True)
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    cpp_extension.load(
+        name=TORCH_EXT_NAME, sources=[source], build_directory=build_dir, is_python_module=False, verbose=verbose,
+        extra_cflags=['-O2', '-std=c++17', '-D__HIP_PLATFORM_AMD__', '-Wno-unused-function'],
+        extra_include_paths=[INCLUDE, os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'include')],
+        extra_ldflags=[f'-L{torch_lib}', '-lc10_hip', '-ltorch_hip', f'-L{HERE}', '-lsimplenerf_hip', "-Wl,-rpath,'$$ORIGIN/../..'"])
+    # (cpp_extension.load has also loaded it into this process: torch.ops.snerf exists from here on)
+    if not os.path.exists(TORCH_EXT):
+        raise RuntimeError(f'torch.utils.cpp_extension did not produce {TORCH_EXT}')
+    os.utime(TORCH_EXT, None)
+    return TORCH_EXT
 
 
 if __name__ == '__main__':
     path = build_library(force='--force' in sys.argv, verbose=True)
     print(path)
+    if '--no-torch-ext' not in sys.argv:
+        print(build_torch_extension(force='--force' in sys.argv, verbose=True))

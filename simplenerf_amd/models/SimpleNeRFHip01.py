@@ -7,6 +7,11 @@ sites (src/Trainer01.py:93,194,328; src/Tester01.py:63) work unchanged.  All ari
 (simplenerf_amd/csrc) through the C ABI in include/simplenerf_hip.h; PyTorch only owns device memory, the stream and
 the parameters.  There is no eager/CPU fallback: CPU tensors or an unbuilt library raise.
 
+Host binding: ``configs['model']['hip_host_binding']`` = ``'torch_ext'`` (default: ``torch.ops.snerf.render``, the
+TORCH_LIBRARY op with a C++ ``torch::autograd::Function`` that SURVEY 8b names -- csrc_torch/snerf_torch.cpp, built by
+torch.utils.cpp_extension) or ``'ctypes'`` (the torch-free binding of the same two C-ABI calls, ops.RenderCall).  Same
+kernels, same results bit for bit; the extension spends ~1 ms less host time per training iteration.
+
 One extra, optional config key: ``configs['model']['hip_precision']`` = ``'fp32'`` (default; fp32 matrix cores) or
 ``'f16x3'`` (fp16 hi/lo split, three MFMAs per product, fp32 accumulate: fp32-grade results ~2.5x faster; covers the
 forward, the activation-keeping training forward, the backward dgrad chain and the large weight-gradient products), or
@@ -43,7 +48,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .. import ops
+from .. import _torch_ext, ops
 
 Tensor = torch.Tensor
 _SKIP_AFTER = 4  # reference: self.skips = [4]
@@ -229,6 +234,10 @@ class SimpleNeRFHip(torch.nn.Module):
         # False (default): the backward kernels write / accumulate parameter gradients straight into ``p.grad``;
         # True: they are returned to autograd (torch.autograd.grad, hooks), which then accumulates them itself
         self.return_param_grads = bool(mcfg.get('hip_return_param_grads', False))
+        self.host_binding = mcfg.get('hip_host_binding', 'torch_ext')
+        if self.host_binding not in ('torch_ext', 'ctypes'):
+            raise KeyError(f"model.hip_host_binding must be 'torch_ext' or 'ctypes', got {self.host_binding!r}")
+        self._desc_ints: Dict[tuple, list] = {}
 
     # ------------------------------------------------------------------------------------------
     def set_random_draws(self, draws: Optional[dict]) -> None:
@@ -320,6 +329,85 @@ class SimpleNeRFHip(torch.nn.Module):
         return self._packed[name][1]
 
     # ------------------------------------------------------------------------------------------
+    def _render_with_ctypes(self, batch, draws, present, packed, s_c, s_f, per_sample, with_grad):
+        """ops.RenderCall (ctypes over the C ABI) + the Python autograd.Function."""
+        mcfg = self.configs['model']
+        call = ops.RenderCall(packed, self.ndc, bool(mcfg['white_bkgd']), bool(mcfg['lindisp']), s_c, s_f, self.precision,
+                              keep_activations=with_grad, per_sample=per_sample)
+        if not with_grad:
+            return call.forward(batch, draws)
+        params = [p for name in present if name for p in getattr(self, name).abi_params()]
+        res = _RenderFunction.apply(self, call, batch, draws, *params)
+        out_levels, it = {level: {} for level in call.levels}, iter(res)
+        for layout in call.output_layout:
+            for level, k in layout:
+                out_levels[level][k] = next(it)
+        z_coarse = next(it)
+        z_fine = draws['z_vals_fine'] if 'z_vals_fine' in draws else (next(it) if self.fine_mlp_needed else None)
+        return z_coarse, z_fine, out_levels
+
+    _EXT_KEYS = ('rgb', 'acc', 'depth', 'depth_var', 'depth_ndc', 'depth_var_ndc', 'alpha', 'visibility', 'weights', 'sigma',
+                 'raw_rgb', 'raw_visibility', 'raw_visibility2', 'visibility2')     # order of `enum Key` in snerf_torch.cpp
+
+    def _render_with_extension(self, batch, draws, present, packed, s_c, s_f, per_sample, with_grad):
+        """torch.ops.snerf.render: one dispatcher call; validation, output allocation, pointer tables and the autograd node
+        live in C++ (csrc_torch/snerf_torch.cpp)."""
+        snerf = _torch_ext.load()
+        mcfg = self.configs['model']
+        key = tuple(present)
+        descs = self._desc_ints.get(key)
+        if descs is None:
+            descs = []
+            for mlp in packed:
+                d = mlp.desc if mlp is not None else None
+                descs += [0] * 10 if d is None else [d.points_net_depth, d.points_net_width, d.views_net_depth, d.views_net_width,
+                                                      d.points_pe_degree, d.views_pe_degree, d.sigma_pe_degree, d.use_view_dirs,
+                                                      d.view_dependent_rgb, d.predict_visibility]
+            self._desc_ints[key] = descs
+        mask = (1 if 'alpha' in per_sample else 0) | (2 if 'visibility' in per_sample else 0) | (4 if 'weights' in per_sample else 0)
+        cfg = [int(self.ndc), int(bool(mcfg['white_bkgd'])), int(bool(mcfg['lindisp'])), s_c, s_f, self.precision, mask]
+        near, far = (batch['near_ndc'], batch['far_ndc']) if self.ndc else (batch['near'], batch['far'])
+        predicts = any(m is not None and m.desc.predict_visibility for m in packed)
+        rays = [batch['rays_o'], batch['rays_d'], batch.get('view_dirs'), batch.get('rays_o_ndc') if self.ndc else None,
+                batch.get('rays_d_ndc') if self.ndc else None, near, far, batch.get('rays_o2') if predicts else None]
+        draw_list = [draws.get('t_rand'), draws.get('u')] + [draws.get(('noise', l)) for l in range(6)] + [draws.get('z_vals_fine')]
+        params, counts = [], [0] * 6
+        if with_grad:
+            for l, name in enumerate(present):
+                if name:
+                    level_params = getattr(self, name).abi_params()
+                    params += level_params
+                    counts[l] = len(level_params)
+        try:
+            res = snerf.render(cfg, descs, [None if m is None else m.buffer for m in packed], rays, draw_list, params, counts,
+                               with_grad, self.return_param_grads)
+        except RuntimeError as error:        # (c10::Error; the range report keeps its own type through either binding)
+            if 'outside the fp16 range' in str(error):
+                raise ops.Fp16RangeError(str(error).split('\n')[0]) from None
+            raise
+        it = iter(res)
+        z_coarse = next(it)
+        z_fine = next(it) if self.fine_mlp_needed else None
+        k_other = rays[7].shape[1] if rays[7] is not None else 0
+        out_levels: Dict[int, Dict[str, Tensor]] = {}
+        for l, mlp in enumerate(packed):
+            if mlp is None:
+                continue
+            d = out_levels[l] = {}
+            vis = bool(mlp.desc.predict_visibility)
+            for k in self._EXT_KEYS:
+                if k in ('depth_ndc', 'depth_var_ndc') and not self.ndc:
+                    continue
+                if k in ('alpha', 'visibility', 'weights') and k not in per_sample:
+                    continue
+                if k == 'raw_visibility' and not vis:
+                    continue
+                if k in ('raw_visibility2', 'visibility2') and not (vis and k_other):
+                    continue
+                d[k] = next(it)
+        return z_coarse, z_fine, out_levels
+
+    # ------------------------------------------------------------------------------------------
     def forward(self, input_batch: dict, retraw: bool = False, sec_views_vis: bool = False) -> Dict[str, Tensor]:
         batch = dict(input_batch)  # the caller's dict is never mutated (reference: deep_dict_copy :68)
         training = self.training
@@ -387,19 +475,10 @@ class SimpleNeRFHip(torch.nn.Module):
             batch.pop('rays_o2', None) if not (sec_views_vis or training) else None
             if (sec_views_vis or training) and 'rays_o2' not in batch:
                 batch['rays_o2'] = self._secondary_origins(batch)          # (n, num_frames - 1, 3), :122-133
-        call = ops.RenderCall(packed, self.ndc, bool(mcfg['white_bkgd']), bool(mcfg['lindisp']), s_c, s_f, self.precision,
-                              keep_activations=with_grad, per_sample=per_sample)
-        if with_grad:
-            params = [p for name in present if name for p in getattr(self, name).abi_params()]
-            res = _RenderFunction.apply(self, call, batch, draws, *params)
-            out_levels, it = {level: {} for level in call.levels}, iter(res)
-            for layout in call.output_layout:
-                for level, k in layout:
-                    out_levels[level][k] = next(it)
-            z_coarse = next(it)
-            z_fine = draws['z_vals_fine'] if 'z_vals_fine' in draws else (next(it) if self.fine_mlp_needed else None)
+        if self.host_binding == 'torch_ext':
+            z_coarse, z_fine, out_levels = self._render_with_extension(batch, draws, present, packed, s_c, s_f, per_sample, with_grad)
         else:
-            z_coarse, z_fine, out_levels = call.forward(batch, draws)
+            z_coarse, z_fine, out_levels = self._render_with_ctypes(batch, draws, present, packed, s_c, s_f, per_sample, with_grad)
 
         out: Dict[str, Tensor] = {}
 

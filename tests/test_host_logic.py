@@ -311,3 +311,24 @@ def test_bench_timed_region_protocol_on_the_cpu():
     assert log == ['fence'] + ['step'] * 5 + ['fence']      # (the dry marks run before the opening fence)
     assert len(device_ms) == len(enqueue_ms) == 5 and all(v >= 2.0 for v in device_ms) and elapsed >= 0.01
     assert sum(device_ms) <= elapsed * 1e3 + 1e-6
+
+
+def test_torch_library_binding_loads_and_rejects_cpu_tensors():
+    """The TORCH_LIBRARY extension (csrc_torch/snerf_torch.cpp, built by torch.utils.cpp_extension) registers
+    torch.ops.snerf.render against the same C ABI; without a GPU it must load, report the ABI version and refuse CPU tensors
+    with a c10::Error (RuntimeError) instead of computing anything."""
+    from simplenerf_amd import _torch_ext
+    snerf = _torch_ext.load()
+    assert int(snerf.abi_version()) == _lib.ABI_VERSION
+    schema = str(torch.ops.snerf.render.default._schema)
+    assert 'Tensor?[] packed' in schema and 'Tensor[] params' in schema and schema.endswith('-> Tensor[]')
+    d = ops.mlp_desc(synth.mlp_config(64))
+    descs = [d.points_net_depth, d.points_net_width, d.views_net_depth, d.views_net_width, d.points_pe_degree, d.views_pe_degree,
+             d.sigma_pe_degree, d.use_view_dirs, d.view_dependent_rgb, d.predict_visibility] + [0] * 50
+    cfg = [0, 0, 0, 64, 0, 0, 1]
+    rays = [torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 3), None, None, torch.ones(4, 1), torch.ones(4, 1), None]
+    packed = [torch.zeros(8)] + [None] * 5
+    with pytest.raises(RuntimeError, match='GPU'):
+        snerf.render(cfg, descs, packed, rays, [None] * 9, [], [0] * 6, False, False)
+    with pytest.raises(RuntimeError, match='cfg holds'):
+        snerf.render(cfg[:3], descs, packed, rays, [None] * 9, [], [0] * 6, False, False)

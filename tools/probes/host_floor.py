@@ -9,8 +9,9 @@ from simplenerf_amd.models.ModelFactory import get_model
 DEV = torch.device('cuda', 0)
 prec = os.environ.get('SNERF_PREC', 'f16x3')
 for rays, sparse in ((32, 32), (256, 256), (2048, 2048)):
-    for mode in ('eager', 'graph'):
+    for mode, binding in (('eager', 'ctypes'), ('eager', 'torch_ext'), ('graph', 'torch_ext')):
         cfg = synth.training_configs(prec, rays, sparse); cfg['sub_batch_size'] = rays + sparse
+        cfg['model']['hip_host_binding'] = binding
         model = get_model(cfg, None)
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
         model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
@@ -32,6 +33,6 @@ for rays, sparse in ((32, 32), (256, 256), (2048, 2048)):
         for _ in range(20): step()
         t_host = (time.perf_counter() - t0) / 20
         torch.cuda.synchronize(); t_all = (time.perf_counter() - t0) / 20
-        print(f'{rays}+{sparse} rows {mode:5s}: host enqueue {t_host*1e3:6.2f} ms/iter, wall {t_all*1e3:6.2f} ms/iter', flush=True)
+        print(f'{rays}+{sparse} rows {mode:5s} {binding:9s}: host enqueue {t_host*1e3:6.2f} ms/iter, wall {t_all*1e3:6.2f} ms/iter', flush=True)
         del graphed, model, opt
         torch.cuda.empty_cache()
