@@ -512,7 +512,12 @@ constexpr int kPairBytes = 2304;   // LDS image of one 32-row tile: piece 0 at +
 constexpr int kPieceGap = 1152;    // the two 16-lane groups of a half-wave read different pieces of the same tile)
 constexpr int kWgrad16Buffers = 3;
 
-template <int NO, int NI>
+// PARTIAL: the small head / encoding jobs -- (8 x 2), (1 x 8), (4 x 1) and (1 x 4) tiles for the main MLP -- share ONE launch
+// of the <2, 2> instance: a wave's register tile may then be only partly covered by the job (wave-uniform guards around its
+// reads, MFMAs and stores).  As four launches of their own register-tile classes each of them was mostly launch, ramp and
+// tail (20-50 us for a few MB of operands; 13 % of the 16-bit training iteration with the reduction, MFMA pipe 4-13 % busy).
+// The per-tile arithmetic and the chunking are unchanged, so the partial sums -- and the gradients -- are bit-identical.
+template <int NO, int NI, bool PARTIAL = false>
 __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const unsigned short* __restrict__ grads,
                                                          const unsigned short* __restrict__ acts, float* __restrict__ partial,
                                                          const float* __restrict__ zeros) {
@@ -526,9 +531,12 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     const WgradJob& job = table.jobs[ji];
     const int chunk = blockIdx.x - table.wg_start[ji];
     const int rows_dy = job.out_tiles * 32;
-    const int wgrid_i = job.in_tiles / NI;
+    const int wgrid_i = PARTIAL ? (job.in_tiles / NI > 1 ? job.in_tiles / NI : 1) : job.in_tiles / NI;
     const int wo = wave / wgrid_i, wi = wave - wo * wgrid_i;
-    const bool active = wo * NO < job.out_tiles;
+    // tiles of this wave's register tile that lie inside the job (all of them unless PARTIAL)
+    const int no_eff = PARTIAL ? (job.out_tiles - wo * NO < NO ? job.out_tiles - wo * NO : NO) : NO;
+    const int ni_eff = PARTIAL ? (job.in_tiles - wi * NI < NI ? job.in_tiles - wi * NI : NI) : NI;
+    const bool active = PARTIAL ? (no_eff > 0 && ni_eff > 0) : wo * NO < job.out_tiles;
     const long long per = (job.blocks + job.chunks - 1) / job.chunks;
     const long long b0 = chunk * per, b1 = (b0 + per < job.blocks) ? b0 + per : job.blocks;
 
@@ -612,11 +620,13 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
         const unsigned a_kk = buf + a_off, b_kk = buf + b_off;
 #pragma unroll
         for (int oo = 0; oo < NO; ++oo) {
+            if (PARTIAL && oo >= no_eff) continue;      // (a tile outside the job would be read from the next buffer's bytes)
             f.a[oo].d[0] = lds_read_tr16(a_kk, oo * kPairBytes);
             f.a[oo].d[1] = lds_read_tr16(a_kk, oo * kPairBytes + 128);
         }
 #pragma unroll
         for (int ii = 0; ii < NI; ++ii) {
+            if (PARTIAL && ii >= ni_eff) continue;
             f.bx[ii].d[0] = lds_read_tr16(b_kk, ii * kPairBytes);
             f.bx[ii].d[1] = lds_read_tr16(b_kk, ii * kPairBytes + 128);
         }
@@ -629,6 +639,7 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
         for (int ii = 0; ii < NI; ++ii) { after_lds_wait(f.bx[ii].d[0]); after_lds_wait(f.bx[ii].d[1]); }
 #pragma unroll
         for (int oo = 0; oo < NO; ++oo) {
+            if (PARTIAL && oo >= no_eff) continue;
             // bf16 pairs -> fp32 (exact), bias sum in true units, x region scale -> fp16
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -644,8 +655,10 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
 #pragma unroll
         for (int oo = 0; oo < NO; ++oo)
 #pragma unroll
-            for (int ii = 0; ii < NI; ++ii)
+            for (int ii = 0; ii < NI; ++ii) {
+                if (PARTIAL && (oo >= no_eff || ii >= ni_eff)) continue;
                 acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[oo], f.bx[ii].h, acc[oo][ii], 0, 0, 0);
+            }
     };
 
     const int nblocks = (int)(b1 - b0);
@@ -685,9 +698,11 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     float* bout = partial + job.bias_off + (long long)chunk * rows_dy;
 #pragma unroll
     for (int oo = 0; oo < NO; ++oo) {
+        if (PARTIAL && oo >= no_eff) continue;
         const int o = wo * NO + oo;
 #pragma unroll
         for (int ii = 0; ii < NI; ++ii) {
+            if (PARTIAL && ii >= ni_eff) continue;
             const int i = wi * NI + ii;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -774,6 +789,14 @@ __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float
         __syncthreads();
     }
 }
+
+// Workgroups (= partial sums the reduction folds afterwards) of a small head / encoding job.  Every chunk ends with a partial
+// of out_tiles x in_tiles x 4 KiB that is written once and read once, so the count trades staging parallelism against
+// partial-sum traffic (the two 8x2-tile encoding jobs of the main MLP: 64 KB per chunk).  -DSNERF_SMALL_CHUNKS=n for A/B builds.
+#ifndef SNERF_SMALL_CHUNKS
+#define SNERF_SMALL_CHUNKS 512
+#endif
+constexpr int kSmallJobChunks = SNERF_SMALL_CHUNKS;
 
 // Register tile (NO, NI) per wave for a job of (out_tiles x in_tiles): the 4 waves must cover it as a WO x WI grid.
 inline void wave_tile(const WgradJob& j, int* no, int* ni) {
@@ -865,7 +888,7 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
             chunks = 256 / peers;   // rounded DOWN: 7 jobs x 37 chunks = 259 workgroups ran as 256 + a second round of 3
             cap = blocks / 8;
         } else {
-            chunks = 512;
+            chunks = kSmallJobChunks;
             cap = blocks / 8;
         }
         if (chunks > cap) chunks = cap;
@@ -913,12 +936,12 @@ int launch_wgrad(const JobTable& table, const float* grads, const float* acts, f
 
 }  // namespace
 
-template <int NO, int NI>
+template <int NO, int NI, bool PARTIAL = false>
 int launch_wgrad16(const JobTable& table, const float* grads, const float* acts, float* partial, hipStream_t stream) {
     int max_tiles = 0;
     for (int j = 0; j < table.count; ++j) max_tiles = std::max(max_tiles, table.jobs[j].out_tiles + table.jobs[j].in_tiles);
     const size_t lds_bytes = (size_t)kWgrad16Buffers * max_tiles * kPairBytes;
-    auto kernel = wgrad16_kernel<NO, NI>;
+    auto kernel = wgrad16_kernel<NO, NI, PARTIAL>;
     static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
     const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), kWgrad16Buffers * 16 * kPairBytes, "mlp_backward");
     if (attr != SNERF_OK) return attr;
@@ -1027,6 +1050,28 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
         if (work > max_work) max_work = work;
     }
     static const int classes[][2] = {{2, 8}, {2, 2}, {2, 1}, {1, 8}, {1, 4}, {1, 2}, {1, 1}};
+    // 16-bit mode: every small job (fewer than 32 tile products: heads, encodings) rides in ONE launch of the <2, 2> instance
+    // with partial register tiles (wgrad16_kernel PARTIAL) instead of one launch per register-tile class
+#ifdef SNERF_PROBE_NO_SMALL_FOLD     // A/B probe builds: one launch per register-tile class, as before round 3
+    auto small16 = [&](const WgradJob&) { return false; };
+#else
+    auto small16 = [&](const WgradJob& job) { return f16 && job.out_tiles * job.in_tiles < 32; };
+#endif
+    if (f16) {
+        JobTable sub;
+        sub.count = 0;
+        sub.wg_start[0] = 0;
+        for (const WgradJob& job : jobs) {
+            if (!small16(job)) continue;
+            sub.jobs[sub.count] = job;
+            sub.wg_start[sub.count + 1] = sub.wg_start[sub.count] + job.chunks;
+            ++sub.count;
+        }
+        if (sub.count > 0) {
+            rc = launch_wgrad16<2, 2, true>(sub, grads, saved_acts, partial, s);
+            if (rc != SNERF_OK) return rc;
+        }
+    }
     for (const auto& cls : classes) {
         JobTable sub;
         sub.count = 0;
@@ -1034,7 +1079,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
         for (const WgradJob& job : jobs) {
             int no, ni;
             wave_tile(job, &no, &ni);
-            if (no != cls[0] || ni != cls[1]) continue;
+            if (no != cls[0] || ni != cls[1] || small16(job)) continue;
             sub.jobs[sub.count] = job;
             sub.wg_start[sub.count + 1] = sub.wg_start[sub.count] + job.chunks;
             ++sub.count;

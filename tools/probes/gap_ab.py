@@ -38,6 +38,9 @@ configs = synth.make_configs('headline')
 camera = synth.camera('fern', 0)
 h, w = camera['resolution']
 first = (h // 2) * w
+# (the ctypes binding: the TORCH_LIBRARY extension is linked against the SHIPPED library, a diagnostic build is only reachable
+# through _lib.LIB_PATH)
+configs['model']['hip_host_binding'] = 'ctypes'
 model = bench.synthetic_model(configs, 7, dev, precision)
 STEPS, ROUNDS = 300, 5
 
