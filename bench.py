@@ -414,7 +414,7 @@ class StandInRenderer:
 
 
 # ---------------------------------------------------------------------------------------------- config 5 (training)
-def training_step(precision, rank, world, device, single_pass=False):
+def training_step(precision, rank, world, device, single_pass=False, graphed=False):
     """BASELINE config 5: a callable running ONE iteration of the reference's training loop (Trainer.train_one_iter,
     src/Trainer01.py:60-107) with every stage on the device: batch assembly (2048 pixel + 2048 sparse-depth rows per GPU,
     each rank a slice of one global index stream), four MLPs forward, nine losses, backward, ONE all-reduce of the
@@ -437,11 +437,22 @@ def training_step(precision, rank, world, device, single_pass=False):
     decayer = get_lr_decayer(cfg)
     state = {'iter': 20000}
 
+    graph = None
+    if graphed:      # the device work of the pass (re-pack, forwards, losses, backward) replayed from ONE HIP graph
+        if world > 1:
+            raise SystemExit('the graphed training step is a single-GPU measurement')
+        graph = harness.GraphedTrainStep(model, losses, batcher.get_next_batch(state['iter']), sub_batch_size=cfg['sub_batch_size'])
+        batcher = BatchAssembler(cfg, synth.training_scene(), device, rank=rank, world_size=world)
+
     def step():
         it = state['iter']
         state['iter'] += 1
         for group in opt.param_groups:
             group['lr'] = decayer.get_updated_learning_rate(it)
+        if graph is not None:
+            totals = graph(batcher.get_next_batch(it))
+            opt.step()
+            return totals
         return harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it), cfg['sub_batch_size'], world,
                                       single_pass=single_pass)
 
@@ -453,11 +464,11 @@ TRAIN_WORKLOAD = ('config 5: 2048 pixel + 2048 sparse-depth rows per GPU in two 
 TRAIN_DTYPE = {'fp32': 'f32', 'f16x3': 'f16x3', 'f16': 'f16 (bf16 layer gradients)'}
 
 
-def time_training(precision, device, steps, warmup, single_pass=False, board_seconds=0.0):
+def time_training(precision, device, steps, warmup, single_pass=False, board_seconds=0.0, graphed=False):
     """Config 5 on one GPU: (ms per iteration, ms of MLP forward launches, ms of MLP backward calls, rows, timing summary)
     from ``steps`` timed iterations after a settle phase and ``warmup`` iterations."""
     _, ops, _, _ = _pkg()
-    step, rows = training_step(precision, 0, 1, device, single_pass)
+    step, rows = training_step(precision, 0, 1, device, single_pass, graphed)
     settle(step, None, chunk=2)
     ops.profile_enable(64 * (steps + warmup))
     for _ in range(warmup):
@@ -504,6 +515,16 @@ def training_record(device, steps=10, warmup=3):
             'mlp_forward_ms_per_step': fwd_ms, 'mlp_backward_ms_per_step': bwd_ms,
             'mlp_share_of_step': (fwd_ms + bwd_ms) / ms, 'dominant_kernels': dominant[precision],
             'timing': time_training.timing}
+    # the same iteration issued two other ways, 16-bit mode (what changes is the host side and the launch count, not the
+    # kernels): ONE model pass over the 4096 rows with the losses still normalised per 2048-row sub-batch
+    # (harness.train_one_iter single_pass: same objective, the reference sub-batches only for device memory), and the
+    # sub-batched pass replayed from one HIP graph (harness.GraphedTrainStep: bit-identical to the eager iteration)
+    for name, kwargs in (('f16_single_pass', {'single_pass': True}), ('f16_graphed', {'graphed': True})):
+        ms, fwd_ms, bwd_ms, rows = time_training('f16', device, steps, warmup, **kwargs)
+        tflops = rows * TRAIN_FLOP_PER_RAY / (ms * 1e-3) / 1e12
+        out['modes'][name] = {'dtype': TRAIN_DTYPE['f16'], 'ms_per_step': ms, 'value': rows / (ms * 1e-3), 'unit': 'rays/s',
+                              'algorithmic_tflops': tflops, 'peak_tflops': PEAK_FP16_MFMA_TFLOPS, 'frac_of_peak': tflops / PEAK_FP16_MFMA_TFLOPS,
+                              'host_enqueue_ms_p50': time_training.timing['enqueue_ms']['p50']}
     return out
 
 

@@ -86,3 +86,42 @@ def test_two_rank_training_reproduces_the_single_process_run(tmp_path, precision
     # the three iterations saw three different batches
     first = next(iter(single[0]))
     assert not torch.equal(single[0][first], single[1][first])
+
+
+def _bench(*flags):
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['SNERF_DIST_BACKEND'] = 'gloo'       # two ranks share the box's one GPU: RCCL refuses that, gloo carries the collectives
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', *flags], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_with_the_real_renderer():
+    """``python bench.py --gpus 2`` exactly as the driver runs it for N > 1 (self-launched ranks, settle, warm-up, fenced timed
+    region, one gather per step), with the real kernels on both ranks: the weak-scaling headline line plus BASELINE config 4's
+    frame strong-scaled over the two ranks (``also_measured_frame``).  Only the transport differs from an 8-GPU node (gloo)."""
+    line = _bench('--steps', '4', '--warmup', '2')
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['data'] == 'synthetic' and line['dtype'] == 'f32'
+    assert line['collective']['ranks'] == 2 and line['value'] > 1e4
+    assert line['roofline']['launches'] == 8 and line['roofline']['launches_not_timed'] == 0
+    assert len(line['timing']['step_trace_ms']) == 4
+    frames = line['also_measured_frame']
+    assert frames['scaling'] == 'strong' and frames['n_gpus'] == 2 and [e['precision'] for e in frames['entries']] == ['fp32', 'f16x3']
+    assert all(e['rays'] == 762048 and e['value'] > 1e4 for e in frames['entries'])
+    assert frames['collective']['bytes_per_rank_and_frame'] == 381024 * 28
+
+
+def test_bench_frame_mode_two_ranks_with_the_real_renderer():
+    """``python bench.py --gpus 2 --frame re10k``: ONE 1008x756 frame per step, block-sharded over the ranks, gathered to
+    rank 0 and converted to the five display outputs there."""
+    line = _bench('--frame', 're10k', '--steps', '2', '--warmup', '1', '--precision', 'f16x3')
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['steps'] == 2
+    assert line['config']['rays_per_frame'] == 762048 and line['config']['rays_per_gpu'] == 381024
+    assert line['collective']['bytes'] == 381024 * 28 and line['value'] > 1e4
