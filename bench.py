@@ -73,7 +73,7 @@ METRIC = 'rays/sec (coarse+fine, 128+128 samples)'
 
 # per-precision constants of the headline kernel: (ceiling in algorithmic TFLOP/s, dtype string, kernel, note)
 PRECISION_INFO = {
-    'fp32': (PEAK_FP32_MFMA_TFLOPS, 'f32', 'mlp_forward_kernel<8,4,true,false,false>', 'fp32 MFMA: one pass per algorithmic FLOP'),
+    'fp32': (PEAK_FP32_MFMA_TFLOPS, 'f32', 'mlp_forward_kernel<8,4,true,false,false,false>', 'fp32 MFMA: one pass per algorithmic FLOP'),
     'f16x3': (PEAK_FP16_MFMA_TFLOPS / 3, 'f16x3 (fp16 hi/lo split, fp32 accumulate)', 'mlp_forward_m16_kernel<3,8>',
               'peak = fp16 dense MFMA peak / 3: the kernel issues three fp16 MFMA passes per algorithmic product, achieved '
               'counts algorithmic FLOPs'),
