@@ -20,6 +20,7 @@
 // rate: under the HBM roofline, overlapped with the matrix work.
 #include <algorithm>
 
+#include "clock_stamp.h"
 #include "mlp_device_f16.h"
 
 namespace snerf {
@@ -508,6 +509,8 @@ union Frag16 {
     f16x8 h;
 };
 
+SNERF_STAMP_DEFINE(wgrad16)
+
 constexpr int kPairBytes = 2304;   // LDS image of one 32-row tile: piece 0 at +0, piece 1 at +1152 (bank phase +32 dwords:
 constexpr int kPieceGap = 1152;    // the two 16-lane groups of a half-wave read different pieces of the same tile)
 constexpr int kWgrad16Buffers = 3;
@@ -662,6 +665,7 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     };
 
     const int nblocks = (int)(b1 - b0);
+    SNERF_STAMP_BEGIN();
     FragSet even, odd;
     f16x8 ah[NO];
     int stage_slot = 0, read_slot = 0;                       // ring positions of the next block to request / to read
@@ -692,6 +696,7 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NO == 2 && NI == 8) SNERF_STAMP_END(wgrad16);      // (the large class)
     if (!active) return;
     const int in_cols = job.in_tiles * 32;
     float* out = partial + job.partial_off + (long long)chunk * rows_dy * in_cols;

@@ -8,9 +8,12 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "clock_stamp.h"
 #include "mlp_device_f16.h"
 
 namespace {
+
+SNERF_STAMP_DEFINE(chain_f16)
 
 struct HalfChainArgs {
     ChainArgs c;
@@ -118,6 +121,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;
+    SNERF_STAMP_BEGIN();
     constexpr int HK = WT * 2;   // k-steps over a full-width dY
     constexpr int VK = VT * 2;   // k-steps over the views layer's dY
 
@@ -284,6 +288,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
         for (int l = depth - 1; l >= 0; --l) trunk_layer(l);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SNERF_STAMP_END(chain_f16);
 }
 
 template <int WT, int VT, bool VIEWDEP, int P, int DEPTH = 0>

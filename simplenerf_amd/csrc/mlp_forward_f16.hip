@@ -19,9 +19,12 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "clock_stamp.h"
 #include "mlp_device_f16.h"
 
 namespace {
+
+SNERF_STAMP_DEFINE(forward_f16)
 
 // f(integral_constant<I>), ..., f(integral_constant<N-1>): one inlined copy of the body per index (a `#pragma unroll` on a
 // loop this large is refused by the optimiser)
@@ -89,6 +92,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
     for (int i = threadIdx.x * 4; i < args.const_floats; i += NW * 64 * 4)
         *reinterpret_cast<f32x4*>(consts + i) = *reinterpret_cast<const f32x4*>(a.packed + a.bias_offset + i);
     __syncthreads();
+    SNERF_STAMP_BEGIN();
 
     const long long first = ((long long)blockIdx.x * NW + wave) * 32 + (lane & 31);
     const bool live = first < a.total;
@@ -257,6 +261,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     watch.report(a.range_flag);
+    SNERF_STAMP_END(forward_f16);
     if (live && half == 0) {
         a.sigma[first] = sigma;
         a.rgb[first * 3 + 0] = rgb[0];

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "clock_stamp.h"
 #include "mlp_device_f16.h"
 
 namespace {
@@ -32,16 +33,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-#ifdef SNERF_CLOCK_STAMP
-// DIAGNOSTIC build only (tools/probes/build_variant.py clock -DSNERF_CLOCK_STAMP; never in the shipped library): per workgroup
-// the shader-clock ticks (s_memtime) and the 100 MHz reference ticks (s_memrealtime) its matrix work took -- their ratio is the
-// clock the chip actually held inside the kernel (MI355X_MICROARCH.md, DVFS give-back 6).  The stamps go to a buffer of their
-// own that no kernel reads; no output depends on them.
-__device__ unsigned long long snerf_clock_stamps[2 * 8192];
-extern "C" int snerf_debug_clock_stamps(unsigned long long* host, int pairs) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(snerf_clock_stamps), sizeof(unsigned long long) * 2 * (pairs < 8192 ? pairs : 8192));
-}
-#endif
+SNERF_STAMP_DEFINE(forward_m16)
 
 struct M16Args {
     MlpArgs m;
@@ -274,9 +266,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         }
     }
     __syncthreads();   // consts visible; every wave is done with the scratch before the first acquire hands the slot to the DMA
-#ifdef SNERF_CLOCK_STAMP
-    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+    SNERF_STAMP_BEGIN();
 
     const float* bias = consts;
     const float* wout = consts + (a.pts_out_w - a.bias_offset);
@@ -344,12 +334,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a wave never ends with LDS-DMA in flight)
     watch.report(a.range_flag);
-#ifdef SNERF_CLOCK_STAMP
-    if (threadIdx.x == 0) {
-        snerf_clock_stamps[2 * (blockIdx.x & 8191)] = __builtin_amdgcn_s_memtime() - stamp_t0;
-        snerf_clock_stamps[2 * (blockIdx.x & 8191) + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
-    }
-#endif
+    SNERF_STAMP_END(forward_m16);
 
     // ---- outputs: the four lane groups hold partial sums over their rows ----------------------------------------------------
 #pragma unroll

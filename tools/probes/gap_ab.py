@@ -33,7 +33,7 @@ from simplenerf_amd import harness, ops, synth  # noqa: E402
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(dev)
 lib = _lib.load()
-stamped = hasattr(lib, 'snerf_debug_clock_stamps')
+stamped = hasattr(lib, 'snerf_debug_clock_stamps_forward_m16')
 configs = synth.make_configs('headline')
 camera = synth.camera('fern', 0)
 h, w = camera['resolution']
@@ -56,10 +56,10 @@ def in_kernel_clock():
         return None
     pairs = 512
     buf = (ctypes.c_ulonglong * (2 * pairs))()
-    lib.snerf_debug_clock_stamps.restype = ctypes.c_int
-    lib.snerf_debug_clock_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    lib.snerf_debug_clock_stamps_forward_m16.restype = ctypes.c_int
+    lib.snerf_debug_clock_stamps_forward_m16.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     torch.cuda.synchronize()
-    assert lib.snerf_debug_clock_stamps(buf, pairs) == 0
+    assert lib.snerf_debug_clock_stamps_forward_m16(buf, pairs) == 0
     ratios = [buf[2 * i] / buf[2 * i + 1] * 0.1 for i in range(pairs) if buf[2 * i + 1] > 0]
     return statistics.median(ratios) if ratios else None
 

@@ -17,7 +17,9 @@ def read(p):
 
 
 nodes = [hw for hw in glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*') if os.path.exists(os.path.join(hw, 'power1_input'))]
-for shape, waves in (('32', '8'), ('16', '8'), ('32', '4'), ('16', '4'), ('32', '8'), ('16', '8')):
+# (shape, waves per workgroup, workgroups per CU): 16x16x32 with 2 resp. 4 MFMAs per fragment at 4, 2 and 1 waves per SIMD
+CASES = (('32', '8', '2'), ('16', '8', '2'), ('64', '8', '2'), ('16', '8', '1'), ('64', '8', '1'), ('16', '4', '1'), ('64', '4', '1'), ('16', '8', '2'), ('64', '8', '2'))
+for shape, waves, wgs in CASES:
     rows, on = [], [True]
 
     def loop():
@@ -25,7 +27,7 @@ for shape, waves in (('32', '8'), ('16', '8'), ('32', '4'), ('16', '4'), ('32', 
             rows.append([(read(os.path.join(hw, 'power1_input')), read(os.path.join(hw, 'freq1_input'))) for hw in nodes])
             time.sleep(0.02)
     th = threading.Thread(target=loop, daemon=True); th.start()
-    out = subprocess.run([exe, shape, seconds, waves], capture_output=True, text=True)
+    out = subprocess.run([exe, shape, seconds, waves, wgs], capture_output=True, text=True)
     on[0] = False; th.join()
     rows = rows[len(rows) // 3:]
     # our GPU = the node with the highest mean power (the box shows all eight)
