@@ -711,7 +711,7 @@ def render_bench(args, rank, world, device, dist, make_renderer, data):
         def board_state(r, achieved_tflops, nominal_peak, seconds=1.2):
             """the same step back to back for ~1.2 s with the board's sensors sampled: power, cap, shader clock, and the
             fraction of the peak AT THAT CLOCK (the nominal peaks are quoted at 2.4 GHz; the sysfs clock is the firmware's
-            average, in-kernel clock reads can be lower -- tools/probes/clock_stamp.py measures that)"""
+            average, in-kernel clock reads are lower -- tools/probes/gap_ab.py measures them on the diagnostic build)"""
             sampler = BoardSampler(device.index or 0)
             with torch.no_grad(), sampler:
                 t0 = time.perf_counter()
@@ -721,7 +721,12 @@ def render_bench(args, rank, world, device, dist, make_renderer, data):
                     torch.cuda.synchronize()
             state = sampler.summary()
             if state['sclk_mhz']:
-                state['frac_of_peak_at_this_clock'] = achieved_tflops / (nominal_peak * state['sclk_mhz'] / 2400.0)
+                # sysfs freq1_input is the firmware's average: in the same runs the clock INSIDE the kernels
+                # (d s_memtime / d s_memrealtime of the -DSNERF_CLOCK_STAMP diagnostic build) read 8 % (16-bit) and 3 % (f16x3)
+                # lower, 0 % for fp32 -- profiles/r03_gap_ab_box*.jsonl; this fraction is therefore a LOWER bound of the one at
+                # the true clock
+                state['frac_of_peak_at_sysfs_clock'] = achieved_tflops / (nominal_peak * state['sclk_mhz'] / 2400.0)
+                state['sclk_source'] = 'sysfs hwmon freq1_input (reads 3-8 % above the in-kernel clock under fp16 load)'
             return state
 
         def tflops(meas):

@@ -5,6 +5,7 @@ binding fails loudly when the extension is missing (``hip_host_binding='ctypes'`
 from __future__ import annotations
 
 import os
+import sys
 
 import torch
 
@@ -24,8 +25,16 @@ def load():
     if not _loaded:
         _lib.load()
         if not os.path.exists(EXT_PATH):
-            raise RuntimeError(f'{EXT_PATH} is missing: run `python -m simplenerf_amd.build` (it builds the TORCH_LIBRARY binding '
-                               f"with torch.utils.cpp_extension), or set configs['model']['hip_host_binding'] = 'ctypes'")
+            # host glue only (no kernels): built on the spot with torch.utils.cpp_extension when a checkout carries the HIP
+            # library but not this file (~30 s, needs the host compiler); a failure is raised, never papered over
+            try:
+                from . import build
+                print(f'[simplenerf_amd] {EXT_PATH} is missing: building the TORCH_LIBRARY binding (torch.utils.cpp_extension)',
+                      file=sys.stderr, flush=True)
+                build.build_torch_extension()
+            except Exception as error:
+                raise RuntimeError(f'{EXT_PATH} is missing and could not be built ({error}); run `python -m simplenerf_amd.build`, or '
+                                   f"set configs['model']['hip_host_binding'] = 'ctypes'") from error
         if not hasattr(torch.ops, 'snerf') or not hasattr(torch.ops.snerf, 'render'):
             torch.ops.load_library(EXT_PATH)
         version = int(torch.ops.snerf.abi_version())
