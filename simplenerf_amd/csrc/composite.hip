@@ -8,6 +8,7 @@
 //
 // Bound: HBM.  Algorithmic bytes per sample: 20 read (sigma 4, rgb 12, depth 4) + 12 written when alpha,
 // visibility and weights are all requested; per ray 12-36 read, 24-32 written.
+#include "resample_device.h"
 #include "snerf_common.h"
 #include "wave.h"
 
@@ -18,9 +19,13 @@ struct CompositeArgs {
     float* out_rgb; float* out_acc; float* out_alpha; float* out_vis; float* out_weights;
     float* out_depth; float* out_depth_var; float* out_depth_ndc; float* out_depth_var_ndc;
     long long num_rays; int s; int ndc; int white;
+    // RESAMPLE: the fused K4 + K5 kernel of the main coarse level (round 3) -- the wave that composited a ray keeps its weights
+    // in LDS and goes straight on to the inverse-CDF resampling + merge of that ray (resample_device.h), instead of a second
+    // launch re-reading depths and weights from HBM: one kernel boundary (~5 us) less per render call
+    int s_f; const float* u; float* z_fine;
 };
 
-template <int C>
+template <int C, bool RESAMPLE = false>
 __global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
     const int lane = snerf::lane_id();
     const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -135,12 +140,38 @@ __global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
             a.out_depth_var_ndc[ray] = var;
         }
     }
+    if constexpr (RESAMPLE) {
+        // this ray's sample tile stays on chip: weights -> LDS, then sample_pdf + merge by the same wave (per-wave LDS:
+        // weights[s] | merged[s + s_f] | cdf[s - 1] | bins[s - 1]); the coarse depths are re-read from the row just loaded
+        extern __shared__ __attribute__((aligned(16))) float lds[];
+        float* mine = lds + (size_t)(threadIdx.x >> 6) * (s + snerf::resample_scratch_floats(s, a.s_f));
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            if (j0 + c < s) mine[j0 + c] = w[c];
+        snerf::wave_lds_sync();
+        snerf::resample_wave(zr, mine, s, a.s_f, a.u ? a.u + ray * a.s_f : nullptr, a.z_fine + ray * (s + a.s_f), mine + s, lane);
+    }
 }
 
-template <int C>
+template <int C, bool RESAMPLE = false>
 void launch(const CompositeArgs& a, hipStream_t stream) {
     const long long blocks = (a.num_rays + 3) / 4;
-    hipLaunchKernelGGL(composite_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    const size_t lds_bytes = RESAMPLE ? 4 * sizeof(float) * (size_t)(a.s + snerf::resample_scratch_floats(a.s, a.s_f)) : 0;
+    hipLaunchKernelGGL((composite_kernel<C, RESAMPLE>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a);
+}
+
+template <bool RESAMPLE>
+void launch_for_samples(const CompositeArgs& a, hipStream_t st) {
+    const int c = (a.s + 63) / 64;
+    switch (c) {
+        case 1: launch<1, RESAMPLE>(a, st); break;
+        case 2: launch<2, RESAMPLE>(a, st); break;
+        case 3: launch<3, RESAMPLE>(a, st); break;
+        case 4: launch<4, RESAMPLE>(a, st); break;
+        case 5: case 6: launch<6, RESAMPLE>(a, st); break;
+        case 7: case 8: launch<8, RESAMPLE>(a, st); break;
+        default: launch<16, RESAMPLE>(a, st); break;
+    }
 }
 
 
@@ -287,20 +318,36 @@ extern "C" int snerf_composite(const float* sigma, const float* rgb, const float
     if ((num_rays + 3) / 4 > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "composite: too many rays in one call");
     CompositeArgs a{sigma, rgb, depths, march_dirs, rays_o, rays_d, out_rgb, out_acc, out_alpha, out_visibility,
                     out_weights, out_depth, out_depth_var, out_depth_ndc, out_depth_var_ndc, num_rays, num_samples,
-                    ndc, white_bkgd};
-    hipStream_t st = (hipStream_t)stream;
-    const int c = (num_samples + 63) / 64;
-    switch (c) {
-        case 1: launch<1>(a, st); break;
-        case 2: launch<2>(a, st); break;
-        case 3: launch<3>(a, st); break;
-        case 4: launch<4>(a, st); break;
-        case 5: case 6: launch<6>(a, st); break;
-        case 7: case 8: launch<8>(a, st); break;
-        default: launch<16>(a, st); break;
-    }
+                    ndc, white_bkgd, 0, nullptr, nullptr};
+    launch_for_samples<false>(a, (hipStream_t)stream);
     return snerf::check_launch("composite");
 }
+
+// K4 + K5 in one launch (render.hip: the main coarse level of a model with a fine pass): snerf_composite's arguments -- the
+// weights output may be NULL, they stay in LDS -- plus snerf_resample_depths' (num_fine, u, depths_fine).  Same arithmetic in
+// the same order as the two separate kernels (tests/native/c_abi_smoke.cpp compares them bit for bit).  Returns
+// SNERF_E_UNSUPPORTED when the sample counts do not fit (the caller then issues the two kernels).
+namespace snerf {
+int composite_resample(const float* sigma, const float* rgb, const float* depths, const float* march_dirs, const float* rays_o,
+                       const float* rays_d, long long num_rays, int num_samples, int ndc, int white_bkgd, float* out_rgb,
+                       float* out_acc, float* out_alpha, float* out_visibility, float* out_weights, float* out_depth,
+                       float* out_depth_var, float* out_depth_ndc, float* out_depth_var_ndc, int num_fine, const float* u,
+                       float* depths_fine, hipStream_t stream) {
+    SNERF_REQUIRE(sigma && rgb && depths && march_dirs && depths_fine, "composite_resample: NULL input");
+    SNERF_REQUIRE(out_rgb && out_acc && out_depth && out_depth_var, "composite_resample: NULL required output");
+    SNERF_REQUIRE(!ndc || (rays_o && rays_d && out_depth_ndc && out_depth_var_ndc),
+                  "composite_resample: ndc needs world rays and the *_ndc outputs");
+    if (num_samples < 3 || num_fine < 1 || num_samples > 64 * 16 || (num_rays + 3) / 4 > 0x7fffffffLL ||
+        4 * sizeof(float) * (size_t)(num_samples + resample_scratch_floats(num_samples, num_fine)) > 64 * 1024)
+        return fail(SNERF_E_UNSUPPORTED, "composite_resample: %d + %d samples not built as one kernel", num_samples, num_fine);
+    if (num_rays == 0) return SNERF_OK;
+    CompositeArgs a{sigma, rgb, depths, march_dirs, rays_o, rays_d, out_rgb, out_acc, out_alpha, out_visibility,
+                    out_weights, out_depth, out_depth_var, out_depth_ndc, out_depth_var_ndc, num_rays, num_samples,
+                    ndc, white_bkgd, num_fine, u, depths_fine};
+    launch_for_samples<true>(a, stream);
+    return check_launch("composite_resample");
+}
+}  // namespace snerf
 
 extern "C" int snerf_composite_backward(const float* sigma, const float* rgb, const float* depths, const float* march_dirs,
                                         const float* rays_o, const float* rays_d, long long num_rays, int num_samples,

@@ -171,6 +171,9 @@ __device__ __forceinline__ void constexpr_fetch(const SlabStream<WT>& st, int sl
 #pragma unroll
     for (int i = 0; i < WT; ++i)
         if (slot == i * EVERY) {
+#ifdef SNERF_ABL_F32_NODMA       // ablation probe: no weight stream (the slabs hold whatever the first request left)
+            continue;
+#endif
             const int chunk = i * 4 + st.wave;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st.cur + chunk * 256 + st.lane * 4),
                                              (__attribute__((address_space(3))) void*)(st.lds + st.parity * SlabStream<WT>::kBufFloats + chunk * 256),

@@ -6,6 +6,14 @@
 
 #include "snerf_common.h"
 
+namespace snerf {   // composite.hip: K4 + K5 of the main coarse level as one launch
+int composite_resample(const float* sigma, const float* rgb, const float* depths, const float* march_dirs, const float* rays_o,
+                       const float* rays_d, long long num_rays, int num_samples, int ndc, int white_bkgd, float* out_rgb,
+                       float* out_acc, float* out_alpha, float* out_visibility, float* out_weights, float* out_depth,
+                       float* out_depth_var, float* out_depth_ndc, float* out_depth_var_ndc, int num_fine, const float* u,
+                       float* depths_fine, hipStream_t stream);
+}
+
 namespace {
 
 struct Marching {
@@ -66,7 +74,15 @@ extern "C" int snerf_render_forward(const snerf_render_config* cfg, const snerf_
     const Marching m = cfg->ndc ? Marching{rays->rays_o_ndc, rays->rays_d_ndc} : Marching{rays->rays_o, rays->rays_d};
     const bool fine = mlps[SNERF_LEVEL_MAIN_FINE].desc != nullptr;
     float* coarse_weights = out->level[0].weights;
-    if (fine && !rays->depths_fine && !coarse_weights) {
+    // the main coarse level of a model with a fine pass: compositing and resampling in ONE kernel, the ray's weights handed
+    // over in LDS (no predict_visibility on that level: its visibility2 compositing reads the weights from memory)
+#ifdef SNERF_PROBE_NO_K4K5_FUSION
+    const bool fuse_resample = false;
+#else
+    const bool fuse_resample = fine && !rays->depths_fine && !mlps[0].desc->predict_visibility && cfg->num_coarse >= 3 &&
+                               sizeof(float) * 4 * (size_t)(2 * cfg->num_coarse + cfg->num_fine + 2 * (cfg->num_coarse - 1)) <= 64 * 1024;
+#endif
+    if (fine && !rays->depths_fine && !coarse_weights && !fuse_resample) {
         SNERF_REQUIRE(workspace, "render_forward: workspace is required (main coarse weights feed the resampling)");
         coarse_weights = workspace;
     }
@@ -105,6 +121,11 @@ extern "C" int snerf_render_forward(const snerf_render_config* cfg, const snerf_
                      : snerf_mlp_forward(mlps[l].desc, mlps[l].packed, m.origins, m.dirs, dirs, depths, n, samples,
                                          rays->sigma_noise[l], o.sigma, o.raw_rgb, cfg->precision, stream);
         if (st != SNERF_OK) return st;
+        if (l == 0 && fuse_resample)
+            return snerf::composite_resample(o.sigma, o.raw_rgb, depths, m.dirs, cfg->ndc ? rays->rays_o : nullptr,
+                                             cfg->ndc ? rays->rays_d : nullptr, n, samples, cfg->ndc, cfg->white_bkgd, o.rgb,
+                                             o.acc, o.alpha, o.visibility, level_weights, o.depth, o.depth_var, o.depth_ndc,
+                                             o.depth_var_ndc, cfg->num_fine, rays->u, out->depths_fine, (hipStream_t)stream);
         return snerf_composite(o.sigma, o.raw_rgb, depths, m.dirs, cfg->ndc ? rays->rays_o : nullptr,
                                cfg->ndc ? rays->rays_d : nullptr, n, samples, cfg->ndc, cfg->white_bkgd, o.rgb, o.acc, o.alpha,
                                o.visibility, level_weights, o.depth, o.depth_var, o.depth_ndc, o.depth_var_ndc, stream);
@@ -120,9 +141,11 @@ extern "C" int snerf_render_forward(const snerf_render_config* cfg, const snerf_
     if (!fine) return SNERF_OK;
     const float* depths_fine = rays->depths_fine;
     if (!depths_fine) {
-        rc = snerf_resample_depths(out->depths_coarse, coarse_weights, n, cfg->num_coarse, cfg->num_fine, rays->u,
-                                   out->depths_fine, stream);
-        if (rc != SNERF_OK) return rc;
+        if (!fuse_resample) {     // (else the main coarse level's kernel has written them already)
+            rc = snerf_resample_depths(out->depths_coarse, coarse_weights, n, cfg->num_coarse, cfg->num_fine, rays->u,
+                                       out->depths_fine, stream);
+            if (rc != SNERF_OK) return rc;
+        }
         depths_fine = out->depths_fine;
     }
     for (int l = 3; l < SNERF_RENDER_LEVELS; ++l) {
