@@ -438,21 +438,18 @@ def training_step(precision, rank, world, device, single_pass=False, graphed=Fal
     state = {'iter': 20000}
 
     graph = None
-    if graphed:      # the device work of the pass (re-pack, forwards, losses, backward) replayed from ONE HIP graph
+    if graphed:      # the WHOLE iteration -- batch assembly, draws, pass, Adam -- replayed from ONE HIP graph (GraphedIteration)
         if world > 1:
-            raise SystemExit('the graphed training step is a single-GPU measurement')
-        graph = harness.GraphedTrainStep(model, losses, batcher.get_next_batch(state['iter']), sub_batch_size=cfg['sub_batch_size'])
-        batcher = BatchAssembler(cfg, synth.training_scene(), device, rank=rank, world_size=world)
+            raise SystemExit('the graphed training iteration is a single-GPU measurement')
+        graph = harness.GraphedIteration(model, losses, opt, batcher, decayer, sub_batch_size=cfg['sub_batch_size'])
 
     def step():
         it = state['iter']
         state['iter'] += 1
+        if graph is not None:
+            return graph(it)
         for group in opt.param_groups:
             group['lr'] = decayer.get_updated_learning_rate(it)
-        if graph is not None:
-            totals = graph(batcher.get_next_batch(it))
-            opt.step()
-            return totals
         return harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it), cfg['sub_batch_size'], world,
                                       single_pass=single_pass)
 
@@ -518,7 +515,8 @@ def training_record(device, steps=10, warmup=3):
     # the same iteration issued two other ways, 16-bit mode (what changes is the host side and the launch count, not the
     # kernels): ONE model pass over the 4096 rows with the losses still normalised per 2048-row sub-batch
     # (harness.train_one_iter single_pass: same objective, the reference sub-batches only for device memory), and the
-    # sub-batched pass replayed from one HIP graph (harness.GraphedTrainStep: bit-identical to the eager iteration)
+    # whole sub-batched iteration -- batch assembly, draws, pass, Adam -- replayed from ONE HIP graph
+    # (harness.GraphedIteration: parameters bit-identical to the eager iterations')
     for name, kwargs in (('f16_single_pass', {'single_pass': True}), ('f16_graphed', {'graphed': True})):
         ms, fwd_ms, bwd_ms, rows = time_training('f16', device, steps, warmup, **kwargs)
         tflops = rows * TRAIN_FLOP_PER_RAY / (ms * 1e-3) / 1e12

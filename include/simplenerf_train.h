@@ -180,6 +180,46 @@ int snerf_adam_step(float* const* params, const float* const* grads, float* cons
                     const long long* sizes, int num_tensors, long long step, double lr, double beta1, double beta2,
                     double eps, snerf_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * G1  per-iteration scalars in DEVICE memory (round 3), so that batch assembly, the training draws and the optimiser step
+ * can be part of a captured HIP graph: a replayed graph cannot change kernel arguments, but the position in the epoch, the
+ * iteration number that keys the draws and Adam's step-dependent factors change every iteration.  The host writes them,
+ * ahead of time, into a ring of `snerf_iteration` records in PINNED host memory; the first node of the graph,
+ * snerf_iteration_advance, copies record (counter mod ring_slots) into the device-resident `current` record and increments
+ * the device-resident counter; the `_at` variants below read `current` instead of taking the scalars as arguments.  The
+ * host must not run more than ring_slots - 1 replays ahead of the device (it fills slot i mod ring_slots for replay i).
+ * Same arithmetic as the scalar-argument entry points, bit for bit.
+ */
+typedef struct snerf_iteration {
+    long long iter_num;                      /* trainer iteration: draws use stream iter_num * num_kinds + kind */
+    long long pixel_epoch, pixel_first;      /* this iteration's pixel rows: positions pixel_first.. of epoch pixel_epoch */
+    long long sparse_epoch, sparse_first;    /* ... and its sparse-depth rows */
+    float adam_neg_step_size;                /* -(lr / (1 - beta1^step)), evaluated in double by the host (as snerf_adam_step) */
+    float adam_bias2_sqrt;                   /* sqrt(1 - beta2^step) */
+    long long reserved[2];
+} snerf_iteration;
+
+/*   ring      PINNED host memory visible to the device (hipHostMalloc / torch pin_memory), ring_slots records
+ *   counter   device, one unsigned 64-bit word (0 before the first replay)      current   device, one record */
+int snerf_iteration_advance(const snerf_iteration* ring, int ring_slots, unsigned long long* counter,
+                            snerf_iteration* current, snerf_stream_t stream);
+/* snerf_shuffled_indices with (epoch, first) = current->{pixel,sparse}_{epoch,first} + first_offset (a rank's shard of the
+ * slice); `sparse` selects the pair.  The caller guarantees that the slice lies inside the epoch (the host knows). */
+int snerf_shuffled_indices_at(unsigned long long seed, const snerf_iteration* current, int sparse, long long first_offset,
+                              long long count, long long domain, const long long* candidates, int num_views, int height,
+                              int width, int crop_y0, int crop_y1, int crop_x0, int crop_x1, long long* out,
+                              snerf_stream_t stream);
+/* snerf_random_uniform / _normal with stream_id = current->iter_num * num_kinds + kind */
+int snerf_random_uniform_at(unsigned long long seed, const snerf_iteration* current, int kind, int num_kinds, long long first_row,
+                            const long long* row_ids, long long num_rows, int row_width, float* out, snerf_stream_t stream);
+int snerf_random_normal_at(unsigned long long seed, const snerf_iteration* current, int kind, int num_kinds, long long first_row,
+                           const long long* row_ids, long long num_rows, int row_width, float scale, float* out,
+                           snerf_stream_t stream);
+/* snerf_adam_step with the two step-dependent factors taken from `current` */
+int snerf_adam_step_at(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                       const long long* sizes, int num_tensors, const snerf_iteration* current, double beta1, double beta2,
+                       double eps, snerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

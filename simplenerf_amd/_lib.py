@@ -15,6 +15,9 @@ LIB_PATH = os.path.join(_HERE, 'libsimplenerf_hip.so')
 ABI_VERSION = 7
 
 
+ITERATION_WORDS = 8      # struct snerf_iteration as 64-bit words (include/simplenerf_train.h)
+
+
 class MlpDesc(ctypes.Structure):
     """struct snerf_mlp_desc"""
     _fields_ = [(name, c_int) for name in (
@@ -138,6 +141,15 @@ SIGNATURES = {
     'snerf_adam_step': (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                 POINTER(c_longlong), c_int, c_longlong, c_double, c_double, c_double, c_double,
                                 c_void_p]),
+    # per-iteration scalars in device memory (whole-iteration HIP graphs)
+    'snerf_iteration_advance': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'snerf_shuffled_indices_at': (c_int, [c_ulonglong, c_void_p, c_int, c_longlong, c_longlong, c_longlong, c_void_p, c_int,
+                                          c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'snerf_random_uniform_at': (c_int, [c_ulonglong, c_void_p, c_int, c_int, c_longlong, c_void_p, c_longlong, c_int, _FP, c_void_p]),
+    'snerf_random_normal_at': (c_int, [c_ulonglong, c_void_p, c_int, c_int, c_longlong, c_void_p, c_longlong, c_int, c_float, _FP,
+                                       c_void_p]),
+    'snerf_adam_step_at': (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                   POINTER(c_longlong), c_int, c_void_p, c_double, c_double, c_double, c_void_p]),
 }
 
 _lib = None

@@ -24,9 +24,14 @@ struct AdamTable {
     unsigned first_block[kTensorsPerLaunch + 1];
     int count;
     float one_minus_beta1, beta2, one_minus_beta2, neg_step_size, bias2_sqrt, eps;
+    const snerf_iteration* at;     // snerf_adam_step_at: the two step-dependent factors come from the device-resident record
 };
 
 __global__ void __launch_bounds__(256) adam_kernel(AdamTable t) {
+    if (t.at) {
+        t.neg_step_size = t.at->adam_neg_step_size;
+        t.bias2_sqrt = t.at->adam_bias2_sqrt;
+    }
     int lo = 0, hi = t.count;                     // largest i with first_block[i] <= blockIdx.x
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -54,21 +59,26 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamTable t) {
 
 }  // namespace
 
-extern "C" int snerf_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
-                               float* const* exp_avg_sq, const long long* sizes, int num_tensors, long long step,
-                               double lr, double beta1, double beta2, double eps, snerf_stream_t stream) {
+static int adam_impl(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                     const long long* sizes, int num_tensors, long long step, double lr, double beta1, double beta2, double eps,
+                     const snerf_iteration* at, snerf_stream_t stream) {
     SNERF_REQUIRE(params && grads && exp_avg && exp_avg_sq && sizes, "adam_step: NULL table");
     SNERF_REQUIRE(num_tensors >= 0, "adam_step: negative tensor count");
-    SNERF_REQUIRE(step >= 1, "adam_step: step must be >= 1, got %lld", step);
+    SNERF_REQUIRE(at || step >= 1, "adam_step: step must be >= 1, got %lld", step);
     SNERF_REQUIRE(beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0, "adam_step: bad hyper-parameters");
-    // python: bias_correction = 1 - beta ** step ; step_size = lr / bc1 ; bc2 ** 0.5   (all in double)
-    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
     AdamTable t;
+    t.at = at;
     t.one_minus_beta1 = (float)(1.0 - beta1);
     t.beta2 = (float)beta2;
     t.one_minus_beta2 = (float)(1.0 - beta2);
-    t.neg_step_size = (float)(-(lr / bc1));
-    t.bias2_sqrt = (float)std::pow(bc2, 0.5);
+    t.neg_step_size = 0.0f;
+    t.bias2_sqrt = 1.0f;
+    if (!at) {
+        // python: bias_correction = 1 - beta ** step ; step_size = lr / bc1 ; bc2 ** 0.5   (all in double)
+        const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+        t.neg_step_size = (float)(-(lr / bc1));
+        t.bias2_sqrt = (float)std::pow(bc2, 0.5);
+    }
     t.eps = (float)eps;
     int i = 0;
     while (i < num_tensors) {
@@ -93,4 +103,17 @@ extern "C" int snerf_adam_step(float* const* params, const float* const* grads, 
         if (int st = snerf::check_launch("adam_step")) return st;
     }
     return SNERF_OK;
+}
+
+extern "C" int snerf_adam_step(float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const long long* sizes, int num_tensors, long long step,
+                               double lr, double beta1, double beta2, double eps, snerf_stream_t stream) {
+    return adam_impl(params, grads, exp_avg, exp_avg_sq, sizes, num_tensors, step, lr, beta1, beta2, eps, nullptr, stream);
+}
+
+extern "C" int snerf_adam_step_at(float* const* params, const float* const* grads, float* const* exp_avg,
+                                  float* const* exp_avg_sq, const long long* sizes, int num_tensors,
+                                  const snerf_iteration* current, double beta1, double beta2, double eps, snerf_stream_t stream) {
+    SNERF_REQUIRE(current, "adam_step_at: NULL iteration record");
+    return adam_impl(params, grads, exp_avg, exp_avg_sq, sizes, num_tensors, 0, 0.0, beta1, beta2, eps, current, stream);
 }

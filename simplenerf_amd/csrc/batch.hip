@@ -91,12 +91,24 @@ constexpr int kFeistelRounds = 8;
 
 struct ShuffleArgs {
     unsigned keys[kFeistelRounds];
+    // `at` != NULL (snerf_shuffled_indices_at): epoch and first come from the device-resident iteration record -- the keys are
+    // then derived in the kernel (the same splitmix64 the host evaluates) and `first` is the shard offset added to its position
+    const snerf_iteration* at;
+    unsigned long long seed;
+    int sparse;
     long long first, count, domain;
     const long long* candidates;
     int half_bits;
     int height, width, crop_y0, crop_x0, crop_h, crop_w;
     long long* out;
 };
+
+__host__ __device__ inline unsigned long long splitmix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
 
 __host__ __device__ inline unsigned mix32(unsigned h) {   // murmur3 finaliser
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
@@ -107,12 +119,23 @@ __global__ void __launch_bounds__(256) shuffled_indices_kernel(ShuffleArgs a) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.count) return;
     const unsigned long long mask = (1ull << a.half_bits) - 1ull;
-    unsigned long long x = (unsigned long long)(a.first + j);
+    unsigned keys[kFeistelRounds];
+    long long first = a.first;
+    if (a.at) {
+        const unsigned long long epoch = (unsigned long long)(a.sparse ? a.at->sparse_epoch : a.at->pixel_epoch);
+        first += a.sparse ? a.at->sparse_first : a.at->pixel_first;
+#pragma unroll
+        for (int r = 0; r < kFeistelRounds; ++r) keys[r] = (unsigned)splitmix64(a.seed ^ splitmix64(epoch * kFeistelRounds + r));
+    } else {
+#pragma unroll
+        for (int r = 0; r < kFeistelRounds; ++r) keys[r] = a.keys[r];
+    }
+    unsigned long long x = (unsigned long long)(first + j);
     do {   // cycle walking: the network permutes [0, 2^(2 half_bits)); re-apply until the image falls inside the domain
         unsigned long long left = x >> a.half_bits, right = x & mask;
 #pragma unroll
         for (int r = 0; r < kFeistelRounds; ++r) {
-            const unsigned long long next = left ^ ((unsigned long long)mix32((unsigned)right + a.keys[r]) & mask);
+            const unsigned long long next = left ^ ((unsigned long long)mix32((unsigned)right + keys[r]) & mask);
             left = right;
             right = next;
         }
@@ -130,12 +153,6 @@ __global__ void __launch_bounds__(256) shuffled_indices_kernel(ShuffleArgs a) {
     a.out[j] = index;
 }
 
-inline unsigned long long splitmix64(unsigned long long z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 struct Philox { unsigned v[4]; };
@@ -151,10 +168,13 @@ __device__ __forceinline__ Philox philox4x32_10(unsigned c0, unsigned c1, unsign
     return Philox{{c0, c1, c2, c3}};
 }
 
+// `at` != NULL (the _at entry points): stream_id = at->iter_num * num_kinds + kind, with (kind, num_kinds) passed in
+// `stream_id` as kind | num_kinds << 16
 template <bool NORMAL>
 __global__ void __launch_bounds__(256) random_kernel(unsigned seed_lo, unsigned seed_hi, unsigned stream_id, long long first_row,
                                                      const long long* __restrict__ row_ids, long long num_rows, int row_width,
-                                                     float scale, float* __restrict__ out) {
+                                                     float scale, float* __restrict__ out, const snerf_iteration* __restrict__ at) {
+    if (at) stream_id = (unsigned)((unsigned long long)at->iter_num * (stream_id >> 16) + (stream_id & 0xffffu));
     const int blocks_per_row = (row_width + 3) / 4;
     const long long total = num_rows * blocks_per_row;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -187,7 +207,8 @@ __global__ void __launch_bounds__(256) random_kernel(unsigned seed_lo, unsigned 
 }
 
 int launch_random(bool normal, unsigned long long seed, unsigned stream_id, long long first_row, const long long* row_ids,
-                  long long num_rows, int row_width, float scale, float* out, snerf_stream_t stream) {
+                  long long num_rows, int row_width, float scale, float* out, snerf_stream_t stream,
+                  const snerf_iteration* at = nullptr) {
     SNERF_REQUIRE(out, "random draws: NULL output");
     SNERF_REQUIRE(num_rows >= 0 && row_width >= 1 && first_row >= 0, "random draws: bad shape (%lld rows from %lld, width %d)",
                   num_rows, first_row, row_width);
@@ -196,10 +217,10 @@ int launch_random(bool normal, unsigned long long seed, unsigned stream_id, long
     const dim3 grid(snerf::stride_grid(work, 256)), block(256);
     if (normal)
         hipLaunchKernelGGL(random_kernel<true>, grid, block, 0, (hipStream_t)stream, (unsigned)seed, (unsigned)(seed >> 32),
-                           stream_id, first_row, row_ids, num_rows, row_width, scale, out);
+                           stream_id, first_row, row_ids, num_rows, row_width, scale, out, at);
     else
         hipLaunchKernelGGL(random_kernel<false>, grid, block, 0, (hipStream_t)stream, (unsigned)seed, (unsigned)(seed >> 32),
-                           stream_id, first_row, row_ids, num_rows, row_width, scale, out);
+                           stream_id, first_row, row_ids, num_rows, row_width, scale, out, at);
     return snerf::check_launch("random draws");
 }
 
@@ -235,15 +256,16 @@ extern "C" int snerf_assemble_batch(const long long* indices, long long num_rays
     return snerf::check_launch("assemble_batch");
 }
 
-extern "C" int snerf_shuffled_indices(unsigned long long seed, unsigned long long epoch, long long first, long long count,
-                                      long long domain, const long long* candidates, int num_views, int height, int width,
-                                      int crop_y0, int crop_y1, int crop_x0, int crop_x1, long long* out,
-                                      snerf_stream_t stream) {
+static int shuffled_indices_impl(unsigned long long seed, unsigned long long epoch, long long first, long long count,
+                                 long long domain, const long long* candidates, int num_views, int height, int width,
+                                 int crop_y0, int crop_y1, int crop_x0, int crop_x1, long long* out, snerf_stream_t stream,
+                                 const snerf_iteration* at, int sparse) {
     SNERF_REQUIRE(out, "shuffled_indices: NULL output");
     SNERF_REQUIRE(domain >= 1 && domain < (1LL << 62), "shuffled_indices: domain %lld outside [1, 2^62)", domain);
     SNERF_REQUIRE(first >= 0 && count >= 0 && first + count <= domain,
                   "shuffled_indices: positions [%lld, %lld) outside the epoch of %lld", first, first + count, domain);
     ShuffleArgs a;
+    a.at = at; a.seed = seed; a.sparse = sparse;
     if (!candidates) {
         SNERF_REQUIRE(num_views >= 1 && crop_y0 >= 0 && crop_y0 < crop_y1 && crop_y1 <= height && crop_x0 >= 0 &&
                       crop_x0 < crop_x1 && crop_x1 <= width, "shuffled_indices: bad crop window [%d,%d)x[%d,%d) of %dx%d",
@@ -264,6 +286,57 @@ extern "C" int snerf_shuffled_indices(unsigned long long seed, unsigned long lon
     a.out = out;
     hipLaunchKernelGGL(shuffled_indices_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return snerf::check_launch("shuffled_indices");
+}
+
+extern "C" int snerf_shuffled_indices(unsigned long long seed, unsigned long long epoch, long long first, long long count,
+                                      long long domain, const long long* candidates, int num_views, int height, int width,
+                                      int crop_y0, int crop_y1, int crop_x0, int crop_x1, long long* out,
+                                      snerf_stream_t stream) {
+    return shuffled_indices_impl(seed, epoch, first, count, domain, candidates, num_views, height, width, crop_y0, crop_y1,
+                                 crop_x0, crop_x1, out, stream, nullptr, 0);
+}
+
+extern "C" int snerf_shuffled_indices_at(unsigned long long seed, const snerf_iteration* current, int sparse, long long first_offset,
+                                         long long count, long long domain, const long long* candidates, int num_views,
+                                         int height, int width, int crop_y0, int crop_y1, int crop_x0, int crop_x1,
+                                         long long* out, snerf_stream_t stream) {
+    SNERF_REQUIRE(current, "shuffled_indices_at: NULL iteration record");
+    return shuffled_indices_impl(seed, 0, first_offset, count, domain, candidates, num_views, height, width, crop_y0, crop_y1,
+                                 crop_x0, crop_x1, out, stream, current, sparse ? 1 : 0);
+}
+
+// G1: the first node of a replayed training graph -- record (counter mod slots) of the host's pinned ring becomes the current one
+namespace {
+__global__ void iteration_advance_kernel(const snerf_iteration* __restrict__ ring, int slots, unsigned long long* counter,
+                                         snerf_iteration* __restrict__ current) {
+    const unsigned long long c = *counter;
+    *current = ring[c % (unsigned long long)slots];
+    *counter = c + 1;
+}
+}  // namespace
+
+extern "C" int snerf_iteration_advance(const snerf_iteration* ring, int ring_slots, unsigned long long* counter,
+                                       snerf_iteration* current, snerf_stream_t stream) {
+    SNERF_REQUIRE(ring && counter && current, "iteration_advance: NULL pointer");
+    SNERF_REQUIRE(ring_slots >= 2, "iteration_advance: the ring needs at least two slots, got %d", ring_slots);
+    hipLaunchKernelGGL(iteration_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ring, ring_slots, counter, current);
+    return snerf::check_launch("iteration_advance");
+}
+
+extern "C" int snerf_random_uniform_at(unsigned long long seed, const snerf_iteration* current, int kind, int num_kinds,
+                                       long long first_row, const long long* row_ids, long long num_rows, int row_width,
+                                       float* out, snerf_stream_t stream) {
+    SNERF_REQUIRE(current && kind >= 0 && num_kinds > kind && num_kinds < 65536, "random_uniform_at: bad record / kind %d of %d", kind, num_kinds);
+    return launch_random(false, seed, (unsigned)kind | ((unsigned)num_kinds << 16), first_row, row_ids, num_rows, row_width, 1.0f, out,
+                         stream, current);
+}
+
+extern "C" int snerf_random_normal_at(unsigned long long seed, const snerf_iteration* current, int kind, int num_kinds,
+                                      long long first_row, const long long* row_ids, long long num_rows, int row_width, float scale,
+                                      float* out, snerf_stream_t stream) {
+    SNERF_REQUIRE(current && kind >= 0 && num_kinds > kind && num_kinds < 65536, "random_normal_at: bad record / kind %d of %d", kind, num_kinds);
+    return launch_random(true, seed, (unsigned)kind | ((unsigned)num_kinds << 16), first_row, row_ids, num_rows, row_width, scale, out,
+                         stream, current);
 }
 
 extern "C" int snerf_random_uniform(unsigned long long seed, unsigned int stream_id, long long first_row,

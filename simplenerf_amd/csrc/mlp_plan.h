@@ -250,12 +250,19 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
         }
         hoff += 24 * 512;
         plan.m16_offset = hoff;
-        for (MlpPlan::HalfStage st : plan.half_stages) {
-            st.dst = hoff;
-            hoff += (long long)st.tiles * st.unit_floats;
-            plan.m16_stages.push_back(st);
+        // only for the layout mlp_forward_m16.hip is built for (the view-dependent 8 x 256 main MLP): the other MLPs' copies
+        // were never read, yet written by every re-pack -- after every optimiser step -- and paid for in stream memory
+        // 
+        const bool m16_layout = plan.view_dependent && !plan.sigma_pe && plan.depth == 8 && plan.wt == 8 && plan.vt == 4 &&
+                                plan.views_out_rows == 3;
+        if (m16_layout) {
+            for (MlpPlan::HalfStage st : plan.half_stages) {
+                st.dst = hoff;
+                hoff += (long long)st.tiles * st.unit_floats;
+                plan.m16_stages.push_back(st);
+            }
+            hoff += 24 * 512;  // prefetch runway
         }
-        hoff += 24 * 512;  // prefetch runway
         off = hoff;
     }
     plan.total_floats = (off + 63) / 64 * 64;

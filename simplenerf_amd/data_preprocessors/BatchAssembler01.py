@@ -93,33 +93,56 @@ class BatchAssembler:
         lo = min(count, self.rank * per)
         return first + lo, min(count, lo + per) - lo, lo
 
-    def select_batch_indices(self, iter_num: int, image_num: Optional[int] = None):
+    def next_positions(self) -> Dict[str, tuple]:
+        """Advance the epoch cursors by one batch (reference :559-563) and return where it sits: ``{'pixel': (epoch, first,
+        count)[, 'sparse': (epoch, first, count)]}`` -- ``count`` is shorter than the configured batch at the end of an epoch."""
+        first, total, self.i_batch, epoch = self._next_slice(self.i_batch, self.epoch, self.num_rays, self.domain)
+        positions = {'pixel': (self.epoch, first, total)}
+        self.epoch = epoch
+        if self.sparse_depth_needed:
+            domain = self.sparse_candidates.shape[0]
+            first, total_sd, self.i_batch_sparse_depth, epoch = self._next_slice(self.i_batch_sparse_depth, self.epoch_sparse,
+                                                                                 self.num_rays_sparse_depth, domain)
+            positions['sparse'] = (self.epoch_sparse, first, total_sd)
+            self.epoch_sparse = epoch
+        return positions
+
+    def is_full(self, positions: Dict[str, tuple]) -> bool:
+        return positions['pixel'][2] == self.num_rays and (not self.sparse_depth_needed or
+                                                           positions['sparse'][2] == self.num_rays_sparse_depth)
+
+    def select_batch_indices(self, iter_num: int, image_num: Optional[int] = None, positions: Optional[Dict[str, tuple]] = None,
+                             at: Optional[Tensor] = None):
         """-> (indices int64 GPU tensor, number of pixel-ray rows, sparse rows present?, (first global pixel row, first global
-        sparse row))   (reference :553-584)"""
+        sparse row))   (reference :553-584).  ``positions``: where the batch sits (default: the next one, advancing the
+        cursors).  ``at``: the device-resident iteration record to read epoch and position from instead (a FULL batch inside a
+        captured graph: the counts are the configured ones)."""
         h, w = self.resolution
         if image_num is not None:
             image_index = self.frame_nums.index(int(image_num))
             first, count, lo = self._shard(image_index * h * w, h * w)
             return torch.arange(first, first + count, dtype=torch.int64, device=self.device), count, False, (lo, lo + count)
-        first, total, self.i_batch, epoch = self._next_slice(self.i_batch, self.epoch, self.num_rays, self.domain)
+        if at is not None:
+            epoch, first, total = 0, 0, self.num_rays
+        else:
+            positions = positions if positions is not None else self.next_positions()
+            epoch, first, total = positions['pixel']
         first, count, lo = self._shard(first, total)
-        indices = ops.shuffled_indices(self.seed, self.epoch, first, count, self.domain, self.device,
-                                       num_views=self.num_views, resolution=self.resolution, crop=self.crop)
-        self.epoch = epoch
+        indices = ops.shuffled_indices(self.seed, epoch, first, count, self.domain, self.device, num_views=self.num_views,
+                                       resolution=self.resolution, crop=self.crop, at=at)
         if not self.sparse_depth_needed:
             return indices, count, False, (lo, lo + count)
         domain = self.sparse_candidates.shape[0]
-        first, total_sd, self.i_batch_sparse_depth, epoch = self._next_slice(self.i_batch_sparse_depth, self.epoch_sparse,
-                                                                             self.num_rays_sparse_depth, domain)
+        epoch, first, total_sd = (0, 0, self.num_rays_sparse_depth) if at is not None else positions['sparse']
         first, n_sd, lo_sd = self._shard(first, total_sd)
-        sparse = ops.shuffled_indices(self.seed + 1, self.epoch_sparse, first, n_sd, domain, self.device,
-                                      candidates=self.sparse_candidates)
-        self.epoch_sparse = epoch
+        sparse = ops.shuffled_indices(self.seed + 1, epoch, first, n_sd, domain, self.device, candidates=self.sparse_candidates,
+                                      at=at, sparse=True)
         # global rows: the single-process batch is [all pixel rows (total) | all sparse rows (total_sd)]
         return torch.cat([indices, sparse]), count, True, (lo, total + lo_sd)
 
     def get_next_batch(self, iter_num: int, image_num: Optional[int] = None, indices: Optional[Tensor] = None,
-                       indices_sparse: Optional[Tensor] = None) -> Dict[str, object]:
+                       indices_sparse: Optional[Tensor] = None, positions: Optional[Dict[str, tuple]] = None,
+                       at: Optional[Tensor] = None) -> Dict[str, object]:
         if indices is not None:     # replay a given order (parity with the reference's numpy stream)
             with_sparse = indices_sparse is not None
             num_pixel = indices.shape[0]
@@ -127,7 +150,7 @@ class BatchAssembler:
             indices = indices.to(self.device, torch.int64)
             first_rows = (0, num_pixel)
         else:
-            indices, num_pixel, with_sparse, first_rows = self.select_batch_indices(iter_num, image_num)
+            indices, num_pixel, with_sparse, first_rows = self.select_batch_indices(iter_num, image_num, positions, at)
         sp = self.sparse if with_sparse else {k: None for k in self.sparse}
         batch = ops.assemble_batch(indices, num_pixel, self.table, self.resolution, self.images, self.ndc, self.near, self.far,
                                    self.near_ndc, self.far_ndc, sp['sparse_depths'], sp['sparse_errors'],

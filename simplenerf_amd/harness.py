@@ -381,6 +381,131 @@ class GraphedTrainStep:
         return self.totals
 
 
+class GraphedIteration:
+    """The WHOLE training iteration as ONE HIP graph (round 3): batch assembly (index permutation + ray
+    assembly), the training draws, weight re-pack, every MLP forward, compositing / resampling, the loss table, the complete
+    backward AND the Adam update -- ``GraphedTrainStep`` replayed only the pass in between, with batch copy, draws and optimiser
+    enqueued from Python around it.  What changes from iteration to iteration cannot be a kernel argument of a replayed graph,
+    so it lives in device memory: the graph's first node (``snerf_iteration_advance``) copies the next record of a pinned host
+    ring -- epoch positions of the pixel and sparse-depth slices, the iteration number that keys the Philox draws, Adam's two
+    step-dependent factors with the decayed learning rate folded in -- into the device-resident record that
+    ``snerf_shuffled_indices_at`` / ``snerf_random_*_at`` / ``snerf_adam_step_at`` read.  Per iteration the host writes one
+    64-byte record and launches one graph: parameters after N iterations are bit-identical to N eager
+    ``train_one_iter`` iterations (tests/test_gpu_optim.py).
+
+    A short batch at the end of an epoch (other tensor shapes) runs eagerly into the graph's static gradient buffers, as
+    ``GraphedTrainStep`` does; the graph is re-captured when ``LossComputer.get_loss_weight`` changes the loss weights.  Single
+    process (the gradient all-reduce of a multi-rank run is not captured).  The host may run at most ``slots - 1`` replays ahead
+    of the device: the slot about to be overwritten is guarded by an event."""
+
+    def __init__(self, model, loss_computer, optimizer, batcher, lr_decayer=None, sub_batch_size: Optional[int] = None,
+                 slots: int = 8, warmup: int = 1):
+        if getattr(batcher, 'world_size', 1) != 1:
+            raise NotImplementedError('GraphedIteration is a single-process path (use GraphedTrainStep + allreduce_gradients)')
+        self.model, self.losses, self.opt, self.batcher, self.decayer = model, loss_computer, optimizer, batcher, lr_decayer
+        self.device = batcher.device
+        self.ring = ops.IterationRing(self.device, slots)
+        self.events = [None] * slots
+        self.sub = int(sub_batch_size) if sub_batch_size else None
+        self.warmup = warmup
+        self.graph = None
+        self.weights_key = None
+        self.totals: Dict[str, Tensor] = {}
+        self.wait_seconds = 0.0           # time the host spent waiting for a ring slot (it was >= slots - 1 replays ahead)
+
+    def _weights(self, iter_num):
+        return tuple(self.losses.get_loss_weight(cfg, iter_num) for cfg in self.losses.losses.values())
+
+    def _passes(self, batch, draws_at) -> Dict[str, Tensor]:
+        """model -> losses -> backward per sub-batch (gradients accumulate in the kernels), totals summed."""
+        n = batch['rays_o'].shape[0]
+        sub = self.sub or n
+        rows = batch['global_rows']
+        totals: Dict[str, Tensor] = {}
+        for start in range(0, n, sub):
+            count = min(sub, n - start)
+            self.model.set_random_draws(self.model.draw_training_randomness(count, rows[start:start + count], self.device,
+                                                                            iter_num=batch.get('iter_num'), at=draws_at))
+            piece = {k: (v[start:start + count] if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+            piece['common_data'] = dict(batch.get('common_data', {}))
+            losses = self.losses.compute_losses(piece, self.model(piece))
+            losses['TotalLoss'].backward()
+            for name, entry in losses.items():
+                value = (entry['loss_value'] if isinstance(entry, dict) else entry).detach()
+                totals[name] = totals[name] + value if name in totals else value
+        return totals
+
+    def _body(self, iter_num: int, whole: bool) -> Dict[str, Tensor]:
+        if whole:
+            self.ring.advance()
+        batch = self.batcher.get_next_batch(iter_num, at=self.ring.current)
+        totals = self._passes(batch, self.ring.current)
+        if whole:
+            self.opt.step_at(self.ring.current)
+        return totals
+
+    def _capture(self, iter_num: int):
+        # optimiser state must exist BEFORE the capture (created inside it, its zero fill would be replayed every iteration)
+        for group in self.opt.param_groups:
+            for p in group['params']:
+                if p.requires_grad and len(self.opt.state[p]) == 0:
+                    self.opt.state[p]['step'] = torch.tensor(0.0, dtype=torch.float32)
+                    self.opt.state[p]['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    self.opt.state[p]['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):          # eager warm-up on a side stream, as torch's graph capture requires: the pass
+            for _ in range(self.warmup):       # only -- no ring advance, no optimiser step
+                self._body(iter_num, whole=False)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        for p in self.model.parameters():
+            p.grad = None                      # gradients are (re)allocated inside the capture: static addresses
+        self.model.invalidate_packed()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.totals = self._body(iter_num, whole=True)
+
+    def __call__(self, iter_num: int) -> Dict[str, Tensor]:
+        positions = self.batcher.next_positions()
+        lr = None
+        if self.decayer is not None:
+            lr = self.decayer.get_updated_learning_rate(iter_num)
+            for group in self.opt.param_groups:
+                group['lr'] = lr
+        lr = self.opt.param_groups[0]['lr'] if lr is None else lr
+        if not self.batcher.is_full(positions):
+            # a short batch at the end of an epoch: the same sub-batched pass launched directly into the (zeroed) static
+            # gradient buffers, then the ordinary optimiser step
+            for p in self.model.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
+            totals = self._passes(self.batcher.get_next_batch(iter_num, positions=positions), None)
+            self.opt.step()
+            return totals
+        key = self._weights(iter_num)
+        if self.graph is None or key != self.weights_key:
+            self._capture(iter_num)            # records the work; nothing of it runs (and no ring record is consumed) until the replay
+            self.weights_key = key
+        slot = self.ring.filled % self.ring.slots
+        if self.events[slot] is not None and not self.events[slot].query():
+            import time
+            t0 = time.perf_counter()
+            self.events[slot].synchronize()    # the replay that read this slot has finished
+            self.wait_seconds += time.perf_counter() - t0
+        neg_step_size, bias2_sqrt = self.opt.graph_factors(self.opt.next_count(), lr)
+        sparse = positions.get('sparse', (0, 0, 0))
+        self.ring.fill(iter_num, positions['pixel'][:2], sparse[:2], neg_step_size, bias2_sqrt)
+        self.graph.replay()
+        event = torch.cuda.Event()
+        event.record()
+        self.events[slot] = event
+        self.opt.count_step()
+        if self.model.precision != ops.PRECISION_FP32 and ops.range_status(clear=True):
+            raise ops.Fp16RangeError("GraphedIteration: an earlier replay met a value outside the fp16 range (|v| > 65504); its "
+                                     "update is invalid -- use hip_precision 'fp32' for this model")
+        return self.totals
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # frame writer (SURVEY row f3): what the reference's Tester does with a predicted frame (src/Tester01.py:69-92), without
 # its skimage dependency -- PNG through zlib, .npy through numpy

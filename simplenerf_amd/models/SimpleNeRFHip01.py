@@ -279,11 +279,12 @@ class SimpleNeRFHip(torch.nn.Module):
         return shapes
 
     def draw_training_randomness(self, n: int, row_offset, device, out: Optional[Dict[str, Tensor]] = None,
-                                 iter_num: Optional[int] = None) -> Dict[str, Tensor]:
+                                 iter_num: Optional[int] = None, at: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """The draws the next training-mode forward would make itself, produced up front (and counted as that forward's):
         pass the result to ``set_random_draws``.  ``row_offset``: the first global row (int) or the batch's
         ``global_rows`` tensor.  ``out`` supplies pre-allocated tensors to fill (static graph inputs).  ``iter_num``: the
-        batch's training iteration (what ``forward`` keys the draws by); None = this module's call counter."""
+        batch's training iteration (what ``forward`` keys the draws by); None = this module's call counter.  ``at``: the
+        device-resident iteration record (``ops.IterationRing.current``) to read the iteration from -- inside a captured graph."""
         call = self._train_calls if iter_num is None else int(iter_num)
         self._train_calls += 1
         noise_std = float(self.configs['model']['raw_noise_std'])
@@ -292,10 +293,11 @@ class SimpleNeRFHip(torch.nn.Module):
         for key, shape in self.training_draw_shapes(n).items():
             stream = call * len(_DRAW_KINDS) + _DRAW_KINDS.index(key)
             target = None if out is None else out[key]
+            where = None if at is None else (at, _DRAW_KINDS.index(key), len(_DRAW_KINDS))
             if key.startswith('noise'):
-                draws[key] = ops.random_normal(self.seed, stream, first, shape, device, noise_std, out=target, rows=rows)
+                draws[key] = ops.random_normal(self.seed, stream, first, shape, device, noise_std, out=target, rows=rows, at=where)
             else:
-                draws[key] = ops.random_uniform(self.seed, stream, first, shape, device, out=target, rows=rows)
+                draws[key] = ops.random_uniform(self.seed, stream, first, shape, device, out=target, rows=rows, at=where)
         return draws
 
     @staticmethod

@@ -695,8 +695,9 @@ def patch_consistency_masks(rays_o: Tensor, rays_d: Tensor, depth1: Tensor, dept
 
 # ---------------------------------------------------------------------------------------------- f4 optimiser
 def adam_step(params: List[Tensor], grads: List[Optional[Tensor]], exp_avg: List[Tensor], exp_avg_sq: List[Tensor],
-              step: int, lr: float, beta1: float, beta2: float, eps: float) -> None:
-    """In-place Adam update of every tensor with a gradient (one launch per 64 tensors)."""
+              step: int, lr: float, beta1: float, beta2: float, eps: float, at: Optional[Tensor] = None) -> None:
+    """In-place Adam update of every tensor with a gradient (one launch per 64 tensors).  ``at``: the device-resident
+    iteration record (``IterationRing.current``) to take the step-dependent factors from instead of ``step`` / ``lr``."""
     lib = _lib.load()
     n = len(params)
     if n == 0:
@@ -713,8 +714,12 @@ def adam_step(params: List[Tensor], grads: List[Optional[Tensor]], exp_avg: List
     ptrs = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
     sizes = (ctypes.c_longlong * n)(*[p.numel() for p in params])
     with torch.cuda.device(params[0].device):
-        st = lib.snerf_adam_step(ptrs(params), ptrs(grads), ptrs(exp_avg), ptrs(exp_avg_sq), sizes, n, int(step),
-                                 float(lr), float(beta1), float(beta2), float(eps), _stream())
+        if at is not None:
+            st = lib.snerf_adam_step_at(ptrs(params), ptrs(grads), ptrs(exp_avg), ptrs(exp_avg_sq), sizes, n,
+                                        ctypes.c_void_p(at.data_ptr()), float(beta1), float(beta2), float(eps), _stream())
+        else:
+            st = lib.snerf_adam_step(ptrs(params), ptrs(grads), ptrs(exp_avg), ptrs(exp_avg_sq), sizes, n, int(step),
+                                     float(lr), float(beta1), float(beta2), float(eps), _stream())
     _lib.check(st, 'snerf_adam_step')
 
 
@@ -784,8 +789,10 @@ def assemble_batch(indices: Tensor, num_pixel_rays: int, table: Tensor, resoluti
 
 
 def shuffled_indices(seed: int, epoch: int, first: int, count: int, domain: int, device, candidates: Optional[Tensor] = None,
-                     num_views: int = 0, resolution=(0, 0), crop=None) -> Tensor:
-    """Positions [first, first+count) of epoch ``epoch``'s permutation of the candidate pixels, as global pixel indices."""
+                     num_views: int = 0, resolution=(0, 0), crop=None, at: Optional[Tensor] = None, sparse: bool = False) -> Tensor:
+    """Positions [first, first+count) of epoch ``epoch``'s permutation of the candidate pixels, as global pixel indices.
+    ``at`` (``IterationRing.current``): epoch and position come from the device-resident iteration record (its pixel or
+    ``sparse`` pair), ``first`` is then the offset added to that position (a rank's shard of the slice)."""
     lib = _lib.load()
     h, w = int(resolution[0]), int(resolution[1])
     y0, y1, x0, x1 = crop if crop is not None else (0, h, 0, w)
@@ -798,9 +805,15 @@ def shuffled_indices(seed: int, epoch: int, first: int, count: int, domain: int,
     if count == 0:
         return out
     with torch.cuda.device(out.device):
-        st = lib.snerf_shuffled_indices(int(seed) & (2 ** 64 - 1), int(epoch), int(first), int(count), int(domain),
-                                        ctypes.c_void_p(0 if candidates is None else candidates.data_ptr()), int(num_views), h, w,
-                                        int(y0), int(y1), int(x0), int(x1), ctypes.c_void_p(out.data_ptr()), _stream())
+        if at is not None:
+            st = lib.snerf_shuffled_indices_at(int(seed) & (2 ** 64 - 1), ctypes.c_void_p(at.data_ptr()), int(bool(sparse)), int(first),
+                                               int(count), int(domain), ctypes.c_void_p(0 if candidates is None else candidates.data_ptr()),
+                                               int(num_views), h, w, int(y0), int(y1), int(x0), int(x1),
+                                               ctypes.c_void_p(out.data_ptr()), _stream())
+        else:
+            st = lib.snerf_shuffled_indices(int(seed) & (2 ** 64 - 1), int(epoch), int(first), int(count), int(domain),
+                                            ctypes.c_void_p(0 if candidates is None else candidates.data_ptr()), int(num_views), h, w,
+                                            int(y0), int(y1), int(x0), int(x1), ctypes.c_void_p(out.data_ptr()), _stream())
     _lib.check(st, 'snerf_shuffled_indices')
     return out
 
@@ -822,7 +835,7 @@ def _row_ids(rows: Optional[Tensor], count: int) -> Optional[Tensor]:
 
 
 def random_uniform(seed: int, stream_id: int, first_row: int, shape, device, out: Optional[Tensor] = None,
-                   rows: Optional[Tensor] = None) -> Tensor:
+                   rows: Optional[Tensor] = None, at=None) -> Tensor:
     """[0,1) Philox draws of shape (rows, width...); element (r, c) depends only on (seed, stream_id, global row of r, c),
     where the global row is ``rows[r]`` (int64 GPU tensor, e.g. a batch's ``global_rows``) or ``first_row + r``.
     ``out`` (optional) receives the draws in place (static buffers of a captured graph)."""
@@ -834,15 +847,20 @@ def random_uniform(seed: int, stream_id: int, first_row: int, shape, device, out
         return out
     rows = _row_ids(rows, count)
     with torch.cuda.device(out.device):
-        st = lib.snerf_random_uniform(int(seed) & (2 ** 64 - 1), int(stream_id) & 0xFFFFFFFF, int(first_row),
-                                      ctypes.c_void_p(0 if rows is None else rows.data_ptr()), count, max(width, 1), _ptr(out),
-                                      _stream())
+        if at is not None:      # (record, kind, number of kinds): the stream is record.iter_num * kinds + kind, read on the device
+            st = lib.snerf_random_uniform_at(int(seed) & (2 ** 64 - 1), ctypes.c_void_p(at[0].data_ptr()), int(at[1]), int(at[2]),
+                                             int(first_row), ctypes.c_void_p(0 if rows is None else rows.data_ptr()), count,
+                                             max(width, 1), _ptr(out), _stream())
+        else:
+            st = lib.snerf_random_uniform(int(seed) & (2 ** 64 - 1), int(stream_id) & 0xFFFFFFFF, int(first_row),
+                                          ctypes.c_void_p(0 if rows is None else rows.data_ptr()), count, max(width, 1), _ptr(out),
+                                          _stream())
     _lib.check(st, 'snerf_random_uniform')
     return out
 
 
 def random_normal(seed: int, stream_id: int, first_row: int, shape, device, scale: float = 1.0,
-                  out: Optional[Tensor] = None, rows: Optional[Tensor] = None) -> Tensor:
+                  out: Optional[Tensor] = None, rows: Optional[Tensor] = None, at=None) -> Tensor:
     lib = _lib.load()
     out = _draw_target(shape, device, out)
     count = int(shape[0])
@@ -851,8 +869,45 @@ def random_normal(seed: int, stream_id: int, first_row: int, shape, device, scal
         return out
     rows = _row_ids(rows, count)
     with torch.cuda.device(out.device):
-        st = lib.snerf_random_normal(int(seed) & (2 ** 64 - 1), int(stream_id) & 0xFFFFFFFF, int(first_row),
-                                     ctypes.c_void_p(0 if rows is None else rows.data_ptr()), count, max(width, 1), float(scale),
-                                     _ptr(out), _stream())
+        if at is not None:
+            st = lib.snerf_random_normal_at(int(seed) & (2 ** 64 - 1), ctypes.c_void_p(at[0].data_ptr()), int(at[1]), int(at[2]),
+                                            int(first_row), ctypes.c_void_p(0 if rows is None else rows.data_ptr()), count,
+                                            max(width, 1), float(scale), _ptr(out), _stream())
+        else:
+            st = lib.snerf_random_normal(int(seed) & (2 ** 64 - 1), int(stream_id) & 0xFFFFFFFF, int(first_row),
+                                         ctypes.c_void_p(0 if rows is None else rows.data_ptr()), count, max(width, 1), float(scale),
+                                         _ptr(out), _stream())
     _lib.check(st, 'snerf_random_normal')
     return out
+
+
+# ---------------------------------------------------------------------------------------------- whole-iteration graphs
+class IterationRing:
+    """The per-iteration scalars of a replayed training graph (struct snerf_iteration, include/simplenerf_train.h): a ring of
+    records in PINNED host memory that the host fills ahead of time, a device-resident counter and the device-resident
+    ``current`` record.  ``advance()`` (captured as the graph's first node) makes record ``counter mod slots`` current."""
+
+    def __init__(self, device, slots: int = 8):
+        self.slots = int(slots)
+        self.device = torch.device(device)
+        self.ring = torch.zeros((self.slots, _lib.ITERATION_WORDS), dtype=torch.int64).pin_memory()
+        self.view = self.ring.numpy()
+        self.counter = torch.zeros((1,), dtype=torch.int64, device=self.device)
+        self.current = torch.zeros((_lib.ITERATION_WORDS,), dtype=torch.int64, device=self.device)
+        self.filled = 0                       # records written so far = index of the next replay
+
+    def fill(self, iter_num: int, pixel: tuple, sparse: tuple, adam_neg_step_size: float, adam_bias2_sqrt: float) -> int:
+        """Write the record of the NEXT replay; ``pixel`` / ``sparse`` = (epoch, first).  -> its slot."""
+        slot = self.filled % self.slots
+        row = self.view[slot]
+        row[0], row[1], row[2], row[3], row[4] = int(iter_num), int(pixel[0]), int(pixel[1]), int(sparse[0]), int(sparse[1])
+        row[5] = int(numpy.array([adam_neg_step_size, adam_bias2_sqrt], dtype=numpy.float32).view(numpy.int64)[0])
+        self.filled += 1
+        return slot
+
+    def advance(self) -> None:
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            st = lib.snerf_iteration_advance(ctypes.c_void_p(self.ring.data_ptr()), self.slots, ctypes.c_void_p(self.counter.data_ptr()),
+                                             ctypes.c_void_p(self.current.data_ptr()), _stream())
+        _lib.check(st, 'snerf_iteration_advance')

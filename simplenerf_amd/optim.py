@@ -46,6 +46,51 @@ class Adam(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self.__dict__['_counts'] = {}
 
+    def graph_factors(self, step: int, lr: float):
+        """(-(lr / (1 - beta1^step)), sqrt(1 - beta2^step)) as float32, evaluated in double like snerf_adam_step does: what a
+        captured ``step_at`` reads from the device-resident iteration record."""
+        import numpy
+        beta1, beta2 = self.param_groups[0]['betas']
+        bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+        return float(numpy.float32(-(lr / bc1))), float(numpy.float32(bc2 ** 0.5))
+
+    @torch.no_grad()
+    def step_at(self, record):
+        """The update of ``step()`` with the step-dependent factors read from the device-resident iteration record (inside a
+        captured graph: nothing here depends on the iteration).  Every parameter must hold a gradient and state; the step
+        COUNTS are kept by the caller (``count_step``)."""
+        for group in self.param_groups:
+            ps = [p for p in group['params'] if p.grad is not None]
+            for p in ps:
+                if len(self.state[p]) == 0:
+                    self.state[p]['step'] = torch.tensor(0.0, dtype=torch.float32)
+                    self.state[p]['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    self.state[p]['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            beta1, beta2 = group['betas']
+            ops.adam_step([p.data for p in ps], [p.grad for p in ps], [self.state[p]['exp_avg'] for p in ps],
+                          [self.state[p]['exp_avg_sq'] for p in ps], 0, 0.0, beta1, beta2, group['eps'], at=record)
+
+    def count_step(self) -> int:
+        """One optimiser step happened outside ``step()`` (a graph replay): advance every parameter's count; -> the new count."""
+        counts = self.__dict__.setdefault('_counts', {})
+        new = None
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                counts[p] = self._count(p) + 1
+                new = counts[p] if new is None else new
+                if counts[p] != new:
+                    raise RuntimeError('graphed optimiser steps need every parameter at the same step count')
+            torch.autograd.graph.increment_version([p for p in group['params'] if p.grad is not None])
+        return int(new or 0)
+
+    def next_count(self) -> int:
+        for group in self.param_groups:
+            for p in group['params']:
+                return self._count(p) + 1
+        return 1
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

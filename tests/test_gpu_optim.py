@@ -186,6 +186,56 @@ def test_graphed_sub_batched_iteration_equals_the_eager_trainer_iteration(precis
         assert torch.equal(a, b), name
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'f16'])
+def test_graphed_whole_iteration_equals_the_eager_trainer_iteration(precision):
+    """harness.GraphedIteration: batch assembly, draws, the sub-batched pass AND the Adam update replayed from ONE HIP graph,
+    the per-iteration scalars (epoch positions, iteration number, Adam's factors with the decayed learning rate) read from a
+    device-resident record that the graph's first node refreshes from a pinned host ring.  Twelve iterations across an epoch
+    boundary of the sparse-depth stream (a short batch, run eagerly into the static gradient buffers) against the eager
+    trainer iteration: loss values and every parameter bit-identical.  The ring has 4 slots here, so the slot guard is used."""
+    from simplenerf_amd import harness
+    from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
+    from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
+    from simplenerf_amd.lr_decayers.LearningRateDecayerFactory import get_lr_decayer
+    from simplenerf_amd.models.ModelFactory import get_model
+    cfg = synth.training_configs(precision, num_rays=192, num_sparse=64)
+    cfg['sub_batch_size'] = 128
+    cfg['losses'] = synth.loss_configs(iter_weighted=False)
+    scene = synth.training_scene(0, 3, 48, 64, sparse_fraction=0.05)
+    models = []
+    for _ in range(2):
+        m = get_model(cfg, None)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 9, 200.0, 8.0).items()})
+        models.append(m.to(DEV).train())
+    eager, graphed = models
+    batch_e, batch_g = BatchAssembler(cfg, scene, DEV), BatchAssembler(cfg, scene, DEV)
+    assert batch_e.sparse_candidates.shape[0] // 64 < 11          # the sparse-depth epoch ends inside the run
+    losses = LossComputer(cfg)
+    decayer = get_lr_decayer(cfg)
+    opt_e, opt_g = optim.Adam(list(eager.parameters()), lr=5e-4), optim.Adam(list(graphed.parameters()), lr=5e-4)
+    step = harness.GraphedIteration(graphed, losses, opt_g, batch_g, decayer, sub_batch_size=128, slots=4)
+    short = 0
+    for it in range(20000, 20012):
+        for group in opt_e.param_groups:
+            group['lr'] = decayer.get_updated_learning_rate(it)
+        batch = batch_e.get_next_batch(it)
+        short += batch['rays_o'].shape[0] < 256
+        ref = harness.train_one_iter(eager, losses, opt_e, batch, 128)
+        got = step(it)
+        assert float(got['TotalLoss']) == float(ref['TotalLoss']), it
+        assert sorted(got) == sorted(ref) and all(float(got[k]) == float(ref[k]) for k in ref), it
+    assert short >= 1
+    for (name, a), b in zip(eager.named_parameters(), graphed.parameters()):
+        assert torch.equal(a, b), name
+    # the optimiser's bookkeeping followed the replays: same step counts, same state -- a checkpoint taken now is the eager one
+    sd_e, sd_g = opt_e.state_dict(), opt_g.state_dict()
+    for k in sd_e['state']:
+        assert float(sd_e['state'][k]['step']) == float(sd_g['state'][k]['step']) == 12.0
+        assert torch.equal(sd_e['state'][k]['exp_avg'], sd_g['state'][k]['exp_avg'])
+        assert torch.equal(sd_e['state'][k]['exp_avg_sq'], sd_g['state'][k]['exp_avg_sq'])
+
+
 @pytest.mark.parametrize('precision', ['f16x3', 'f16'])
 def test_graph_replays_stay_exact_while_the_gradients_shrink(precision):
     """Regression (r02): with the fp16 modes' region-maximum table cleared by a captured hipMemsetAsync node, graph
