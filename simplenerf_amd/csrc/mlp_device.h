@@ -91,10 +91,23 @@ __device__ __forceinline__ float keep_if_bit(float v, unsigned word, int bit) {
     return __uint_as_float(__float_as_uint(v) & (unsigned)__builtin_amdgcn_sbfe((int)word, bit, 1));
 }
 // ReLU sign bits (see MlpPlan::act_mask): bit r of a tile's 16-bit field = accumulator register r of this lane > 0.
+// Two VALU per value: the compare leaves the wave's result in a scalar pair and one add-with-carry shifts the lane's bit into
+// the word (m <- m + m + carry, registers taken from 15 down to 0) -- compare + select + shift-or, what the C expression
+// `m |= (h[r] > 0) << r` compiles to, is three (128 fewer VALU per 256-wide layer and wave in every training forward; round 3).
+// The compare stays a compiler-visible instruction (__builtin_amdgcn_fcmp) ON PURPOSE: the values are MFMA results, and the
+// wait states between an MFMA's write and a VALU read are inserted by the compiler for its own instructions only -- an inline
+// asm that read the accumulator itself saw stale registers now and then (run-to-run differences in the 16-bit training
+// gradients, found by test_full_size_training_batch_properties).  The add-with-carry reads only VALU results.
+// Exactly the predicate of the reference's ReLU derivative: both zeros and NaN give 0.
+__device__ __forceinline__ unsigned positive_bit(unsigned m, float v) {
+    const unsigned long long positive = __builtin_amdgcn_fcmpf(v, 0.0f, 2 /* ordered greater-than */);
+    asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(m) : "s"(positive) : "vcc");
+    return m;
+}
 __device__ __forceinline__ unsigned relu_bits(const float* __restrict__ h) {
     unsigned m = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m |= (h[r] > 0.0f ? 1u : 0u) << r;
+    for (int r = 15; r >= 0; --r) m = positive_bit(m, h[r]);
     return m;
 }
 // registers h[16u + r] of U (even) tiles starting at tile index t0 (even) -> mask words of this wave block

@@ -382,7 +382,7 @@ __device__ __forceinline__ void store_relu_masks(const f32x16* acc, unsigned* __
     for (int u = 0; u < U; u += 2) {
         unsigned word = 0;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) word |= (acc[u + (r >> 4)][r & 15] > 0.0f ? 1u : 0u) << r;
+        for (int r = 31; r >= 0; --r) word = positive_bit(word, acc[u + (r >> 4)][r & 15]);
         __builtin_nontemporal_store(word, masks + ((t0 + u) >> 1) * 64 + lane);
     }
 }
@@ -393,7 +393,7 @@ __device__ __forceinline__ void relu_mask_tile(const f32x16& acc, int u, unsigne
                                                int lane) {
     unsigned m = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m |= (acc[r] > 0.0f ? 1u : 0u) << r;
+    for (int r = 15; r >= 0; --r) m = positive_bit(m, acc[r]);
     if ((u & 1) == 0) {
         bits = m;
     } else {
