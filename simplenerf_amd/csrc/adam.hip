@@ -28,10 +28,10 @@ struct AdamTable {
 };
 
 __global__ void __launch_bounds__(256) adam_kernel(AdamTable t) {
-    if (t.at) {
-        t.neg_step_size = t.at->adam_neg_step_size;
-        t.bias2_sqrt = t.at->adam_bias2_sqrt;
-    }
+    // (locals, never a store into `t`: a modified by-value table is copied to scratch by every thread -- 2.6 KB each, which
+    // made this kernel 160 us instead of 10; tools/isa_stats.sh adam must show scratch 0)
+    const float neg_step_size = t.at ? t.at->adam_neg_step_size : t.neg_step_size;
+    const float bias2_sqrt = t.at ? t.at->adam_bias2_sqrt : t.bias2_sqrt;
     int lo = 0, hi = t.count;                     // largest i with first_block[i] <= blockIdx.x
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -49,10 +49,10 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamTable t) {
             const float grad = g[i];
             const float m1 = fmaf(t.one_minus_beta1, grad - m[i], m[i]);
             const float v1 = fmaf(t.one_minus_beta2 * grad, grad, v[i] * t.beta2);
-            const float denom = sqrtf(v1) / t.bias2_sqrt + t.eps;
+            const float denom = sqrtf(v1) / bias2_sqrt + t.eps;
             m[i] = m1;
             v[i] = v1;
-            p[i] = p[i] + (t.neg_step_size * m1) / denom;
+            p[i] = p[i] + (neg_step_size * m1) / denom;
         }
     }
 }

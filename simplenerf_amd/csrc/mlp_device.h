@@ -6,6 +6,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct MlpArgs {
     const float* packed;
@@ -91,23 +92,24 @@ __device__ __forceinline__ float keep_if_bit(float v, unsigned word, int bit) {
     return __uint_as_float(__float_as_uint(v) & (unsigned)__builtin_amdgcn_sbfe((int)word, bit, 1));
 }
 // ReLU sign bits (see MlpPlan::act_mask): bit r of a tile's 16-bit field = accumulator register r of this lane > 0.
-// Two VALU per value: the compare leaves the wave's result in a scalar pair and one add-with-carry shifts the lane's bit into
-// the word (m <- m + m + carry, registers taken from 15 down to 0) -- compare + select + shift-or, what the C expression
-// `m |= (h[r] > 0) << r` compiles to, is three (128 fewer VALU per 256-wide layer and wave in every training forward; round 3).
-// The compare stays a compiler-visible instruction (__builtin_amdgcn_fcmp) ON PURPOSE: the values are MFMA results, and the
-// wait states between an MFMA's write and a VALU read are inserted by the compiler for its own instructions only -- an inline
-// asm that read the accumulator itself saw stale registers now and then (run-to-run differences in the 16-bit training
-// gradients, found by test_full_size_training_batch_properties).  The add-with-carry reads only VALU results.
-// Exactly the predicate of the reference's ReLU derivative: both zeros and NaN give 0.
-__device__ __forceinline__ unsigned positive_bit(unsigned m, float v) {
-    const unsigned long long positive = __builtin_amdgcn_fcmpf(v, 0.0f, 2 /* ordered greater-than */);
-    asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(m) : "s"(positive) : "vcc");
-    return m;
+// 1.5 VALU per value and no scalar register in between: the sign bit of (0 - v) IS the predicate v > 0 (0 - (+-0) = +0,
+// positive denormals stay denormal), the subtraction is one packed instruction per two values, and v_alignbit_b32 shifts
+// the bit into the word ({m, t} >> 31 = m << 1 | sign(t); registers taken from 15 down to 0).  The C expression
+// `m |= (h[r] > 0) << r` compiles to compare + select + shift-or, three per value plus the wait states gfx950 needs between a
+// VALU write of a scalar pair and the VALU that reads it as a mask.  (An inline-asm compare + add-with-carry pair -- two per
+// value -- was tried first and is NOT safe: the compiler inserts neither those wait states nor the ones between an MFMA's
+// write and a VALU read for instructions inside an asm; the 16-bit training gradients differed run to run.)  Exactly the
+// predicate of the reference's ReLU derivative for every number; a NaN pre-activation may give either bit (the fp16 modes
+// fail the call on one, "Range" in simplenerf_hip.h; in fp32 the outputs are NaN as well).
+__device__ __forceinline__ unsigned positive_bits(unsigned m, float a, float b) {   // m <- m << 2 | [a > 0] << 1 | [b > 0]
+    const f32x2 t = f32x2{0.0f, 0.0f} - f32x2{a, b};
+    m = __builtin_amdgcn_alignbit(m, __float_as_uint(t[0]), 31);
+    return __builtin_amdgcn_alignbit(m, __float_as_uint(t[1]), 31);
 }
 __device__ __forceinline__ unsigned relu_bits(const float* __restrict__ h) {
     unsigned m = 0;
 #pragma unroll
-    for (int r = 15; r >= 0; --r) m = positive_bit(m, h[r]);
+    for (int r = 15; r >= 1; r -= 2) m = positive_bits(m, h[r], h[r - 1]);
     return m;
 }
 // registers h[16u + r] of U (even) tiles starting at tile index t0 (even) -> mask words of this wave block

@@ -5,7 +5,6 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -382,7 +381,7 @@ __device__ __forceinline__ void store_relu_masks(const f32x16* acc, unsigned* __
     for (int u = 0; u < U; u += 2) {
         unsigned word = 0;
 #pragma unroll
-        for (int r = 31; r >= 0; --r) word = positive_bit(word, acc[u + (r >> 4)][r & 15]);
+        for (int r = 31; r >= 1; r -= 2) word = positive_bits(word, acc[u + (r >> 4)][r & 15], acc[u + (r >> 4)][(r & 15) - 1]);
         __builtin_nontemporal_store(word, masks + ((t0 + u) >> 1) * 64 + lane);
     }
 }
@@ -393,7 +392,7 @@ __device__ __forceinline__ void relu_mask_tile(const f32x16& acc, int u, unsigne
                                                int lane) {
     unsigned m = 0;
 #pragma unroll
-    for (int r = 15; r >= 0; --r) m = positive_bit(m, acc[r]);
+    for (int r = 15; r >= 1; r -= 2) m = positive_bits(m, acc[r], acc[r - 1]);
     if ((u & 1) == 0) {
         bits = m;
     } else {

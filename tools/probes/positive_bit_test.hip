@@ -1,21 +1,22 @@
-// Checks positive_bit (mlp_device.h: compare + v_addc_co building ReLU mask words) against the plain C expression on random data,
-// including zeros, negatives zeros, NaN and denormals.   hipcc --offload-arch=gfx950 -O3 -I simplenerf_amd/csrc -I include ...
+// Checks positive_bits (mlp_device.h: sign of 0 - v shifted into the ReLU mask word by v_alignbit) against the plain C expression
+// on random data including both zeros and denormals of both signs (NaN is excluded: either bit is allowed there).   hipcc --offload-arch=gfx950 -O3 -I simplenerf_amd/csrc -I include ...
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-__device__ __forceinline__ unsigned positive_bit(unsigned m, float v) {
-    const unsigned long long positive = __builtin_amdgcn_fcmpf(v, 0.0f, 2);
-    asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(m) : "s"(positive) : "vcc");
-    return m;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned positive_bits(unsigned m, float a, float b) {
+    const f32x2 t = f32x2{0.0f, 0.0f} - f32x2{a, b};
+    m = __builtin_amdgcn_alignbit(m, __float_as_uint(t[0]), 31);
+    return __builtin_amdgcn_alignbit(m, __float_as_uint(t[1]), 31);
 }
 __global__ void k(const float* in, unsigned* out_asm, unsigned* out_c, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     unsigned a = 0, c = 0;
 #pragma unroll
-    for (int r = 15; r >= 0; --r) a = positive_bit(a, in[i * 16 + r]);
+    for (int r = 15; r >= 1; r -= 2) a = positive_bits(a, in[i * 16 + r], in[i * 16 + r - 1]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) c |= (in[i * 16 + r] > 0.0f ? 1u : 0u) << r;
     out_asm[i] = a; out_c[i] = c;
@@ -26,7 +27,7 @@ int main() {
     srand(3);
     for (auto& v : h) {
         const int t = rand() % 16;
-        v = t == 0 ? 0.0f : t == 1 ? -0.0f : t == 2 ? 1e-42f : t == 3 ? -1e-42f : t == 4 ? __builtin_nanf("") : (float)rand() / RAND_MAX - 0.5f;
+        v = t == 0 ? 0.0f : t == 1 ? -0.0f : t == 2 ? 1e-42f : t == 3 ? -1e-42f : (float)rand() / RAND_MAX - 0.5f;
     }
     float* d; unsigned *a, *c;
     hipMalloc(&d, h.size() * 4); hipMalloc(&a, n * 4); hipMalloc(&c, n * 4);
