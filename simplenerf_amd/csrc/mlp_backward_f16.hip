@@ -43,6 +43,27 @@ __device__ __forceinline__ void publish_max(unsigned* word, float v, int lane) {
     if (lane == 0 && v > 0.0f) atomicMax(word, __float_as_uint(v));
 }
 
+// max(v of this lane, v of the lane 32 away) without the LDS crossbar: v_permlane32_swap exchanges the upper half of one
+// register with the lower half of another (two copies of v in, [lo, lo] and [hi, hi] out)
+__device__ __forceinline__ float lane_halves_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// publish_max for a non-negative v with the wave maximum formed by DPP row operations (shifts within the 16-lane rows, then
+// the row broadcasts; lanes outside a step's mask see 0, the identity here): a dozen VALU instructions where the six
+// dependent __shfl_xor steps each cost an LDS-crossbar round trip.  The maximum lands in lane 63.
+__device__ __forceinline__ void publish_max_dpp(unsigned* word, float v, int lane) {
+#define SNERF_DPP_MAX(ctrl, rows) v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), ctrl, rows, 0xf, true)))
+    SNERF_DPP_MAX(0x111, 0xf);   // row_shr:1
+    SNERF_DPP_MAX(0x112, 0xf);   // row_shr:2
+    SNERF_DPP_MAX(0x114, 0xf);   // row_shr:4
+    SNERF_DPP_MAX(0x118, 0xf);   // row_shr:8   -> lane 15 of every row holds the row's maximum
+    SNERF_DPP_MAX(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    SNERF_DPP_MAX(0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+#undef SNERF_DPP_MAX
+    if (lane == 63 && v > 0.0f) atomicMax(word, __float_as_uint(v));
+}
+
 template <int U>
 __device__ __forceinline__ float tiles_max(const f32x16 (&acc)[U]) {
     float m = 0.0f;
@@ -115,7 +136,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int WT, int VT, bool VIEWDEP, int P, int DEPTH>
 // (one workgroup per CU also for P = 1: at the 256-register budget of two the kernel spills ~120 registers and the
 // training iteration measured 11.1 -> 14.4 ms)
-__global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfChainArgs args) {
+__global__ void __launch_bounds__(256, (P == 1 && VIEWDEP) ? 2 : 1) mlp_backward_chain_f16x3_kernel(HalfChainArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ChainArgs& a = args.c;
     const int lane = threadIdx.x & 63;
@@ -258,6 +279,105 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
         }
     }
     // ---- trunk, last layer first: dY_l = dh_{l+1} . [h_{l+1} > 0];  dh_l = W_l[:, h-columns]^T dY_l -------------
+    if constexpr (P == 1) {
+        // Single-product chain (round 3): one wave per SIMD, so VALU work placed BETWEEN the tiles' MFMA runs executes with
+        // the matrix pipe idle -- the layer epilogue (mask, maximum, scale back + bf16 store, renormalise, fp16 operands: 6.5
+        // VALU per value, 830 per layer) used to do exactly that and the pipe was 25 % busy (PMC).  Here every piece of it
+        // that the data flow allows rides BEHIND an MFMA of the next tile (seg_mfma1_side):
+        //   * tile u's mask + maximum + scaled bf16 store run during the product of tile u+1 (one register pair per two
+        //     k-steps);
+        //   * the operand fragments of the next layer's products (k-step t <- registers 8(t&1).. of tile t>>1, times the
+        //     sample's renormalisation factor) are converted during the product of that layer's tile 0, two k-steps ahead
+        //     of the MFMA that consumes them.
+        // What is left between two layers' matrix work: the last tile's epilogue, the sample maximum (lane halves exchanged
+        // with v_permlane32_swap, the region maximum reduced with DPP row operations instead of six LDS-crossbar shuffles) and
+        // the first two fragments.  The arithmetic -- every value, every rounding -- is the one of the serial formulation.
+        __bf16* const rows16 = reinterpret_cast<__bf16*>(grads);
+        const int slot8 = (2 * (lane & 31) + half) * 8;
+        float mrun = 0.0f;       // this lane's max |dY| over the tiles of the layer being finished, at the scale `acc` carries
+        bf16x8 stage;
+        auto epilogue_pair = [&](int t, int pr, int row0, const unsigned (&words)[WT / 2]) __attribute__((always_inline)) {
+#ifdef SNERF_ABL_CHAIN_NOEPI     // timing ablation (tools/probes/build_variant.py): no epilogue work at all -- wrong results
+            return;
+#endif
+            const int r = 2 * pr, b0 = 16 * (t & 1) + r;
+            const float x = keep_if_bit_2op(acc[t][r], words[t >> 1], b0);
+            const float y = keep_if_bit_2op(acc[t][r + 1], words[t >> 1], b0 + 1);
+            acc[t][r] = x; acc[t][r + 1] = y;
+            // (the NaN-propagating maximum: v_maximum3_f32 with |x| modifiers, no quieting moves in front of it)
+            mrun = __builtin_elementwise_maximum(mrun, __builtin_elementwise_maximum(__builtin_fabsf(x), __builtin_fabsf(y)));
+            const bf16x2 q = __builtin_convertvector(f32x2{x, y} * gback, bf16x2);
+            stage[r & 7] = q[0]; stage[(r & 7) + 1] = q[1];
+#ifdef SNERF_ABL_CHAIN_NOSTORE   // timing ablation: the epilogue's arithmetic, but nothing written
+            if (pr == 7 && t == 0 && stage[0] == (__bf16)123.0f)
+#else
+            if ((pr & 3) == 3)   // eight values staged: one 16-byte store (read once, by the weight-gradient kernel)
+#endif
+            {
+                __builtin_nontemporal_store(stage, reinterpret_cast<bf16x8*>(rows16 + (long long)row0 * 32 + (2 * t + (pr >> 2)) * 512 + slot8));
+                st.note_vmem(1);
+            }
+        };
+        float fnext = 1.0f;
+        auto convert_fragment = [&](int t) __attribute__((always_inline)) {
+            const f32x16& src = acc[t >> 1];
+            const int o = 8 * (t & 1);
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const f16x2 h = __builtin_convertvector(f32x2{src[o + j], src[o + j + 1]} * fnext, f16x2);
+                xh[t][j] = h[0]; xh[t][j + 1] = h[1];
+            }
+        };
+        // mask words: the layer being finished, and the one below it (requested one whole layer of products ahead: HBM latency
+        // is longer than one tile's product)
+        unsigned words_now[WT / 2], words_next[WT / 2];
+        load_relu_words<WT>(words_now, masks, (depth - 1) * WT, lane);
+        if (depth > 1) load_relu_words<WT>(words_next, masks, (depth - 2) * WT, lane);
+#pragma unroll
+        for (int t = 0; t < WT; ++t)
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) epilogue_pair(t, pr, (depth - 1) * a.width, words_now);
+        auto phase = [&](int l) __attribute__((always_inline)) {   // products with W_l^T; epilogues of layer l - 1
+            const float msample = lane_halves_max(mrun);
+            if (dy_max) publish_max_dpp(dy_max + (l * a.width) / 32, msample * gback, lane);
+            fnext = renorm_factor(msample);
+            if (!(gscale * fnext < 1.0e30f) || !(gscale * fnext > 1.0e-30f)) fnext = 1.0f;
+            gscale *= fnext;
+            gback = 1.0f / gscale;
+            mrun = 0.0f;
+#pragma unroll
+            for (int i = 0; i < WT / 2; ++i) words_now[i] = words_next[i];
+            if (l > 1) load_relu_words<WT>(words_next, masks, (l - 2) * WT, lane);
+            convert_fragment(0);
+            convert_fragment(1);
+            const int row0 = (l - 1) * a.width;
+#pragma unroll
+            for (int u = 0; u < WT; ++u) {
+                const float* unit = next_unit();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+                if (u == 0) {
+                    seg_mfma1_side<HK>(acc[0], unit, xh, st, [&](int ks) __attribute__((always_inline)) {
+                        if (ks + 2 < HK) convert_fragment(ks + 2);
+                    });
+                } else {
+                    seg_mfma1_side<HK>(acc[u], unit, xh, st, [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int pr = ks * 8 / HK; pr < (ks + 1) * 8 / HK; ++pr) epilogue_pair(u - 1, pr, row0, words_now);
+                    });
+                }
+            }
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) epilogue_pair(WT - 1, pr, row0, words_now);
+        };
+        if constexpr (DEPTH > 0) {
+            static_for<0, DEPTH - 1>([&](auto step) __attribute__((always_inline)) { phase(DEPTH - 1 - decltype(step)::value); });
+        } else {
+#pragma unroll 1
+            for (int l = depth - 1; l >= 1; --l) phase(l);
+        }
+        if (dy_max) publish_max_dpp(dy_max, mrun * gback, lane);   // layer 0's region
+    } else {
     unsigned relu_words[WT / 2];   // sign bits of the layer whose dY is formed next; requested one layer ahead
     load_relu_words<WT>(relu_words, masks, (depth - 1) * WT, lane);
     auto trunk_layer = [&](int l) __attribute__((always_inline)) {
@@ -286,6 +406,7 @@ __global__ void __launch_bounds__(256, 1) mlp_backward_chain_f16x3_kernel(HalfCh
     } else {
 #pragma unroll 1
         for (int l = depth - 1; l >= 0; --l) trunk_layer(l);
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SNERF_STAMP_END(chain_f16);

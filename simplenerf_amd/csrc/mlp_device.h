@@ -91,6 +91,14 @@ __device__ __forceinline__ void load_acc_tile(float (&h)[N], const float* __rest
 __device__ __forceinline__ float keep_if_bit(float v, unsigned word, int bit) {
     return __uint_as_float(__float_as_uint(v) & (unsigned)__builtin_amdgcn_sbfe((int)word, bit, 1));
 }
+// The same, kept at two instructions: left alone, the optimiser rewrites `v & sext(bit)` into test + compare + select (three,
+// plus the two wait states gfx950 wants between the compare's scalar result and the select).  The empty asm only makes the
+// extracted field opaque; it contains no instruction.
+__device__ __forceinline__ float keep_if_bit_2op(float v, unsigned word, int bit) {
+    int k = __builtin_amdgcn_sbfe((int)word, bit, 1);
+    asm("" : "+v"(k));
+    return __uint_as_float(__float_as_uint(v) & (unsigned)k);
+}
 // ReLU sign bits (see MlpPlan::act_mask): bit r of a tile's 16-bit field = accumulator register r of this lane > 0.
 // 1.5 VALU per value and no scalar register in between: the sign bit of (0 - v) IS the predicate v > 0 (0 - (+-0) = +0,
 // positive denormals stay denormal), the subtraction is one packed instruction per two values, and v_alignbit_b32 shifts

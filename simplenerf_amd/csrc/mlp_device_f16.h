@@ -282,6 +282,36 @@ __device__ __forceinline__ void seg_mfma1(f32x16& acc, const float*& p, const f1
     p += NKS * 256;
 }
 
+// The same with `side(ks)` slotted behind the MFMA of every k-step (ks is a compile-time constant after unrolling): VALU work
+// that does not depend on this tile's accumulator issues while the matrix pipe runs the MFMA (32 cycles = eight VALU slots).
+// With one wave per SIMD nothing else fills those slots -- work placed BETWEEN tiles instead runs with the matrix pipe idle.
+template <int NKS, int NB, typename Stream, typename Side>
+__device__ __forceinline__ void seg_mfma1_side(f32x16& acc, const float*& p, const f16x8 (&bh)[NB], Stream& st, Side&& side) {
+    static_assert(NB >= NKS, "operand array too short");
+    constexpr int AHEAD = 4;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+    f16x8 a[AHEAD + 1];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        if (i < NKS) a[i] = lds_read_f16x8(base, i * 1024);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + AHEAD < NKS) a[(ks + AHEAD) % (AHEAD + 1)] = lds_read_f16x8(base, (ks + AHEAD) * 1024);
+        constexpr int kLast = NKS - 1;
+        const int newer = kLast - ks < AHEAD ? kLast - ks : AHEAD;
+        f16x8& cur = a[ks % (AHEAD + 1)];
+        if (newer == 4) lds_wait_all_but<4>(cur);
+        else if (newer == 3) lds_wait_all_but<3>(cur);
+        else if (newer == 2) lds_wait_all_but<2>(cur);
+        else if (newer == 1) lds_wait_all_but<1>(cur);
+        else lds_wait_all_but<0>(cur);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bh[ks], acc, 0, 0, 0);
+        if ((ks & (Stream::kWaves - 1)) == 0) st.fetch_piece();
+        side(ks);
+    }
+    p += NKS * 256;
+}
+
 struct NoSide {
     __device__ __forceinline__ void step(int) const {}
 };
