@@ -819,7 +819,9 @@ struct Workspace {
 // `f16`: SNERF_PRECISION_F16 -- dY and X are 16-bit operand pieces (same row numbers; encoding tiles in register order)
 Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool f16 = false) {
     Workspace w;
-    const long long blocks = (total_samples + 127) / 128 * 4;
+    // wave blocks the chain writes and the weight-gradient jobs contract over: whole workgroups of the chain kernel (eight
+    // waves in the 16-bit mode, mlp_backward_f16.hip chain_waves; snerf_mlp_saved_floats sizes the saved tiles the same way)
+    const long long blocks = f16 ? (total_samples + 255) / 256 * 8 : (total_samples + 127) / 128 * 4;
     w.grads_floats = blocks * p.grad_rows() * 32;   // (the 16-bit tiles use the first half)
     long long off = kRegionTableFloat0 + kRegionSlots * kRegionWords;
     // [0, 64): zero page for padded rows; [192, 448): 1 KiB zero page; [448, 8640): per-region max |dY| words (region_max)

@@ -8,6 +8,13 @@
 #include <algorithm>
 #include <type_traits>
 
+// timing ablations of this kernel alone (tools/probes/build_variant.py; wrong results): no weight DMA / no workgroup barrier
+#ifdef SNERF_ABL_CHAIN_NODMA
+#define SNERF_ABL_NODMA
+#endif
+#ifdef SNERF_ABL_CHAIN_NOBARRIER
+#define SNERF_ABL_NOBARRIER
+#endif
 #include "clock_stamp.h"
 #include "mlp_device_f16.h"
 
@@ -130,14 +137,23 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// Workgroup shape of the chain.  Single-product chain of a view-dependent MLP (the 16-bit training mode's main kernel): EIGHT
+// waves -- two per SIMD, 256 registers each -- sharing ONE weight stream (half the L2 -> LDS traffic and DMA instructions of
+// two 4-wave workgroups per CU) through a five-slot ring (see UnitStreamT: the counted waits then tolerate three units of
+// store latency).  Everything else: four waves, one per SIMD, three slots.
+constexpr int chain_waves(int products, bool viewdep) { return products == 1 && viewdep ? 8 : 4; }
+constexpr int chain_ring(int products, bool viewdep) { return products == 1 && viewdep ? 5 : kUnitBuffers; }
+
 // DEPTH > 0: compile-time trunk depth, layer loop fully unrolled -- the unit schedule (k-steps of each unit and its two
 // successors, DMA pieces, counted vmcnt immediates incl. the dY stores, ring slots) folds to constants instead of ~200
 // scalar instructions per unit of 16 MFMAs (see mlp_forward_f16.hip).
 template <int WT, int VT, bool VIEWDEP, int P, int DEPTH>
 // (one workgroup per CU also for P = 1: at the 256-register budget of two the kernel spills ~120 registers and the
 // training iteration measured 11.1 -> 14.4 ms)
-__global__ void __launch_bounds__(256, (P == 1 && VIEWDEP) ? 2 : 1) mlp_backward_chain_f16x3_kernel(HalfChainArgs args) {
+__global__ void __launch_bounds__(chain_waves(P, VIEWDEP) * 64, chain_waves(P, VIEWDEP) == 8 ? 2 : 1) mlp_backward_chain_f16x3_kernel(HalfChainArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = chain_waves(P, VIEWDEP);
+    constexpr int RING = chain_ring(P, VIEWDEP);
     const ChainArgs& a = args.c;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -155,15 +171,17 @@ __global__ void __launch_bounds__(256, (P == 1 && VIEWDEP) ? 2 : 1) mlp_backward
         if (VIEWDEP && idx < WT) return VK;
         return HK;
     };
-    UnitStreamT<P> st;
+    UnitStreamT<P, NW, RING> st;
     st.start(a.packed + args.half_dgrad_offset, lds, ks_of(0), ks_of(1), lane, wave, args.slot_floats);
+#pragma unroll
+    for (int u = 2; u < RING - 1; ++u) st.start_more(u, ks_of(u));
     int unit_idx = 0;
     auto next_unit = [&]() {
-        const float* p = st.acquire(ks_of(unit_idx + 1), ks_of(unit_idx + 2));
+        const float* p = st.acquire(ks_of(unit_idx + 1), ks_of(unit_idx + RING - 1));
         ++unit_idx;
         return p + lane * 4;
     };
-    const long long block = (long long)blockIdx.x * 4 + wave;
+    const long long block = (long long)blockIdx.x * NW + wave;
     const long long first = block * 32 + (lane & 31);
     const bool live = first < a.total;
     // this workgroup's copy of the region-maximum table (64 copies of 128 words, see region_max in mlp_backward.hip)
@@ -414,13 +432,16 @@ __global__ void __launch_bounds__(256, (P == 1 && VIEWDEP) ? 2 : 1) mlp_backward
 
 template <int WT, int VT, bool VIEWDEP, int P, int DEPTH = 0>
 int launch_chain_half(const HalfChainArgs& args, hipStream_t stream) {
-    const long long blocks = (args.c.total + 127) / 128;
-    const size_t lds_bytes = sizeof(float) * (kUnitBuffers * (size_t)args.slot_floats + 1024);  // ring + DMA dump area
+    constexpr int NW = chain_waves(P, VIEWDEP), RING = chain_ring(P, VIEWDEP);
+    // (the 16-bit workspace holds whole groups of eight wave blocks, plan_workspace; the padded blocks get zero gradients)
+    const long long wave_blocks = P == 1 ? (args.c.total + 255) / 256 * 8 : (args.c.total + 127) / 128 * 4;
+    const long long blocks = wave_blocks / NW;
+    const size_t lds_bytes = sizeof(float) * (RING * (size_t)args.slot_floats + NW * 256);  // ring + DMA dump area
     auto kernel = mlp_backward_chain_f16x3_kernel<WT, VT, VIEWDEP, P, DEPTH>;
     static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
-    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 1024)), "mlp_backward");
+    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (RING * (P == 1 ? 24 * 256 : kUnitBufFloats) + NW * 256)), "mlp_backward");
     if (attr != SNERF_OK) return attr;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, args);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, stream, args);
     return snerf::check_launch("mlp_backward(chain, f16x3)");
 }
 
@@ -435,7 +456,7 @@ int mlp_backward_chain_f16x3(const MlpPlan& plan, const ChainArgs& a, int produc
     args.half_dgrad_offset = plan.half_dgrad_offset;
     int most_ks = 0;
     for (const MlpPlan::HalfStage& st : plan.half_dgrad_stages) most_ks = std::max(most_ks, st.unit_floats / 512);
-    args.slot_floats = products == 3 ? kUnitBufFloats : (most_ks + 3) / 4 * 4 * 256;   // hi halves only (see the forward)
+    args.slot_floats = products == 3 ? kUnitBufFloats : (most_ks + 7) / 8 * 8 * 256;   // hi halves only, whole DMA rounds of up to eight waves
     const int key = plan.wt * 10 + plan.vt;
 #define SNERF_CHAIN(WT_, VT_, VD_) return products == 3 ? launch_chain_half<WT_, VT_, VD_, 3>(args, stream) : launch_chain_half<WT_, VT_, VD_, 1>(args, stream)
     if (key == 84 && a.depth == 8)   // the shipped 8 x 256 trunk with a views layer: compile-time unit schedule

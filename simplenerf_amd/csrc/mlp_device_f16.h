@@ -44,10 +44,17 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform in [0,
 // NW = waves of the workgroup that share the ring (4, or 8 for the single-product forward: two waves per SIMD reading ONE
 // weight stream -- the same occupancy as two 4-wave workgroups per CU at half the L2 -> LDS traffic, which is what bounds
 // the 16-bit forward: 2 x 128 KB per layer and CU at fp16 MFMA rates is ~150 GB/s per CU, twice what a CU draws from L2).
-template <int P, int NW = 4>
+// D = ring slots (default three, "two units ahead").  A deeper ring requests unit i + D - 1 while unit i is consumed, and --
+// what matters to kernels that also STORE between units -- the counted wait at unit i then leaves everything the wave issued
+// during the last D - 2 units in flight, not just the last one: vmcnt retires in order, so a store whose write acknowledgement
+// takes longer than one unit's matrix work (HBM under a 3 TB/s write stream: ~2 us) otherwise stalls the next acquire.
+template <int P, int NW = 4, int D = kUnitBuffers>
 struct UnitStreamT {
     static_assert(NW == 4 || (NW == 8 && P == 1), "8-wave rings are built for the single-product kernels only");
+    static_assert(D >= 3 && D <= 6, "ring depth");
     static constexpr int kWaves = NW;
+    static constexpr int kSlots = D;
+    int hist[D > 3 ? D - 3 : 1];   // vector-memory instructions of the D - 3 units before the current one, newest first
     const float* fetch_ptr;  // global address of the next unit to request
     const float* stream_base;
     float* lds;
@@ -87,7 +94,7 @@ struct UnitStreamT {
     // the stream into a per-wave dump area instead of touching a live buffer.
     __device__ __forceinline__ void issued_next_none() {
         pend_src = stream_base;
-        pend_dst = lds + kUnitBuffers * slot_floats + wave * 256;  // dump: NW KiB right after the ring
+        pend_dst = lds + D * slot_floats + wave * 256;  // dump: NW KiB right after the ring
         pend_left = 0;
         issued = 0;
     }
@@ -106,12 +113,21 @@ struct UnitStreamT {
                                           int slot_floats_ = kUnitBufFloats) {
         fetch_ptr = first; stream_base = first; lds = lds_base; slot = 0; lane = lane_; wave = wave_; pend_left = 0; issued = 0;
         younger = 0; slot_floats = slot_floats_;
+#pragma unroll
+        for (int i = 0; i < (D > 3 ? D - 3 : 1); ++i) hist[i] = 0;
         fetch(ks0, 0);
         if (ks1 > 0) fetch(ks1, 1);
         if (ks1 <= 0) issued_next_none();
     }
-    // Unit i becomes readable.  `next` = k-steps of unit i+1 (still in flight afterwards), `next2` = k-steps of unit i+2,
-    // which is requested now into the slot unit i-1 just vacated (0 = no such unit).
+    // deeper rings: units 2 .. D - 2 of the initial run-ahead (call right after start(); 0 k-steps = no such unit)
+    __device__ __forceinline__ void start_more(int unit, int ks) {
+#pragma unroll
+        for (int i = D - 4; i > 0; --i) hist[i] = hist[i - 1];
+        hist[0] = issued;
+        if (ks > 0) fetch(ks, unit); else issued_next_none();
+    }
+    // Unit i becomes readable.  `next` = k-steps of unit i+1 (still in flight afterwards), `next2` = k-steps of unit i+D-1
+    // (i+2 for the three-slot ring), which is requested now into the slot unit i-1 just vacated (0 = no such unit).
     // The request for unit i+2 is only OPENED here; its DMA instructions are issued one per two k-steps from inside the
     // MFMA loop (fetch_piece) so that their issue cost (~60-100 cycles each) does not sit in front of the tile's MFMAs.
     __device__ __forceinline__ const float* acquire(int next, int next2) {
@@ -121,12 +137,18 @@ struct UnitStreamT {
         // together, in issue order).  Kernels that store tiles between units report those stores (note_vmem); ignoring
         // them made the wait stricter than needed: it drained the run-ahead DMA and the stores at every unit of the
         // training forward (MFMA pipe 34 % busy against 48 % without the stores).  The counter saturates at 63.
-        const int in_flight = issued + younger;
+        const int cur = issued + younger;
+        int in_flight = cur;
+#pragma unroll
+        for (int i = 0; i < D - 3; ++i) in_flight += hist[i];
+#pragma unroll
+        for (int i = D - 4; i > 0; --i) hist[i] = hist[i - 1];
+        if (D > 3) hist[0] = cur;
         const int allowed = next > 0 ? (in_flight < 63 ? in_flight : 63) : 0;
         // (the generic 64-way dispatch compiles to a compare-and-branch tree of ~30 scalar instructions, and with one wave
         // per SIMD every instruction is an issue slot: the steady-state counts of the 256-wide trunk -- the successor's
         // k/2 resp. k/4 DMA instructions and nothing else -- are tested first)
-        if (allowed == (P == 3 ? 8 : 16 / NW)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P == 3 ? 8 : 16 / NW) : "memory");
+        if (D == 3 && allowed == (P == 3 ? 8 : 16 / NW)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P == 3 ? 8 : 16 / NW) : "memory");
         else wait_vmcnt(allowed);
         younger = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my LDS reads of unit i-1 are complete
@@ -134,9 +156,9 @@ struct UnitStreamT {
         __builtin_amdgcn_s_barrier();
 #endif
         const float* ready = lds + slot * slot_floats;
-        const int vacated = slot == 0 ? kUnitBuffers - 1 : slot - 1;
+        const int vacated = slot == 0 ? D - 1 : slot - 1;
         if (next2 > 0) begin_fetch(next2, vacated); else issued_next_none();
-        slot = slot == kUnitBuffers - 1 ? 0 : slot + 1;
+        slot = slot == D - 1 ? 0 : slot + 1;
         return ready;
     }
 };
