@@ -430,7 +430,12 @@ def training_step(precision, rank, world, device, single_pass=False, graphed=Fal
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
     model = model.to(device).train()
-    batcher = BatchAssembler(cfg, synth.training_scene(), device, rank=rank, world_size=world)
+    # the sparse-depth epoch is a whole number of global batches (largest such count <= 1.5 M of the 2.29 M pixels), so that
+    # every iteration really has 2048 sparse rows per GPU.  (Until round 3 the scene held ~4 570 sparse points: every third
+    # iteration ran a 476-row sparse batch and the reported mean -- 8.39 ms in the 16-bit mode -- understated the full-size
+    # iteration, 9.3 ms, by 10 %.  `short_batches` in the line counts iterations of the timed region that were not full.)
+    sparse_points = (1500000 // (rows * world)) * rows * world
+    batcher = BatchAssembler(cfg, synth.training_scene(sparse_points=sparse_points), device, rank=rank, world_size=world)
     losses = LossComputer(cfg)
     opt = optim.Adam(list(model.parameters()), lr=cfg['optimizer']['lr_initial'],
                      betas=(cfg['optimizer']['beta1'], cfg['optimizer']['beta2']))
@@ -447,12 +452,16 @@ def training_step(precision, rank, world, device, single_pass=False, graphed=Fal
         it = state['iter']
         state['iter'] += 1
         if graph is not None:
-            return graph(it)
+            out = graph(it)
+            step.short_batches += int(graph.last_was_short)
+            return out
         for group in opt.param_groups:
             group['lr'] = decayer.get_updated_learning_rate(it)
-        return harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it), cfg['sub_batch_size'], world,
-                                      single_pass=single_pass)
+        batch = batcher.get_next_batch(it)
+        step.short_batches += int(batch['rays_o'].shape[0] != 2 * rows)
+        return harness.train_one_iter(model, losses, opt, batch, cfg['sub_batch_size'], world, single_pass=single_pass)
 
+    step.short_batches = 0
     return step, 2 * rows
 
 
@@ -472,7 +481,9 @@ def time_training(precision, device, steps, warmup, single_pass=False, board_sec
         step()
     torch.cuda.synchronize()
     ops.profile_reset()
+    step.short_batches = 0
     elapsed, device_ms, enqueue_ms = timed_steps(step, steps, torch.cuda.synchronize)
+    time_training.short_batches = step.short_batches
     fwd, _ = ops.profile_collect(ops.PROFILE_MLP_FORWARD)
     bwd, _ = ops.profile_collect(ops.PROFILE_MLP_BACKWARD)
     dropped = ops.profile_dropped()
@@ -480,6 +491,7 @@ def time_training(precision, device, steps, warmup, single_pass=False, board_sec
     time_training.board = None
     time_training.timing = step_summary(elapsed, device_ms, enqueue_ms, None)
     time_training.timing['launches_not_timed'] = dropped
+    time_training.timing['short_batches'] = step.short_batches   # iterations of the timed region with fewer than 4096 rows
     if board_seconds > 0:      # the same iteration for about a second with the board's power / clock sensors sampled
         sampler = BoardSampler(device.index or 0)
         with sampler:
@@ -540,6 +552,7 @@ def train_bench(args, rank, world, device, dist):
     fence()
     if world == 1:
         settle(step, None, chunk=2)
+    step.short_batches = 0
     elapsed, device_ms, enqueue_ms = timed_steps(step, args.steps, fence)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -555,6 +568,7 @@ def train_bench(args, rank, world, device, dist):
                        'parallelism': f'row-shard x{world}' + (' + 1 gradient all-reduce/step' if world > 1 else '')},
             'algorithmic_tflops': per_gpu * TRAIN_FLOP_PER_RAY * world * args.steps / elapsed / 1e12,
             'timing': step_summary(elapsed, device_ms, enqueue_ms, None)}
+        line['timing']['short_batches'] = step.short_batches   # timed iterations with fewer than rows_per_gpu rows (epoch ends)
         if world > 1:
             line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size()}
         print(json.dumps(line), flush=True)

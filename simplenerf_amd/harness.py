@@ -473,7 +473,8 @@ class GraphedIteration:
             for group in self.opt.param_groups:
                 group['lr'] = lr
         lr = self.opt.param_groups[0]['lr'] if lr is None else lr
-        if not self.batcher.is_full(positions):
+        self.last_was_short = not self.batcher.is_full(positions)
+        if self.last_was_short:
             # a short batch at the end of an epoch: the same sub-batched pass launched directly into the (zeroed) static
             # gradient buffers, then the ordinary optimiser step
             for p in self.model.parameters():

@@ -324,12 +324,19 @@ def optim_case(seed: int = 0) -> dict:
     return {'params': params, 'grads': grads, 'iters': iters, 'record': (1, 2, 6)}
 
 
-def training_scene(seed: int = 0, num_views: int = 3, height: int = 756, width: int = 1008, sparse_fraction: float = 2e-3) -> dict:
+def training_scene(seed: int = 0, num_views: int = 3, height: int = 756, width: int = 1008, sparse_fraction: float = 2e-3,
+                   sparse_points: int = None) -> dict:
     """``synth_scene`` at a training resolution in the form ``BatchAssembler`` takes, plus dense sparse-depth tables
-    (true plane depth + noise on a random ``sparse_fraction`` of the pixels, -1 elsewhere)."""
+    (true plane depth + noise on a random ``sparse_fraction`` of the pixels, -1 elsewhere).
+    ``sparse_points``: exactly that many pixels carry a sparse depth instead (a benchmark wants an epoch that is a whole
+    number of batches: with the default ~4 570 points every third 2048-row batch of the epoch is 476 rows short)."""
     scene = synth_scene(seed, num_views, height, width)
     rng = numpy.random.RandomState(seed + 50)
     has = rng.uniform(size=scene['true_depth'].shape) < sparse_fraction
+    if sparse_points is not None:
+        has = numpy.zeros(scene['true_depth'].size, dtype=bool)
+        has[rng.choice(has.size, size=int(sparse_points), replace=False)] = True
+        has = has.reshape(scene['true_depth'].shape)
     depth = numpy.where(has, scene['true_depth'] + 0.05 * rng.standard_normal(has.shape), -1.0).astype(numpy.float32)
     error = numpy.where(has, rng.uniform(0.1, 2.0, size=has.shape), -1.0).astype(numpy.float32)
     return {**scene, 'near': 1.0, 'far': 6.0, 'near_ndc': 0.0, 'far_ndc': 1.0, 'frame_nums': list(range(num_views)),
