@@ -141,8 +141,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // waves -- two per SIMD, 256 registers each -- sharing ONE weight stream (half the L2 -> LDS traffic and DMA instructions of
 // two 4-wave workgroups per CU) through a five-slot ring (see UnitStreamT: the counted waits then tolerate three units of
 // store latency).  Everything else: four waves, one per SIMD, three slots.
-constexpr int chain_waves(int products, bool viewdep) { return products == 1 && viewdep ? 8 : 4; }
-constexpr int chain_ring(int products, bool viewdep) { return products == 1 && viewdep ? 5 : kUnitBuffers; }
+constexpr int chain_waves(int products, bool viewdep, int depth) { return products == 1 && (viewdep || depth > 0) ? 8 : 4; }
+constexpr int chain_ring(int products, bool viewdep, int depth) { return products == 1 && (viewdep || depth > 0) ? 5 : kUnitBuffers; }
 
 // DEPTH > 0: compile-time trunk depth, layer loop fully unrolled -- the unit schedule (k-steps of each unit and its two
 // successors, DMA pieces, counted vmcnt immediates incl. the dY stores, ring slots) folds to constants instead of ~200
@@ -150,10 +150,10 @@ constexpr int chain_ring(int products, bool viewdep) { return products == 1 && v
 template <int WT, int VT, bool VIEWDEP, int P, int DEPTH>
 // (one workgroup per CU also for P = 1: at the 256-register budget of two the kernel spills ~120 registers and the
 // training iteration measured 11.1 -> 14.4 ms)
-__global__ void __launch_bounds__(chain_waves(P, VIEWDEP) * 64, chain_waves(P, VIEWDEP) == 8 ? 2 : 1) mlp_backward_chain_f16x3_kernel(HalfChainArgs args) {
+__global__ void __launch_bounds__(chain_waves(P, VIEWDEP, DEPTH) * 64, chain_waves(P, VIEWDEP, DEPTH) == 8 ? 2 : 1) mlp_backward_chain_f16x3_kernel(HalfChainArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NW = chain_waves(P, VIEWDEP);
-    constexpr int RING = chain_ring(P, VIEWDEP);
+    constexpr int NW = chain_waves(P, VIEWDEP, DEPTH);
+    constexpr int RING = chain_ring(P, VIEWDEP, DEPTH);
     const ChainArgs& a = args.c;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -294,6 +294,9 @@ __global__ void __launch_bounds__(chain_waves(P, VIEWDEP) * 64, chain_waves(P, V
                 if (!VIEWDEP) v = fmaf(w3[q], dhead[3], fmaf(w2[q], dhead[2], fmaf(w1[q], dhead[1], v)));
                 acc[g >> 2][4 * (g & 3) + q] += v;
             }
+            // (keeps the four-row variant's weight loads from being hoisted in front of the loop all at once: 512 registers
+            // of loaded weights made the 256-register instance spill 270)
+            if (!VIEWDEP && (g & 3) == 3) asm volatile("" ::: "memory");
         }
     }
     // ---- trunk, last layer first: dY_l = dh_{l+1} . [h_{l+1} > 0];  dh_l = W_l[:, h-columns]^T dY_l -------------
@@ -432,7 +435,7 @@ __global__ void __launch_bounds__(chain_waves(P, VIEWDEP) * 64, chain_waves(P, V
 
 template <int WT, int VT, bool VIEWDEP, int P, int DEPTH = 0>
 int launch_chain_half(const HalfChainArgs& args, hipStream_t stream) {
-    constexpr int NW = chain_waves(P, VIEWDEP), RING = chain_ring(P, VIEWDEP);
+    constexpr int NW = chain_waves(P, VIEWDEP, DEPTH), RING = chain_ring(P, VIEWDEP, DEPTH);
     // (the 16-bit workspace holds whole groups of eight wave blocks, plan_workspace; the padded blocks get zero gradients)
     const long long wave_blocks = P == 1 ? (args.c.total + 255) / 256 * 8 : (args.c.total + 127) / 128 * 4;
     const long long blocks = wave_blocks / NW;
@@ -461,6 +464,8 @@ int mlp_backward_chain_f16x3(const MlpPlan& plan, const ChainArgs& a, int produc
 #define SNERF_CHAIN(WT_, VT_, VD_) return products == 3 ? launch_chain_half<WT_, VT_, VD_, 3>(args, stream) : launch_chain_half<WT_, VT_, VD_, 1>(args, stream)
     if (key == 84 && a.depth == 8)   // the shipped 8 x 256 trunk with a views layer: compile-time unit schedule
         return products == 3 ? launch_chain_half<8, 4, true, 3, 8>(args, stream) : launch_chain_half<8, 4, true, 1, 8>(args, stream);
+    if (key == 80 && a.depth == 8 && products == 1)   // the augmentation MLPs of the shipped experiments (no views layer)
+        return launch_chain_half<8, 4, false, 1, 8>(args, stream);
     switch (key) {
         case 84: SNERF_CHAIN(8, 4, true);
         case 80: SNERF_CHAIN(8, 4, false);
