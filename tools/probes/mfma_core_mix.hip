@@ -1,6 +1,6 @@
 // What does the single-product MLP kernels' inner loop cost beyond its MFMAs?  One dependent chain of v_mfma_f32_32x32x16_f16
 // per wave, as in seg_mfma1 (mlp_device_f16.h), with optional extras per MFMA: (L) the 1-KiB weight fragment read from LDS
-// four k-steps ahead with counted lgkmcnt waits, (V) K full-rate VALU instructions, (S) K2 scalar instructions, (T) every 16th
+// four k-steps ahead with counted lgkmcnt waits, (V) K full-rate VALU instructions, (T) every 16th
 // MFMA a fresh accumulator (a new tile: no dependence on the previous MFMA).  One or two waves per SIMD.
 // Prints ns per MFMA and SIMD.   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/mfma_core_mix tools/probes/mfma_core_mix.hip
 #include <hip/hip_runtime.h>
@@ -22,7 +22,7 @@ template <int N> __device__ __forceinline__ void wait_but(f16x8& a) {
     if (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)::"memory");
 }
 
-template <bool L, int KV, int KS, int WAVES>
+template <bool L, int KV, int WAVES>
 __global__ void __launch_bounds__(WAVES * 256, WAVES) core_kernel(const f16x8* ops, float* out, int iters) {
     extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
     const int lane = threadIdx.x & 63;
@@ -32,7 +32,6 @@ __global__ void __launch_bounds__(WAVES * 256, WAVES) core_kernel(const f16x8* o
     f16x8 b = ops[64 + lane], a0 = ops[lane];
     f32x16 acc = {0};
     float v[8];
-    int sreg = iters;
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)a0[i] + i;
     float sink = 0;
@@ -56,23 +55,21 @@ __global__ void __launch_bounds__(WAVES * 256, WAVES) core_kernel(const f16x8* o
             }
 #pragma unroll
             for (int i = 0; i < KV; ++i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(v[i & 7]) : "v"(v[(i + 3) & 7]));
-#pragma unroll
-            for (int i = 0; i < KS; ++i) asm volatile("s_add_i32 %0, %0, 3" : "+s"(sreg));
         }
         sink += acc[0];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;     // next tile: fresh accumulator
     }
-    float s = sink + sreg;
+    float s = sink;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += v[i];
     if (s == 1234.5f) out[0] = s;
 }
 
-template <bool L, int KV, int KS, int WAVES>
+template <bool L, int KV, int WAVES>
 void run(const char* label, const f16x8* ops, float* out) {
     const int iters = 256;
-    auto k = core_kernel<L, KV, KS, WAVES>;
+    auto k = core_kernel<L, KV, WAVES>;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k, dim3(256), dim3(WAVES * 256), 16 * 1024, 0, ops, out, iters);
     hipDeviceSynchronize();
@@ -90,17 +87,15 @@ int main() {
     f16x8* ops; float* out;
     hipMalloc(&ops, h.size() * 2); hipMalloc(&out, 4);
     hipMemcpy(ops, h.data(), h.size() * 2, hipMemcpyHostToDevice);
-    run<false, 0, 0, 1>("warm-up", ops, out);
-    run<false, 0, 0, 1>("MFMA chain only", ops, out);
-    run<false, 0, 0, 2>("MFMA chain only", ops, out);
-    run<true, 0, 0, 1>("+ LDS fragment reads", ops, out);
-    run<true, 0, 0, 2>("+ LDS fragment reads", ops, out);
-    run<true, 7, 0, 1>("+ LDS + 7 VALU", ops, out);
-    run<true, 7, 0, 2>("+ LDS + 7 VALU", ops, out);
-    run<true, 7, 3, 1>("+ LDS + 7 VALU + 3 SALU", ops, out);
-    run<true, 7, 3, 2>("+ LDS + 7 VALU + 3 SALU", ops, out);
-    run<true, 4, 3, 2>("+ LDS + 4 VALU + 3 SALU", ops, out);
-    run<true, 3, 1, 2>("+ LDS + 3 VALU + 1 SALU", ops, out);
-    run<false, 7, 3, 2>("(no LDS) 7 VALU + 3 SALU", ops, out);
+    run<false, 0, 1>("warm-up", ops, out);
+    run<false, 0, 1>("MFMA chain only", ops, out);
+    run<false, 0, 2>("MFMA chain only", ops, out);
+    run<true, 0, 1>("+ LDS fragment reads", ops, out);
+    run<true, 0, 2>("+ LDS fragment reads", ops, out);
+    run<true, 4, 1>("+ LDS + 4 VALU", ops, out);
+    run<true, 4, 2>("+ LDS + 4 VALU", ops, out);
+    run<true, 7, 1>("+ LDS + 7 VALU", ops, out);
+    run<true, 7, 2>("+ LDS + 7 VALU", ops, out);
+    run<false, 7, 2>("(no LDS) 7 VALU", ops, out);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
