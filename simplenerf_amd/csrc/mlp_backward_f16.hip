@@ -281,6 +281,11 @@ __global__ void __launch_bounds__(chain_waves(P, VIEWDEP, DEPTH) * 64, chain_wav
         const float* wo = a.packed + a.pts_out_w;
 #pragma unroll
         for (int g = 0; g < WT * 4; ++g) {
+            // One tile's weight loads at a time: the pointer of tile t is made to depend on a finished value of tile t-1.
+            // Left free, the compiler issued the four-row variant's 128 loads (512 registers) in front of the loop and the
+            // 256-register instance spilled 270 of them -- 135 KB of scratch traffic per wave block, as much as the kernel's
+            // dY stores (PMC: 8.8 KB of HBM traffic per sample against the main chain's 4.8).
+            if (!VIEWDEP && g > 0 && (g & 3) == 0) asm volatile("" : "+s"(wo) : "v"(acc[(g >> 2) - 1][15]));
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(wo + 8 * g + 4 * half);
             f32x4 w1 = {0, 0, 0, 0}, w2 = {0, 0, 0, 0}, w3 = {0, 0, 0, 0};
             if (!VIEWDEP) {
@@ -294,9 +299,6 @@ __global__ void __launch_bounds__(chain_waves(P, VIEWDEP, DEPTH) * 64, chain_wav
                 if (!VIEWDEP) v = fmaf(w3[q], dhead[3], fmaf(w2[q], dhead[2], fmaf(w1[q], dhead[1], v)));
                 acc[g >> 2][4 * (g & 3) + q] += v;
             }
-            // (keeps the four-row variant's weight loads from being hoisted in front of the loop all at once: 512 registers
-            // of loaded weights made the 256-register instance spill 270)
-            if (!VIEWDEP && (g & 3) == 3) asm volatile("" ::: "memory");
         }
     }
     // ---- trunk, last layer first: dY_l = dh_{l+1} . [h_{l+1} > 0];  dh_l = W_l[:, h-columns]^T dY_l -------------
