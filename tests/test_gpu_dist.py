@@ -125,3 +125,23 @@ def test_bench_frame_mode_two_ranks_with_the_real_renderer():
     assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['steps'] == 2
     assert line['config']['rays_per_frame'] == 762048 and line['config']['rays_per_gpu'] == 381024
     assert line['collective']['bytes'] == 381024 * 28 and line['value'] > 1e4
+
+
+def test_bench_training_line_counts_full_size_iterations_only():
+    """``python bench.py --train --precision f16``: every timed iteration of BASELINE config 5 runs 2048 pixel + 2048
+    sparse-depth rows (the synthetic scene's sparse-depth epoch is a whole number of batches; until round 3 every third
+    iteration was 1 572 rows short and the line still divided by 4096), and the line says so (``timing.short_batches``)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--train', '--precision', 'f16', '--steps', '7', '--warmup', '2',
+                        '--no-alt', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert line['config']['rows_per_gpu'] == 4096 and line['steps'] == 7 and line['dtype'].startswith('f16')
+    assert line['timing']['short_batches'] == 0
+    trace = line['timing']['step_trace_ms']
+    # seven consecutive full-size iterations take the same time (a short one was 30 % faster)
+    assert len(trace) == 7 and max(trace[1:]) < 1.15 * min(trace[1:]), trace

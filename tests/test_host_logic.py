@@ -179,6 +179,20 @@ def test_batch_assembler_epoch_and_shard_arithmetic():
         assert covered == list(range(40, 140))
 
 
+def test_benchmark_scene_has_an_epoch_of_whole_batches():
+    """``synth.training_scene(sparse_points=...)`` puts a sparse depth on EXACTLY that many pixels, and the count bench.py
+    asks for is a whole number of global batches for every rank count the driver uses -- so that no timed iteration of
+    config 5 is a short one (the default scene's ~4 570 points made every third 2048-row batch 476 rows)."""
+    from simplenerf_amd import synth
+    scene = synth.training_scene(num_views=2, height=24, width=32, sparse_points=128)
+    assert int((scene['sparse_depths'] >= 0).sum()) == 128 == int((scene['sparse_errors'] >= 0).sum())
+    assert int((synth.training_scene(num_views=2, height=24, width=32)['sparse_depths'] >= 0).sum()) != 128   # default: a fraction
+    for world in (1, 2, 4, 8):
+        rows = 2048
+        points = (1500000 // (rows * world)) * rows * world        # bench.training_step
+        assert points % (rows * world) == 0 and points <= 3 * 756 * 1008 and points >= 64 * rows * world
+
+
 def test_frame_writer_round_trips(tmp_path):
     """harness.save_image / save_depth (the Tester's frame writer, reference src/Tester01.py:69-92): the PNG decodes
     back to the same pixels (parsed here with zlib only), .npy keeps the values, unknown suffixes raise."""
