@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(chain_waves(P, VIEWDEP, DEPTH) * 64, chain_wav
     const float head_max = fmaxf(fmaxf(fabsf(dhead[0]), fabsf(dhead[1])), fmaxf(fabsf(dhead[2]), fabsf(dhead[3])));
     if (dy_max) publish_max(dy_max + a.grad_head / 32, head_max, lane);   // region scale of the head-weight products
     float gscale = renorm_factor(head_max);
-    if (!(gscale < 1.0e30f)) gscale = 1.0e30f;
+    if (!(gscale < 0x1p99f)) gscale = 0x1p99f;   // (a power of two, like every factor that follows: the 16-bit trunk scales by exponent)
     float gback = 1.0f / gscale;
     const float dsig_raw = dhead[0];  // re-enters below, after the views/feature products have been renormalised
 #pragma unroll
@@ -318,6 +318,9 @@ __global__ void __launch_bounds__(chain_waves(P, VIEWDEP, DEPTH) * 64, chain_wav
         __bf16* const rows16 = reinterpret_cast<__bf16*>(grads);
         const int slot8 = (2 * (lane & 31) + half) * 8;
         float mrun = 0.0f;       // this lane's max |dY| over the tiles of the layer being finished, at the scale `acc` carries
+        // exponents of the two power-of-two factors (gback = 2^gback_exp: gscale is a product of renorm_factor() values)
+        auto exponent_of = [](float power_of_two) { return (int)((__float_as_uint(power_of_two) >> 23) & 0xffu) - 127; };
+        int gback_exp = exponent_of(gback), fnext_exp = 0;
         bf16x8 stage;
         auto epilogue_pair = [&](int t, int pr, int row0, const unsigned (&words)[WT / 2]) __attribute__((always_inline)) {
 #ifdef SNERF_ABL_CHAIN_NOEPI     // timing ablation (tools/probes/build_variant.py): no epilogue work at all -- wrong results
@@ -329,7 +332,10 @@ __global__ void __launch_bounds__(chain_waves(P, VIEWDEP, DEPTH) * 64, chain_wav
             acc[t][r] = x; acc[t][r + 1] = y;
             // (the NaN-propagating maximum: v_maximum3_f32 with |x| modifiers, no quieting moves in front of it)
             mrun = __builtin_elementwise_maximum(mrun, __builtin_elementwise_maximum(__builtin_fabsf(x), __builtin_fabsf(y)));
-            const bf16x2 q = __builtin_convertvector(f32x2{x, y} * gback, bf16x2);
+            // (the two power-of-two scalings of this path are v_ldexp_f32, not multiplies: the compiler packs a pair of fp32
+            // multiplies into one v_pk_mul_f32, and packed fp32 arithmetic is the one VALU class that does NOT issue in the
+            // shadow of an MFMA -- r03_mfma_valu_shadow.txt; 571 -> 534 us per fine-size call, gradients bit-identical)
+            const bf16x2 q = __builtin_convertvector(f32x2{__builtin_ldexpf(x, gback_exp), __builtin_ldexpf(y, gback_exp)}, bf16x2);
             stage[r & 7] = q[0]; stage[(r & 7) + 1] = q[1];
 #ifdef SNERF_ABL_CHAIN_NOSTORE   // timing ablation: the epilogue's arithmetic, but nothing written
             if (pr == 7 && t == 0 && stage[0] == (__bf16)123.0f)
@@ -341,13 +347,12 @@ __global__ void __launch_bounds__(chain_waves(P, VIEWDEP, DEPTH) * 64, chain_wav
                 st.note_vmem(1);
             }
         };
-        float fnext = 1.0f;
         auto convert_fragment = [&](int t) __attribute__((always_inline)) {
             const f32x16& src = acc[t >> 1];
             const int o = 8 * (t & 1);
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
-                const f16x2 h = __builtin_convertvector(f32x2{src[o + j], src[o + j + 1]} * fnext, f16x2);
+                const f16x2 h = __builtin_convertvector(f32x2{__builtin_ldexpf(src[o + j], fnext_exp), __builtin_ldexpf(src[o + j + 1], fnext_exp)}, f16x2);
                 xh[t][j] = h[0]; xh[t][j + 1] = h[1];
             }
         };
@@ -363,10 +368,12 @@ __global__ void __launch_bounds__(chain_waves(P, VIEWDEP, DEPTH) * 64, chain_wav
         auto phase = [&](int l) __attribute__((always_inline)) {   // products with W_l^T; epilogues of layer l - 1
             const float msample = lane_halves_max(mrun);
             if (dy_max) publish_max_dpp(dy_max + (l * a.width) / 32, msample * gback, lane);
-            fnext = renorm_factor(msample);
+            float fnext = renorm_factor(msample);
             if (!(gscale * fnext < 1.0e30f) || !(gscale * fnext > 1.0e-30f)) fnext = 1.0f;
             gscale *= fnext;
             gback = 1.0f / gscale;
+            fnext_exp = exponent_of(fnext);
+            gback_exp = exponent_of(gback);
             mrun = 0.0f;
 #pragma unroll
             for (int i = 0; i < WT / 2; ++i) words_now[i] = words_next[i];
