@@ -12,11 +12,16 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-enum { AND, BFE, PKMUL, CVTBF, CVTF16, MAX3, ACCRD, ALIGNBIT, PKADD, KINDS };
-static const char* kNames[KINDS] = {"and", "bfe", "pkmul", "cvtbf", "cvtf16", "max3", "accrd", "alignbit", "pkadd"};
+enum { AND, BFE, PKMUL, CVTBF, CVTF16, MAX3, ACCRD, ALIGNBIT, PKADD, PKMAXH, FMA, LDEXP, STORE, KINDS };
+static const char* kNames[KINDS] = {"and", "bfe", "pkmul", "cvtbf", "cvtf16", "max3", "accrd", "alignbit", "pkadd", "pkmaxf16", "fma", "ldexp", "store16B"};
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int KIND>
-__device__ __forceinline__ void one(float (&v)[16], f32x2 (&w)[8], const f32x16& spare, int i) {
+__device__ __forceinline__ void one(float (&v)[16], f32x2 (&w)[8], const f32x16& spare, int i, f32x4* sink = nullptr) {
+    if (KIND == PKMAXH) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(v[i & 15]) : "v"(v[(i + 5) & 15]));
+    if (KIND == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i & 15]) : "v"(v[(i + 5) & 15]), "v"(v[(i + 6) & 15]));
+    if (KIND == LDEXP) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(v[i & 15]) : "v"(3));
+    if (KIND == STORE) __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, sink + (i & 63) * 4096);
     float& x = v[i & 15];
     f32x2& p = w[i & 7];
     if (KIND == AND) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(v[(i + 5) & 15]));
@@ -46,7 +51,7 @@ __global__ void __launch_bounds__(256, 1) loop_kernel(const f16x8* ops, float* o
         for (int m = 0; m < 8; ++m) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < K; ++i) one<KIND>(v, w, spare, m * K + i);
+            for (int i = 0; i < K; ++i) one<KIND>(v, w, spare, m * K + i, reinterpret_cast<f32x4*>(out) + 1024 + (blockIdx.x * 256 + threadIdx.x));
         }
     }
     float s = 0;
@@ -80,12 +85,17 @@ int main() {
     std::vector<_Float16> h(128 * 8);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (_Float16)(0.001f * (i % 97));
     f16x8* ops; float* out;
-    hipMalloc(&ops, h.size() * 2); hipMalloc(&out, 4);
+    hipMalloc(&ops, h.size() * 2); hipMalloc(&out, (size_t)(1024 + 64 * 4096 + 65536) * 16);
     hipMemcpy(ops, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     run<AND, 0>(ops, out);
     const float base = run<AND, 0>(ops, out);
     printf("bare dependent MFMA chain: %.2f ns per MFMA (one wave per SIMD, 256 workgroups)\n", base);
     row<AND>(ops, out, base); row<BFE>(ops, out, base); row<PKMUL>(ops, out, base); row<PKADD>(ops, out, base); row<CVTBF>(ops, out, base);
     row<CVTF16>(ops, out, base); row<MAX3>(ops, out, base); row<ACCRD>(ops, out, base); row<ALIGNBIT>(ops, out, base);
+    row<PKMAXH>(ops, out, base); row<FMA>(ops, out, base); row<LDEXP>(ops, out, base);
+    {   // stores: K = 1 and 2 per MFMA only (16 B per lane = 1 KiB per instruction)
+        const float t1 = run<STORE, 1>(ops, out), t2 = run<STORE, 2>(ops, out);
+        printf("store16B  K=1 %.2f  K=2 %.2f   (one / two global_store_dwordx4 per MFMA)\n", t1 / base, t2 / base);
+    }
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
