@@ -5,6 +5,10 @@
 // Same arithmetic as mlp_forward_f16.hip: each operand is an fp16 hi/lo pair and each product is three MFMAs
 // (hi.hi + hi.lo + lo.hi) into an fp32 accumulator; W^T is pre-split at pack time (MlpPlan::half_dgrad_stages) and
 // streamed through the 3-slot LDS ring, one 32-row IN-feature tile (all of its k-steps over the OUT features) per unit.
+// P = 1 (SNERF_PRECISION_F16, the 16-bit training mode): one MFMA per product, bf16 dY pieces, and -- round 3 -- a trunk
+// whose layer epilogues ride behind the next tile's MFMAs (two waves per SIMD, eight-wave workgroups, five-slot ring); see
+// the comment at `if constexpr (P == 1)` below.  Bound: instruction issue + LDS fragment reads (45 ns per MFMA
+// and SIMD against a 26-ns "MFMA + one LDS fragment" floor); algorithmic HBM bytes 4.6 KB per sample (dY stores).
 #include <algorithm>
 #include <type_traits>
 
@@ -148,8 +152,9 @@ constexpr int chain_ring(int products, bool viewdep, int depth) { return product
 // successors, DMA pieces, counted vmcnt immediates incl. the dY stores, ring slots) folds to constants instead of ~200
 // scalar instructions per unit of 16 MFMAs (see mlp_forward_f16.hip).
 template <int WT, int VT, bool VIEWDEP, int P, int DEPTH>
-// (one workgroup per CU also for P = 1: at the 256-register budget of two the kernel spills ~120 registers and the
-// training iteration measured 11.1 -> 14.4 ms)
+// (P = 3 and the runtime-depth view-independent P = 1 instance: one 4-wave workgroup per CU, 512 registers per wave; the
+// 8-wave single-product instances run at the 256-register budget -- round 2's serial epilogue spilled ~120 registers there,
+// the pipelined trunk below none)
 __global__ void __launch_bounds__(chain_waves(P, VIEWDEP, DEPTH) * 64, chain_waves(P, VIEWDEP, DEPTH) == 8 ? 2 : 1) mlp_backward_chain_f16x3_kernel(HalfChainArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NW = chain_waves(P, VIEWDEP, DEPTH);
