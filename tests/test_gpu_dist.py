@@ -143,5 +143,7 @@ def test_bench_training_line_counts_full_size_iterations_only():
     assert line['config']['rows_per_gpu'] == 4096 and line['steps'] == 7 and line['dtype'].startswith('f16')
     assert line['timing']['short_batches'] == 0
     trace = line['timing']['step_trace_ms']
-    # seven consecutive full-size iterations take the same time (a short one was 30 % faster)
-    assert len(trace) == 7 and max(trace[1:]) < 1.15 * min(trace[1:]), trace
+    # no iteration is markedly FASTER than the typical one (a short batch was 30 % faster; a slow outlier on a busy box is
+    # not this test's business)
+    typical = sorted(trace[1:])[len(trace[1:]) // 2]
+    assert len(trace) == 7 and min(trace[1:]) > 0.85 * typical, trace
