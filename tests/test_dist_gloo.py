@@ -205,3 +205,28 @@ def test_bench_self_launch_reports_a_failing_rank():
     r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_bench_under_the_drivers_launcher():
+    """The driver's N > 1 command, verbatim: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 --steps K --warmup W`` -- the ranks come from the launcher (RANK / LOCAL_RANK /
+    WORLD_SIZE in the environment) instead of bench.py's own, and rank 0 alone prints the ONE JSON line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(SNERF_BENCH_STANDIN='1', SNERF_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 3 and line['warmup'] == 1 and line['scaling'] == 'weak'
+    assert line['collective']['ranks'] == 2 and line['value'] > 0 and len(line['timing']['step_trace_ms']) == 3
