@@ -9,7 +9,11 @@
 itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment) BEFORE anything in
 this process touches the GPU, relays rank 0's JSON line and exits with the ranks' status.  Under
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N``
-the launcher's environment is used as it is.  One rank per GPU, RCCL (torch.distributed backend "nccl") between them.
+the launcher's environment is used as it is.  One rank per GPU, RCCL (torch.distributed backend "nccl") between them;
+a launch with more ranks than the node has GPUs is refused.  ``--force-collective`` runs the N > 1 protocol (process group,
+barrier, the per-step gather, max-over-ranks reduction) with N = 1, so that every RCCL call of the multi-GPU line executes
+on a one-GPU box.  (GPU-less rehearsals of the launcher and of the N > 1 protocol live in tests/bench_rehearsal.py, which
+calls ``main`` with a stand-in renderer and the gloo backend; this file has no such switch.)
 
 One "step" = one pass of the whole hot path over one batch of 1024 rays per GPU: on-device ray generation for the
 rank's pixel block of a fern frame, coarse depths, coarse MLP, compositing, inverse-CDF resampling + merge, fine MLP,
@@ -34,7 +38,10 @@ Printed JSON (rank 0, one line) also carries
                 inside the timed region / their HIP-event durations, against 157.3 TFLOP/s (MI355X_MICROARCH.md)
   cpu_baseline  the oracle (torch CPU fp32 restatement of the reference path, reference chunking) timed on this
                 host on the same 1024-ray batch, best of 9 after one warm-up
-  collective    (N > 1) backend, number of ranks and bytes per rank and step torch.distributed moves
+  collective    (N > 1) backend, number of ranks and bytes per rank and step torch.distributed moves, ``gather_ms`` (the
+                gather's own time per step, events around the call on the launch stream: p50 / max over the timed steps, per
+                rank) and ``per_rank`` (each rank's step_ms p50, its MLP-kernel ms per step and its elapsed seconds) so that
+                a sub-linear point is attributable to a rank, to the kernels or to the collective
   also_measured*        the same step in the other two arithmetic modes (N = 1)
   also_measured_frame   BASELINE configs 2 and 4 as whole frames: raygen -> render -> display conversion -> D2H of the five
                         display outputs (Tester.predict_frame), wall time per frame.  N = 1: fern 1008x756 (reference-native),
@@ -93,7 +100,7 @@ FRAME_DISPLAY_BYTES = 3 + 4 * 4       # uint8 colour + depth, depth_var, depth_n
 FRAME_GATHER_BYTES = 4 * (3 + 4)      # fp32 colour + the four depth columns per ray cross xGMI to rank 0
 
 
-def launch_ranks(num_ranks: int) -> int:
+def launch_ranks(num_ranks: int, script=None) -> int:
     """Self-launch for ``--gpus N`` without a launcher: N child processes, one per GPU, each a fresh interpreter running
     this file with the rank environment set.  The parent never initialises the GPU (no HIP call, no library load) and
     never exec()s: it waits, forwards rank 0's output and returns the worst exit status.  If a rank dies the others are
@@ -108,7 +115,7 @@ def launch_ranks(num_ranks: int) -> int:
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         log = tempfile.TemporaryFile(mode='w+')
         logs.append(log)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=log,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=log,
                                       stderr=None if rank == 0 else subprocess.STDOUT))
     codes = [None] * num_ranks
     while any(c is None for c in codes):
@@ -157,47 +164,69 @@ def synthetic_model(configs, seed, device, precision='fp32'):
 
 
 def host_cores():
-    """Threads for the CPU leg: the cores this process may run on, capped at the GPU box's per-GPU CPU share (16)."""
+    """The cores this process may run on (its affinity mask; os.cpu_count() where the platform has none)."""
     try:
-        n = len(os.sched_getaffinity(0))
+        return max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(n, 16))
+        return max(1, os.cpu_count() or 1)
 
 
-def cpu_baseline(configs, camera, first_ray, runs=9):
-    """Oracle on the host CPU, same rays and weights as the GPU step; bounded: 1 warm-up + ``runs`` passes over the 1024
-    rays (~10 s of CPU work on 16 cores)."""
+def cpu_baseline(configs, camera, first_ray, budget_seconds=9.0, max_runs=9):
+    """Oracle on the host CPU, same rays and weights as the GPU step.  BASELINE.md section 3's protocol --
+    ``torch.set_num_threads(os.cpu_count())``, one warm-up, best of the following passes -- plus, beside it, the same at 16
+    threads (the GPU box's per-GPU CPU share: with more threads than cores the process may use, the first leg oversubscribes).
+    Each leg is bounded: 1 warm-up + up to ``max_runs`` passes over the 1024 rays or ``budget_seconds`` of CPU work, whichever
+    comes first.  `value` is the FASTER leg (the baseline at its best), `cores` the threads of that leg."""
     from oracle import nerf_oracle, raygen_oracle
     _, _, synth, get_model = _pkg()
-    cores = host_cores()
-    torch.set_num_threads(cores)
     shapes = {k: tuple(v.shape) for k, v in get_model(configs, None).state_dict().items()}
     params = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, sigma_gain=200.0, sigma_shift=8.0).items()}
     full = raygen_oracle.full_frame_batch(camera['resolution'], camera['intrinsic'], camera['pose'], camera['near'],
                                           camera['far'], True, camera['near_ndc'], camera['far_ndc'])
     batch = {k: torch.from_numpy(numpy.ascontiguousarray(v[first_ray:first_ray + RAYS_PER_GPU])) for k, v in full.items()}
-    times = []
-    with torch.no_grad():
-        for i in range(runs + 1):
-            t0 = time.perf_counter()
-            nerf_oracle.render(params, configs, batch, training=False)
-            if i > 0:
+
+    def leg(threads):
+        torch.set_num_threads(threads)
+        times = []
+        with torch.no_grad():
+            nerf_oracle.render(params, configs, batch, training=False)        # warm-up
+            while len(times) < max_runs and (not times or sum(times) < budget_seconds):
+                t0 = time.perf_counter()
+                nerf_oracle.render(params, configs, batch, training=False)
                 times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {'value': RAYS_PER_GPU / best, 'unit': 'rays/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{RAYS_PER_GPU} rays of the same workload, best of {runs} after 1 warm-up ({best:.3f} s best, '
-                      f'{sum(times) / len(times):.3f} s mean; {sum(times):.1f} s of CPU work), torch {torch.__version__} CPU fp32, '
-                      f'chunk 4096 / netchunk 16384'}
+        return {'threads': threads, 'value': RAYS_PER_GPU / min(times), 'unit': 'rays/s', 'runs': len(times),
+                'best_s': min(times), 'mean_s': sum(times) / len(times)}
+
+    counts = []
+    for n in (os.cpu_count() or 1, 16):
+        if n not in counts:
+            counts.append(n)
+    previous = torch.get_num_threads()
+    try:
+        legs = [leg(n) for n in counts]
+    finally:
+        torch.set_num_threads(previous)
+    best = max(legs, key=lambda r: r['value'])
+    return {'value': best['value'], 'unit': 'rays/s', 'cores': best['threads'], 'kind': 'port',
+            'sample': f"{RAYS_PER_GPU} rays of the same workload, best of {best['runs']} after 1 warm-up ({best['best_s']:.3f} s best, "
+                      f"{best['mean_s']:.3f} s mean), torch {torch.__version__} CPU fp32, chunk 4096 / netchunk 16384",
+            'legs': legs, 'host': {'os_cpu_count': os.cpu_count(), 'usable_cores': host_cores()}}
 
 
 def pmc_traffic(precision):
-    """HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run (profiles/), or None."""
-    path = os.path.join(REPO, 'profiles', 'pmc_traffic.json' if precision == 'fp32' else f'pmc_traffic_{precision}.json')
-    if os.path.exists(path):
-        with open(path) as f:
-            return json.load(f).get('mlp_forward_hbm_bytes_per_launch')
-    return None
+    """HBM bytes per launch of the dominant kernel and where the figure comes from.  bench.py cannot read the memory
+    counters of its own process (they need rocprofv3 around it): the figure is the one a separate ``rocprofv3 --pmc`` run of
+    this same command wrote to profiles/ (tools/pmc_passes.sh + tools/collect_pmc.py), named in ``traffic_source`` with the
+    commit it was collected at.  -> (bytes or None, source text or None)"""
+    name = 'pmc_traffic.json' if precision == 'fp32' else f'pmc_traffic_{precision}.json'
+    path = os.path.join(REPO, 'profiles', name)
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        record = json.load(f)
+    source = (f"profiles/{name}: separate rocprofv3 --pmc passes of `bench.py --no-cpu-baseline --no-alt` (FETCH_SIZE | WRITE_SIZE), "
+              f"collected at commit {record.get('commit', 'unrecorded')} -- NOT measured in this run")
+    return record.get('mlp_forward_hbm_bytes_per_launch'), source
 
 
 # ---------------------------------------------------------------------------------------------- timing protocol
@@ -294,7 +323,8 @@ def headline_line(world, steps, warmup, precision, elapsed, device_ms, enqueue_m
     if launch_ms:
         achieved = sum(launch_samples) * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12
         line['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                            'traffic': pmc_traffic(precision), 'kernel': kernel_name, 'note': note, 'launches': len(launch_ms),
+                            'traffic': pmc_traffic(precision)[0], 'traffic_source': pmc_traffic(precision)[1],
+                            'traffic_algorithmic': sum(launch_samples) * 20 / len(launch_ms) + 595844 * 4, 'kernel': kernel_name, 'note': note, 'launches': len(launch_ms),
                             'avg_launch_ms': kernel_ms / len(launch_ms), 'kernel_share_of_step': kernel_ms / (elapsed * 1e3),
                             'launches_not_timed': int(dropped),
                             'step_frac': world * RAYS_PER_GPU * steps * (128 + 256) * FLOP_PER_SAMPLE / elapsed / 1e12 / peak / world}
@@ -304,15 +334,37 @@ def headline_line(world, steps, warmup, precision, elapsed, device_ms, enqueue_m
     return line
 
 
+def max_over_ranks(value, dist, device):
+    """the contract's max-over-ranks of a scalar (one all-reduce; the tensor lives on the rank's GPU under RCCL)"""
+    if dist is None:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def per_rank_table(values, dist, device):
+    """``values`` (a short list of floats) of every rank, as a list of lists indexed by rank (one all-gather)."""
+    if dist is None:
+        return [list(map(float, values))]
+    where = device if dist.get_backend() == 'nccl' else None         # gloo gathers host tensors
+    mine = torch.tensor(values, dtype=torch.float64, device=where)
+    table = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(table, mine)
+    return [[float(v) for v in row.cpu()] for row in table]
+
+
 # ---------------------------------------------------------------------------------------------- renderers
 class HipRenderer:
     """The product path for one rank: the drop-in model on this rank's GPU."""
     gpu = True
 
-    def __init__(self, precision, device, rank, world, kind='headline'):
+    def __init__(self, precision, device, rank, world, kind='headline', collective=None):
         harness, ops, synth, _ = _pkg()
         self.harness, self.ops, self.synth = harness, ops, synth
         self.precision, self.device, self.rank, self.world = precision, device, rank, world
+        self.collective = world > 1 if collective is None else collective      # True with one rank under --force-collective
+        self.gather_marks = None         # [(before, after)] per step while the gather is being timed
         self.configs = synth.with_overrides(synth.make_configs(kind), hip_precision=precision)
         self.model = synthetic_model(synth.make_configs(kind), 7, device, precision)
         self.camera = synth.camera('fern', 0)
@@ -327,9 +379,18 @@ class HipRenderer:
 
     def step(self):
         local = self.local()
-        if self.world > 1:
+        if not self.collective:
+            return local
+        if self.gather_marks is None:
             return self.harness.gather_rays(local, self.world * RAYS_PER_GPU, self.rank, self.world)
-        return local
+        # the gather's own time: events on the launch stream either side of the call (torch.distributed makes this stream
+        # wait for the collective's, so the second event fires when the gathered data may be used)
+        before, after = _Mark(self.gpu), _Mark(self.gpu)
+        before.record()
+        full = self.harness.gather_rays(local, self.world * RAYS_PER_GPU, self.rank, self.world)
+        after.record()
+        self.gather_marks.append((before, after))
+        return full
 
     def frame_camera(self, name):
         scene, kwargs, _ = FRAMES[name]
@@ -337,7 +398,8 @@ class HipRenderer:
 
     def frame(self, name):
         """Tester.predict_frame for this rank's block of the frame; the five display outputs as host arrays on rank 0."""
-        return self.harness.predict_frame(self.model, self.configs, self.frame_camera(name), self.device, self.rank, self.world)
+        return self.harness.predict_frame(self.model, self.configs, self.frame_camera(name), self.device, self.rank, self.world,
+                                          collective=self.collective)
 
     def frame_block(self, name, rays=65536):
         cam = self.frame_camera(name)
@@ -354,67 +416,8 @@ class HipRenderer:
         return ms, samples, self.ops.profile_dropped()
 
 
-class StandInRenderer:
-    """SNERF_BENCH_STANDIN=1 (tests/test_dist_gloo.py only): the renderer replaced by a CPU stand-in whose outputs are a
-    function of the global ray index, so that the launcher, rendezvous, settle / warm-up / timed protocol, per-rank
-    blocks, gathers, max-over-ranks timing and the JSON lines of BOTH bench modes run without GPUs and every gathered
-    frame can be checked exactly.  The lines say ``"data": "stand-in"``; they are not measurements."""
-    gpu = False
-    FRAME = (37, 41)      # rays = 1517: ragged over 2, 3 and 8 ranks
-
-    def __init__(self, precision, device, rank, world, kind='headline'):
-        from simplenerf_amd import harness
-        self.harness, self.rank, self.world = harness, rank, world
-        self.first = rank * RAYS_PER_GPU
-
-    @staticmethod
-    def _outputs(first, count):
-        idx = torch.arange(first, first + count, dtype=torch.float32)
-        return {'rgb_fine': torch.stack([idx, 2 * idx, 3 * idx], 1), 'depth_fine': idx + 0.5}
-
-    def local(self):
-        return self._outputs(self.first, RAYS_PER_GPU)
-
-    def step(self):
-        local = self.local()
-        if self.world > 1:
-            full = self.harness.gather_rays(local, self.world * RAYS_PER_GPU, self.rank, self.world)
-        else:
-            full = local
-        if self.rank == 0:
-            ref = self._outputs(0, self.world * RAYS_PER_GPU)
-            assert all(torch.equal(full[k], ref[k]) for k in ref)
-        return full
-
-    def frame_camera(self, name):
-        return {'resolution': self.FRAME}
-
-    def frame(self, name):
-        n = self.FRAME[0] * self.FRAME[1]
-        first, count = self.harness.shard_range(n, self.rank, self.world)
-        local = self._outputs(first, count)
-        full = self.harness.gather_rays(local, n, self.rank, self.world) if self.world > 1 else local
-        if self.rank != 0:
-            return None
-        ref = self._outputs(0, n)
-        assert all(torch.equal(full[k], ref[k]) for k in ref)
-        return {'image': full['rgb_fine'].numpy(), 'depth': full['depth_fine'].numpy()}
-
-    def frame_block(self, name, rays=65536):
-        self._outputs(0, 64)
-
-    def profile(self, capacity):
-        pass
-
-    def profile_reset(self):
-        pass
-
-    def profile_collect(self):
-        return [], [], 0
-
-
 # ---------------------------------------------------------------------------------------------- config 5 (training)
-def training_step(precision, rank, world, device, single_pass=False, graphed=False):
+def training_step(precision, rank, world, device, single_pass=False, graphed=False, collective=False):
     """BASELINE config 5: a callable running ONE iteration of the reference's training loop (Trainer.train_one_iter,
     src/Trainer01.py:60-107) with every stage on the device: batch assembly (2048 pixel + 2048 sparse-depth rows per GPU,
     each rank a slice of one global index stream), four MLPs forward, nine losses, backward, ONE all-reduce of the
@@ -459,7 +462,8 @@ def training_step(precision, rank, world, device, single_pass=False, graphed=Fal
             group['lr'] = decayer.get_updated_learning_rate(it)
         batch = batcher.get_next_batch(it)
         step.short_batches += int(batch['rays_o'].shape[0] != 2 * rows)
-        return harness.train_one_iter(model, losses, opt, batch, cfg['sub_batch_size'], world, single_pass=single_pass)
+        return harness.train_one_iter(model, losses, opt, batch, cfg['sub_batch_size'], world, single_pass=single_pass,
+                                      force_collective=collective)
 
     step.short_batches = 0
     return step, 2 * rows
@@ -540,10 +544,10 @@ def training_record(device, steps=10, warmup=3):
 
 def train_bench(args, rank, world, device, dist):
     """--train: BASELINE config 5 instead of the headline metric (see training_step)."""
-    step, per_gpu = training_step(args.precision, rank, world, device, args.single_pass)
+    step, per_gpu = training_step(args.precision, rank, world, device, args.single_pass, collective=dist is not None)
 
     def fence():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -554,10 +558,8 @@ def train_bench(args, rank, world, device, dist):
         settle(step, None, chunk=2)
     step.short_batches = 0
     elapsed, device_ms, enqueue_ms = timed_steps(step, args.steps, fence)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    ranks = per_rank_table([_quantiles(device_ms)['p50'], elapsed], dist, device)
+    elapsed = max_over_ranks(elapsed, dist, device)
     if rank == 0:
         line = {
             'metric': 'training rays/sec (config 5: forward + backward + optimiser, 4 MLPs, 9 losses)',
@@ -569,8 +571,10 @@ def train_bench(args, rank, world, device, dist):
             'algorithmic_tflops': per_gpu * TRAIN_FLOP_PER_RAY * world * args.steps / elapsed / 1e12,
             'timing': step_summary(elapsed, device_ms, enqueue_ms, None)}
         line['timing']['short_batches'] = step.short_batches   # timed iterations with fewer than rows_per_gpu rows (epoch ends)
-        if world > 1:
-            line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size()}
+        if dist is not None:
+            line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(), 'bytes': 2265488 * 4,
+                                  'pattern': 'one all-reduce of the flattened parameter gradients per iteration',
+                                  'per_rank': [{'rank': i, 'step_ms_p50': r[0], 'elapsed_s': r[1]} for i, r in enumerate(ranks)]}
         print(json.dumps(line), flush=True)
 
 
@@ -590,11 +594,7 @@ def time_frames(renderer, name, frames, warmup, fence, world, dist=None, device=
     for _ in range(frames):
         out = renderer.frame(name)
     fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, device)
     return elapsed, rays, out
 
 
@@ -641,7 +641,7 @@ def frame_bench(args, rank, world, device, dist, make_renderer, data):
     generates and renders its own block, rank 0 receives the frame through one gather, converts and copies it to the host.
     `value` = frame rays x K frames / max-over-ranks wall time."""
     def fence():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         if data == 'synthetic':
             torch.cuda.synchronize()
@@ -658,11 +658,12 @@ def frame_bench(args, rank, world, device, dist, make_renderer, data):
             'ms_per_step': entry['ms_per_frame'], 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': PRECISION_INFO[args.precision][1] if data == 'synthetic' else 'none', 'data': data,
             'config': {'workload': FRAMES[args.frame][2] + ': one frame per step, ' + FRAME_PATH, 'rays_per_frame': rays,
-                       'rays_per_gpu': per, 'samples': '64+128', 'parallelism': f'ray-shard x{world}' + (' + 1 gather/frame' if world > 1 else '')},
+                       'rays_per_gpu': per, 'samples': '64+128',
+                       'parallelism': f'ray-shard x{world}' + (' + 1 gather/frame' if dist is not None else '')},
             'roofline': {'bound': 'mfma', 'achieved': entry['algorithmic_tflops'], 'peak': entry['peak_tflops'], 'unit': 'TFLOP/s',
                          'frac': entry['frac_of_peak'], 'traffic': None,
                          'note': 'whole-frame wall time (not a kernel time): algorithmic FLOPs of the frame / wall, against N x the per-GPU peak'}}
-    if world > 1:
+    if dist is not None:
         line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                               'bytes': per * FRAME_GATHER_BYTES, 'pattern': 'one gather of the five per-ray outputs to rank 0 per frame'}
     print(json.dumps(line), flush=True)
@@ -678,28 +679,38 @@ def measure_headline(renderer, steps, warmup, fence, world, do_settle=True):
             renderer.step()
         fence()
         renderer.profile_reset()
+        if renderer.collective:
+            renderer.gather_marks = []          # from here on every step brackets its gather with two events
         elapsed, device_ms, enqueue_ms = timed_steps(renderer.step, steps, fence, renderer.gpu)
+    gather_ms = [a.ms_until(b) for a, b in (renderer.gather_marks or [])]
+    renderer.gather_marks = None
     launch_ms, launch_samples, dropped = renderer.profile_collect()
     renderer.profile(0)
     return {'elapsed': elapsed, 'device_ms': device_ms, 'enqueue_ms': enqueue_ms, 'launch_ms': launch_ms,
-            'launch_samples': launch_samples, 'dropped': dropped, 'settle_info': settle_info}
+            'launch_samples': launch_samples, 'dropped': dropped, 'settle_info': settle_info, 'gather_ms': gather_ms}
 
 
 def render_bench(args, rank, world, device, dist, make_renderer, data):
     gpu = data == 'synthetic'
 
+    collective = dist is not None          # N > 1, or N = 1 under --force-collective
+
     def fence():
-        if world > 1:
+        if collective:
             dist.barrier()
         if gpu:
             torch.cuda.synchronize()
 
     renderer = make_renderer(args.precision, 'headline')
     m = measure_headline(renderer, args.steps, args.warmup, fence, world)
-    if world > 1:
-        t = torch.tensor([m['elapsed']], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        m['elapsed'] = float(t.item())
+    ranks = None
+    if collective:
+        # what each rank saw, so that a sub-linear point can be attributed: its own step time, the MLP kernels' share of
+        # it, the gather's own time, its elapsed seconds (the line's value uses the maximum)
+        g = _quantiles(m['gather_ms']) if m['gather_ms'] else {'p50': 0.0, 'max': 0.0}
+        ranks = per_rank_table([_quantiles(m['device_ms'])['p50'], sum(m['launch_ms']) / max(args.steps, 1), g['p50'], g['max'],
+                                m['elapsed']], dist, device)
+        m['elapsed'] = max_over_ranks(m['elapsed'], dist, device)
     result = None
     if rank == 0:
         result = headline_line(world, args.steps, args.warmup, args.precision, m['elapsed'], m['device_ms'], m['enqueue_ms'],
@@ -707,17 +718,23 @@ def render_bench(args, rank, world, device, dist, make_renderer, data):
         if not gpu:
             result['dtype'] = 'none'
             result['config'] = {'workload': 'launcher rehearsal, no renderer'}
-        if world > 1:
+        if collective:
             result['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
-                                    'bytes': RAYS_PER_GPU * 16, 'pattern': 'one gather of (rgb, depth) = 16 B/ray to rank 0 per step'}
+                                    'bytes': RAYS_PER_GPU * 16, 'pattern': 'one gather of (rgb, depth) = 16 B/ray to rank 0 per step',
+                                    'gather_ms': {'p50': max(r[2] for r in ranks), 'max': max(r[3] for r in ranks),
+                                                  'how': 'events either side of the gather on each rank, worst rank'},
+                                    'per_rank': [{'rank': i, 'step_ms_p50': r[0], 'mlp_kernel_ms_per_step': r[1],
+                                                  'gather_ms_p50': r[2], 'gather_ms_max': r[3], 'elapsed_s': r[4]}
+                                                 for i, r in enumerate(ranks)]}
+            result['config']['parallelism'] = f'ray-shard x{world} + 1 gather/step'
     alt = args.precision == 'fp32' and not args.no_alt
-    if world > 1 and alt:
+    if collective and alt:
         frames = frame_records_sharded(make_renderer, fence, rank, world, dist, device)     # every rank takes part
         if rank == 0:
             result['also_measured_frame'] = frames
     if rank != 0:
         return
-    if world == 1 and alt and gpu:
+    if not collective and alt and gpu:
         harness, ops, synth, _ = _pkg()
 
         def board_state(r, achieved_tflops, nominal_peak, seconds=1.2):
@@ -773,7 +790,15 @@ def render_bench(args, rank, world, device, dist, make_renderer, data):
     print(json.dumps(result), flush=True)
 
 
-def main():
+def visible_gpus():
+    """GPUs this process can use (does not initialise HIP on this image)."""
+    return torch.cuda.device_count()
+
+
+def main(argv=None, renderer_cls=None, backend='nccl', share_devices=False, script=None):
+    """``renderer_cls`` / ``backend`` / ``share_devices`` / ``script`` are for tests/bench_rehearsal.py only (a GPU-less
+    stand-in renderer, gloo instead of RCCL, several ranks on one GPU, and the file the self-launcher starts its ranks from);
+    `python bench.py` always runs HipRenderer over RCCL with one rank per GPU."""
     global SETTLE_SECONDS
     ap = argparse.ArgumentParser()
     ap.add_argument('--train', action='store_true',
@@ -791,48 +816,62 @@ def main():
                     help=f'untimed settle phase before the warm-up steps (default {SETTLE_SECONDS}; 0 reproduces the cold start)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary measurements (other precisions, frames, training, sustained)')
+    ap.add_argument('--force-collective', action='store_true',
+                    help='run the N > 1 protocol -- process group, barriers, the per-step gather (or gradient all-reduce), the '
+                         'max-over-ranks reduction -- with whatever N is, including 1: every RCCL call of the multi-GPU line on a '
+                         'one-GPU box')
     ap.add_argument('--precision', choices=('fp32', 'f16x3', 'f16'), default='fp32',
                     help="arithmetic of the fused MLP kernel: fp32 MFMA; fp16 hi/lo split with 3 MFMAs per product "
                          "(fp32-grade results, same parity tests); or f16 = one fp16 MFMA per product with 16-bit saved "
                          "tensors (BASELINE config 5's 16-bit training mode, own tolerances: tests/test_gpu_f16.py)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.settle_seconds is not None:
         SETTLE_SECONDS = max(0.0, args.settle_seconds)
     if args.steps is None:
         args.steps = 5 if args.frame else 50
     if args.warmup is None:
         args.warmup = 1 if args.frame else 5
+    standin = renderer_cls is not None
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        raise SystemExit(launch_ranks(args.gpus))       # nothing above this line touches the GPU
+        if backend == 'nccl' and not share_devices and args.gpus > visible_gpus():
+            raise SystemExit(f'--gpus {args.gpus}: this node has {visible_gpus()} GPU(s); RCCL needs one device per rank')
+        raise SystemExit(launch_ranks(args.gpus, script))       # nothing above this line touches the GPU
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but the launcher set WORLD_SIZE={world}')
-    standin = os.environ.get('SNERF_BENCH_STANDIN') == '1'
     dist = None
     device = None
     if not standin:
         if not torch.cuda.is_available():
             raise SystemExit('bench.py needs an MI355X: the HIP renderer has no CPU path')
-        local_rank = local_rank % torch.cuda.device_count()
+        count = torch.cuda.device_count()
+        if share_devices:
+            local_rank = local_rank % count         # rehearsal only: several ranks on the one GPU of a test box (gloo)
+        elif world > count or local_rank >= count:
+            # one rank per GPU, no wrap-around: two RCCL ranks on one device fail late and obscurely (and two ranks sharing a
+            # GPU would halve each other's throughput silently with any other backend)
+            raise SystemExit(f'rank {rank}: LOCAL_RANK={local_rank}, WORLD_SIZE={world} but this node shows {count} GPU(s); '
+                             f'bench.py runs one rank per GPU')
         torch.cuda.set_device(local_rank)
         device = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # RCCL ('nccl') on a multi-GPU node; SNERF_DIST_BACKEND=gloo lets the same code path be rehearsed with several
-        # ranks sharing one GPU (RCCL refuses two ranks on one device) or, with the stand-in renderer, on the CPU
-        backend = os.environ.get('SNERF_DIST_BACKEND', 'nccl')
-        if backend == 'nccl':
+        if 'MASTER_PORT' not in os.environ:       # --force-collective without a launcher: a one-rank group of our own
+            with socket.socket() as sock:
+                sock.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
+        if backend == 'nccl':                     # RCCL, bound to this rank's device
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     def make_renderer(precision, kind):
-        return (StandInRenderer if standin else HipRenderer)(precision, device, rank, world, kind)
+        return (renderer_cls or HipRenderer)(precision, device, rank, world, kind, collective=dist is not None)
 
     data = 'stand-in' if standin else 'synthetic'
     try:
@@ -845,7 +884,7 @@ def main():
         else:
             render_bench(args, rank, world, device, dist, make_renderer, data)
     finally:
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
 

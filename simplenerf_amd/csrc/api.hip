@@ -35,7 +35,13 @@ std::atomic<int> g_profile_on{0};
 int profile_begin(int kind, hipStream_t stream, long long samples) {
     if (!g_profile_on.load(std::memory_order_relaxed)) return -1;
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone) return -1;
+    if (hipStreamIsCapturing(stream, &capture) != hipSuccess) {
+        // e.g. the legacy stream while another stream captures in global mode (hipErrorStreamCaptureImplicit): not timed, and
+        // the error must not stay behind for an unrelated launch's hipGetLastError
+        (void)hipGetLastError();
+        return -1;
+    }
+    if (capture != hipStreamCaptureStatusNone) return -1;
     std::lock_guard<std::mutex> lock(g_profile_mutex);
     if (g_profile_used >= (int)g_profile.size()) { ++g_profile_dropped; return -1; }
     const int slot = g_profile_used++;

@@ -1062,7 +1062,16 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
 #ifdef SNERF_PROBE_NO_SMALL_FOLD     // A/B probe builds: one launch per register-tile class, as before round 3
     auto small16 = [&](const WgradJob&) { return false; };
 #else
-    auto small16 = [&](const WgradJob& job) { return f16 && job.out_tiles * job.in_tiles < 32; };
+    // ... provided the four waves of that instance COVER the job: wave (wo, wi) of a wgrid_o x wgrid_i grid owns out tiles
+    // [2 wo, 2 wo + 2) x in tiles [2 wi, 2 wi + 2) (wgrad16_kernel: wgrid_i = max(in_tiles / 2, 1)); a shape they do not
+    // cover (3 in-tiles, 16 x 1, ...) goes to its own register-tile class below instead of silently losing tiles
+    auto small16 = [&](const WgradJob& job) {
+        if (!f16 || job.out_tiles * job.in_tiles >= 32) return false;
+        const int wgrid_i = std::max(job.in_tiles / 2, 1);
+        if (wgrid_i > 4 || 4 % wgrid_i != 0) return false;
+        const int wgrid_o = 4 / wgrid_i;
+        return wgrid_i * 2 >= job.in_tiles && wgrid_o * 2 >= job.out_tiles;
+    };
 #endif
     if (f16) {
         JobTable sub;

@@ -32,6 +32,7 @@ struct MlpArgs {
     float* visibility2;       // (total, num_other)
     int num_other;
     int* range_flag;          // fp16 modes: pinned host word, OR-ed with kRangeActivation when an operand left the fp16 range
+    const int* weight_range;  // fp16 modes: the packed buffer's weight-range word (snerf_mlp_pack), forwarded to range_flag
 };
 
 // Arguments of the backward chain kernels (fp32: mlp_backward.hip, f16x3: mlp_backward_f16.hip)

@@ -185,8 +185,11 @@ struct RangeWatch {
         for (int i = 0; i < 8; ++i) m = __builtin_elementwise_maximum(m, __builtin_fabsf((float)converted[i]));
         probe(m);
     }
-    __device__ __forceinline__ void report(int* flag) const {
+    // `weight_range`: the consumed packed buffer's word (one thread of the grid forwards it)
+    __device__ __forceinline__ void report(int* flag, const int* weight_range) const {
         if (!(worst <= 3.0e38f) && flag) __hip_atomic_fetch_or(flag, snerf::kRangeActivation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (flag && weight_range && blockIdx.x == 0 && threadIdx.x == 0 && *weight_range != 0)
+            __hip_atomic_fetch_or(flag, snerf::kRangeWeight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 };
 

@@ -231,11 +231,13 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     if (num_rays == 0) return SNERF_OK;
     MlpArgs a;
     a.range_flag = nullptr;
+    a.weight_range = nullptr;
     if (precision != SNERF_PRECISION_FP32) {    // fp16 modes: report an earlier launch's range violation, then arm the watch
         const int range = snerf::report_range(train ? "mlp_forward_train" : "mlp_forward");
         if (range != SNERF_OK) return range;
         a.range_flag = snerf::range_flag();
         if (!a.range_flag) return SNERF_E_HIP;
+        a.weight_range = reinterpret_cast<const int*>(packed + plan.weight_range_word);
     }
     a.visibility = vis.visibility; a.view_dirs2 = vis.view_dirs2; a.visibility2 = vis.visibility2; a.num_other = vis.num_other;
     a.packed = packed; a.origins = origins; a.dirs = dirs; a.view_dirs = view_dirs; a.depths = depths;

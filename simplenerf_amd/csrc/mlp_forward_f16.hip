@@ -197,6 +197,14 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
             if constexpr (P == 1) convert_tile<true>(acc[u], xh[2 * u], xh[2 * u + 1]);
             else split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
         }
+        if constexpr (!VIEWDEP && STORE16) {
+            // a view-independent MLP's last activations are saved for the head weight gradients and multiplied by nothing in
+            // this pass: no later pre-activation would turn non-finite, so they are watched directly
+            if (last) {
+#pragma unroll
+                for (int i = 0; i < HK; ++i) watch.see(xh[i]);
+            }
+        }
         if (STORE16) { store_pieces<HK>(xh, tile16 + (a.act_h1 + l * a.width) * 32, lane); st.note_vmem(HK); }
     };
     if constexpr (DEPTH > 0) {
@@ -260,7 +268,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoidf((col[c] + __shfl_xor(col[c], 32, 64)) + bo[c]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    watch.report(a.range_flag);
+    watch.report(a.range_flag, a.weight_range);
     SNERF_STAMP_END(forward_f16);
     if (live && half == 0) {
         a.sigma[first] = sigma;

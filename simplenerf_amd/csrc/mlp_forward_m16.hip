@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         for (int c = 0; c < 3; ++c) tile_dot_relu16(acc[u], wv + c * VT * 32 + 32 * u, grp, col[c]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a wave never ends with LDS-DMA in flight)
-    watch.report(a.range_flag);
+    watch.report(a.range_flag, a.weight_range);
     SNERF_STAMP_END(forward_m16);
 
     // ---- outputs: the four lane groups hold partial sums over their rows ----------------------------------------------------

@@ -27,7 +27,7 @@ struct StageTable {
     const float* w[kStagesPerLaunch][3];
     snerf::MlpPlan::HalfStage stage[kStagesPerLaunch];
     int m16[kStagesPerLaunch];   // 1: fragment layout of the 16x16x32 MFMA (mlp_forward_m16.hip)
-    int* range_flag;             // pinned host word: kRangeWeight is OR-ed in when a weight does not fit fp16
+    int* weight_range;           // word of the packed buffer: kRangeWeight is OR-ed in when a weight does not fit fp16
 };
 constexpr int kCopiesPerLaunch = 16;
 struct CopyTable {
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
             if (out < sg.out_dim && row < sg.feat_hi) tv = w[(long long)out * sg.ld + sg.col_offset + row];
             const _Float16 thi = (_Float16)tv;
             out_store(dst16, u, unit_ks, ks_unit, lane, slot, thi, (_Float16)(tv - (float)thi));
-            if (!(fabsf(tv) <= 65504.0f)) __hip_atomic_fetch_or(table.range_flag, snerf::kRangeWeight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (!(fabsf(tv) <= 65504.0f)) __hip_atomic_fetch_or(table.weight_range, snerf::kRangeWeight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
         if (sg.kind == snerf::SEG_ACC) {
@@ -139,8 +139,9 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         out_store(dst16, u, unit_ks, ks_unit, lane, slot, hi, lo);
-        // (NaN included; reported by the next fp16-mode call only -- an fp32-mode model may hold such weights legitimately)
-        if (!(fabsf(v) <= 65504.0f)) __hip_atomic_fetch_or(table.range_flag, snerf::kRangeWeight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (NaN included.  Recorded in the packed buffer itself and reported only by an fp16-mode kernel that consumes THIS
+        // buffer: an fp32-mode model may hold such weights legitimately, and must not trip another model's fp16-mode call)
+        if (!(fabsf(v) <= 65504.0f)) __hip_atomic_fetch_or(table.weight_range, snerf::kRangeWeight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -195,8 +196,7 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
     }
     {
         StageTable table;
-        table.range_flag = snerf::range_flag();
-        if (!table.range_flag) return SNERF_E_HIP;
+        table.weight_range = reinterpret_cast<int*>(packed + plan.weight_range_word);     // zeroed by the fill above
         int n = 0;
         long long most = 0;
         auto flush = [&]() {

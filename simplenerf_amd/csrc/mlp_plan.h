@@ -50,6 +50,7 @@ struct MlpPlan {
     std::vector<HalfStage> m16_stages;
     long long m16_offset = 0;
     long long total_floats = 0;
+    long long weight_range_word = 0;      // float offset of the buffer's fp16 weight-range word (see build_plan)
 
     // ---- saved-activation / gradient tiles of one 32-sample wave block (backward only) -----------------------
     // Every tensor is stored [feature][32 samples] (feature-major inside the block), features in natural order.
@@ -265,7 +266,10 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
         }
         off = hoff;
     }
-    plan.total_floats = (off + 63) / 64 * 64;
+    // one reserved block behind the streams: word 0 is OR-ed with kRangeWeight by snerf_mlp_pack when a weight of THIS buffer
+    // does not fit fp16, and read by the fp16-mode kernels that consume the buffer (an fp32-mode model may hold such weights)
+    plan.weight_range_word = (off + 63) / 64 * 64;
+    plan.total_floats = plan.weight_range_word + 64;
     *p = plan;
     return SNERF_OK;
 }

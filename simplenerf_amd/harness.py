@@ -96,14 +96,15 @@ def gather_rays(local: Dict[str, Tensor], num_rays: int, rank: int, world_size: 
 
 @torch.no_grad()
 def render_frame(model, camera: dict, ndc: bool, device, keys: Iterable[str] = DEFAULT_KEYS, rank: int = 0,
-                 world_size: int = 1, ray_block: int = 65536) -> Optional[Dict[str, Tensor]]:
+                 world_size: int = 1, ray_block: int = 65536, collective: Optional[bool] = None) -> Optional[Dict[str, Tensor]]:
     """Full frame, (h*w, .) per key.  With world_size > 1 every rank renders its block and rank 0 receives the
-    frame through one gather (returns None on the other ranks)."""
+    frame through one gather (returns None on the other ranks).  ``collective=True`` issues that gather with a single rank
+    too (a one-rank process group: the RCCL call path of the multi-GPU run on a one-GPU box)."""
     h, w = camera['resolution']
     n = h * w
     first, count = shard_range(n, rank, world_size)
     local = render_rays_blockwise(model, camera, ndc, device, first, count, keys, ray_block)
-    if world_size == 1:
+    if not (world_size > 1 if collective is None else collective):
         return local
     return gather_rays(local, n, rank, world_size)
 
@@ -146,25 +147,26 @@ def retrieve_inference_outputs(configs: dict, resolution, network_outputs: Dict[
 
 @torch.no_grad()
 def predict_frame(model, configs: dict, camera: dict, device, rank: int = 0, world_size: int = 1,
-                  ray_block: int = 65536) -> Optional[dict]:
+                  ray_block: int = 65536, collective: Optional[bool] = None) -> Optional[dict]:
     """NerfTester.predict_frame (src/Tester01.py:57-66): full-frame batch -> model under no_grad -> the five display
     outputs.  Rays are generated on the device per block; with world_size > 1 each rank renders its block of the frame
     and rank 0 receives it through one gather (None on the other ranks)."""
     ndc = bool(configs['data_loader']['ndc'])
     suffix = '_fine' if 'fine_mlp' in configs['model'] else '_coarse'
     keys = [f'rgb{suffix}', f'depth{suffix}', f'depth_var{suffix}'] + ([f'depth_ndc{suffix}', f'depth_var_ndc{suffix}'] if ndc else [])
-    frame = render_frame(model, camera, ndc, device, keys, rank, world_size, ray_block)
+    frame = render_frame(model, camera, ndc, device, keys, rank, world_size, ray_block, collective)
     if frame is None:
         return None
     return retrieve_inference_outputs(configs, camera['resolution'], frame)
 
 
-def allreduce_gradients(parameters, world_size: int, group=None) -> None:
+def allreduce_gradients(parameters, world_size: int, group=None, force: bool = False) -> None:
     """Training with rays sharded over ranks: average every parameter gradient across ranks with ONE collective
     (all gradients flattened into a single buffer: 2 265 488 floats = 9.06 MB for the 4-MLP model).
     Equivalent to the reference's DataParallel, which gathers the per-device outputs and takes the loss mean over the
-    whole batch (src/Trainer01.py:93-96), when every rank holds the same number of rays."""
-    if world_size == 1:
+    whole batch (src/Trainer01.py:93-96), when every rank holds the same number of rays.  ``force``: issue the collective
+    with a single rank too (one-rank process group -- the RCCL call path on a one-GPU box)."""
+    if world_size == 1 and not force:
         return
     import torch.distributed as dist
     # EVERY trainable parameter takes part, zeros standing in for a missing gradient: a rank whose shard of a short last
@@ -187,7 +189,7 @@ def allreduce_gradients(parameters, world_size: int, group=None) -> None:
 
 
 def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch_size: Optional[int] = None,
-                   world_size: int = 1, group=None, single_pass: bool = False) -> Dict[str, Tensor]:
+                   world_size: int = 1, group=None, single_pass: bool = False, force_collective: bool = False) -> Dict[str, Tensor]:
     """One optimisation step over ``input_batch`` the way the reference's trainer does it (Trainer.train_one_iter,
     src/Trainer01.py:60-107): gradients cleared, the batch cut into consecutive sub-batches, ``model`` ->
     ``compute_losses`` -> ``TotalLoss.backward()`` per sub-batch (gradients accumulate: the step minimises the SUM of
@@ -233,7 +235,7 @@ def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch
                 value = value.detach() if isinstance(value, torch.Tensor) else torch.as_tensor(float(value))
                 totals[name] = totals[name] + value if name in totals else value
         objective.backward()
-        allreduce_gradients(model.parameters(), world_size, group)
+        allreduce_gradients(model.parameters(), world_size, group, force_collective)
         optimizer.step()
         return totals
     for start in range(0, n, sub):
@@ -252,7 +254,7 @@ def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch
             value = entry['loss_value'] if isinstance(entry, dict) else entry
             value = value.detach() if isinstance(value, torch.Tensor) else torch.as_tensor(float(value))
             totals[name] = totals[name] + value if name in totals else value
-    allreduce_gradients(model.parameters(), world_size, group)
+    allreduce_gradients(model.parameters(), world_size, group, force_collective)
     optimizer.step()
     return totals
 
@@ -402,6 +404,8 @@ class GraphedIteration:
                  slots: int = 8, warmup: int = 1):
         if getattr(batcher, 'world_size', 1) != 1:
             raise NotImplementedError('GraphedIteration is a single-process path (use GraphedTrainStep + allreduce_gradients)')
+        if len(optimizer.param_groups) != 1:
+            raise NotImplementedError('GraphedIteration replays ONE (step size, bias correction) record: a single parameter group')
         self.model, self.losses, self.opt, self.batcher, self.decayer = model, loss_computer, optimizer, batcher, lr_decayer
         self.device = batcher.device
         self.ring = ops.IterationRing(self.device, slots)

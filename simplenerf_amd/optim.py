@@ -50,6 +50,7 @@ class Adam(torch.optim.Optimizer):
         """(-(lr / (1 - beta1^step)), sqrt(1 - beta2^step)) as float32, evaluated in double like snerf_adam_step does: what a
         captured ``step_at`` reads from the device-resident iteration record."""
         import numpy
+        self.require_single_schedule()
         beta1, beta2 = self.param_groups[0]['betas']
         bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
         return float(numpy.float32(-(lr / bc1))), float(numpy.float32(bc2 ** 0.5))
@@ -86,10 +87,26 @@ class Adam(torch.optim.Optimizer):
         return int(new or 0)
 
     def next_count(self) -> int:
+        """The step count the next graphed update runs at: the count of the parameters ``count_step`` advances (those holding a
+        gradient) + 1.  They must agree -- ONE device-resident record serves every parameter of a replay."""
+        found = None
         for group in self.param_groups:
             for p in group['params']:
-                return self._count(p) + 1
-        return 1
+                if p.grad is None:
+                    continue                      # frozen / unused: count_step leaves it alone, so must this
+                count = self._count(p)
+                if found is None:
+                    found = count
+                elif count != found:
+                    raise RuntimeError(f'graphed optimiser steps need every parameter at the same step count ({found} vs {count})')
+        return (found or 0) + 1
+
+    def require_single_schedule(self) -> None:
+        """A graphed update reads ONE (step size, bias correction) record: every group must share betas and learning rate."""
+        first = self.param_groups[0]
+        for group in self.param_groups[1:]:
+            if tuple(group['betas']) != tuple(first['betas']) or group['lr'] != first['lr']:
+                raise RuntimeError('graphed optimiser steps need the same betas and learning rate in every parameter group')
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -148,9 +148,8 @@ def _run_bench(ranks, *flags):
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-    env.update(SNERF_BENCH_STANDIN='1', SNERF_DIST_BACKEND='gloo')
-    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', str(ranks), *flags],
-                       capture_output=True, text=True, timeout=300, env=env)
+    r = subprocess.run([sys.executable, os.path.join(repo, 'tests', 'bench_rehearsal.py'), '--standin', '--backend', 'gloo', '--',
+                        '--gpus', str(ranks), *flags], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout
@@ -162,13 +161,19 @@ def test_bench_self_launches_its_ranks(ranks):
     """``python bench.py --gpus N`` with no launcher around it (how the driver calls it): bench.py starts its N rank
     processes itself, they rendezvous over torch.distributed (gloo here, RCCL on a GPU node), every rank contributes its
     1024-ray block to the gather, and the parent relays ONE JSON line whose ``collective`` object reports the ranks.  The
-    renderer is replaced by the CPU stand-in (SNERF_BENCH_STANDIN=1) -- what is exercised is the launcher and the N > 1
+    renderer is replaced by the CPU stand-in (tests/bench_rehearsal.py calls bench.main with it) -- what is exercised is the launcher and the N > 1
     protocol (settle, warm-up, fenced timed region with per-step stamps, max over ranks), which needs no GPU.  The default
     N > 1 line also carries BASELINE config 4's frame, strong-scaled over the same ranks (``also_measured_frame``)."""
     line = _run_bench(ranks, '--steps', '3', '--warmup', '1')
     assert line['n_gpus'] == ranks and line['steps'] == 3 and line['warmup'] == 1 and line['scaling'] == 'weak'
     assert line['collective']['backend'] == 'gloo' and line['collective']['ranks'] == ranks
     assert line['collective']['bytes'] == 1024 * 16
+    # attribution of a sub-linear point: every rank's own step time, kernel time, gather time and elapsed seconds
+    per_rank = line['collective']['per_rank']
+    assert [r['rank'] for r in per_rank] == list(range(ranks))
+    assert all(r['step_ms_p50'] > 0 and r['gather_ms_p50'] >= 0 and r['elapsed_s'] > 0 for r in per_rank)
+    assert line['collective']['gather_ms']['max'] >= line['collective']['gather_ms']['p50'] >= 0
+    assert line['ms_per_step'] * 1e-3 * 3 == pytest.approx(max(r['elapsed_s'] for r in per_rank), rel=1e-9)
     assert line['data'] == 'stand-in' and line['value'] > 0
     timing = line['timing']
     assert set(timing['step_ms']) == {'p50', 'p90', 'max', 'first', 'argmax'} and len(timing['step_trace_ms']) == 3
@@ -195,21 +200,51 @@ def test_bench_frame_mode_strong_scales_one_frame(ranks):
                                       'pattern': 'one gather of the five per-ray outputs to rank 0 per frame'}
 
 
+@pytest.mark.parametrize('mode', [(), ('--frame', 're10k')])
+def test_bench_force_collective_runs_the_multi_rank_protocol_with_one_rank(mode):
+    """``--force-collective`` at N = 1: a one-rank process group, barriers in the fences, the gather in every step and the
+    max-over-ranks reduction -- the code the N > 1 line runs (under RCCL on a GPU box: tests/test_gpu_dist.py)."""
+    line = _run_bench(1, '--force-collective', '--steps', '2', '--warmup', '1', *mode)
+    assert line['n_gpus'] == 1 and line['collective']['backend'] == 'gloo' and line['collective']['ranks'] == 1
+    if not mode:
+        assert len(line['collective']['per_rank']) == 1 and 'gather' in line['config']['parallelism']
+        assert line['also_measured_frame']['collective']['ranks'] == 1
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """bench.py proper (no rehearsal switches): ``--gpus 2`` on a node with fewer than two GPUs is an error BEFORE any rank is
+    started, and a launcher-provided rank whose LOCAL_RANK has no device of its own is an error before the process group is
+    created -- no wrap-around of ranks onto one device (until round 3: ``local_rank % device_count``)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('a multi-GPU node')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and 'GPU(s)' in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    env.update(RANK='1', LOCAL_RANK='1', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29999')
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and ('GPU(s)' in r.stderr or 'needs an MI355X' in r.stderr)
+
+
 def test_bench_self_launch_reports_a_failing_rank():
     """A rank that dies takes the launch down with a non-zero status instead of leaving the others in the rendezvous."""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-    env.update(SNERF_BENCH_STANDIN='1', SNERF_DIST_BACKEND='no-such-backend')
-    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
-                       capture_output=True, text=True, timeout=300, env=env)
+    r = subprocess.run([sys.executable, os.path.join(repo, 'tests', 'bench_rehearsal.py'), '--standin', '--backend', 'no-such-backend',
+                        '--', '--gpus', '2', '--steps', '1', '--warmup', '0'], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
 
 
 def test_bench_under_the_drivers_launcher():
-    """The driver's N > 1 command, verbatim: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
-    127.0.0.1 --master-port P bench.py --gpus 2 --steps K --warmup W`` -- the ranks come from the launcher (RANK / LOCAL_RANK /
+    """The driver's N > 1 command (``python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 --steps K --warmup W``) with the rehearsal wrapper in bench.py's place, which hands
+    the same argument list to ``bench.main`` -- the ranks come from the launcher (RANK / LOCAL_RANK /
     WORLD_SIZE in the environment) instead of bench.py's own, and rank 0 alone prints the ONE JSON line."""
     import json
     import socket
@@ -220,10 +255,9 @@ def test_bench_under_the_drivers_launcher():
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-    env.update(SNERF_BENCH_STANDIN='1', SNERF_DIST_BACKEND='gloo')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-                        '--master-port', str(port), os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
-                       capture_output=True, text=True, timeout=300, env=env)
+                        '--master-port', str(port), os.path.join(repo, 'tests', 'bench_rehearsal.py'), '--standin', '--backend', 'gloo',
+                        '--', '--gpus', '2', '--steps', '3', '--warmup', '1'], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout

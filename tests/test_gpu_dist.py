@@ -94,9 +94,10 @@ def _bench(*flags):
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-    env['SNERF_DIST_BACKEND'] = 'gloo'       # two ranks share the box's one GPU: RCCL refuses that, gloo carries the collectives
-    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', *flags], capture_output=True, text=True,
-                       timeout=900, env=env)
+    # two ranks share the box's one GPU: RCCL refuses that, gloo carries the collectives (tests/bench_rehearsal.py hands
+    # bench.main the backend and the permission to share a device; bench.py itself has neither switch)
+    r = subprocess.run([sys.executable, os.path.join(repo, 'tests', 'bench_rehearsal.py'), '--backend', 'gloo', '--share-devices', '--',
+                        '--gpus', '2', *flags], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -147,3 +148,115 @@ def test_bench_training_line_counts_full_size_iterations_only():
     # not this test's business)
     typical = sorted(trace[1:])[len(trace[1:]) // 2]
     assert len(trace) == 7 and min(trace[1:]) > 0.85 * typical, trace
+
+
+# ------------------------------------------------------------------------------------------------------------ RCCL
+_RCCL_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from simplenerf_amd import harness
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)      # as bench.py does for every rank
+done = []
+dist.barrier(); done.append('barrier')
+n = 1000
+idx = torch.arange(n, dtype=torch.float32, device=dev)
+local = {'rgb_fine': torch.stack([idx, 2 * idx, 3 * idx], 1), 'depth_fine': idx + 0.5}
+full = harness.gather_rays(local, n, 0, 1); done.append('gather')
+assert full['rgb_fine'].is_cuda and torch.equal(full['rgb_fine'], local['rgb_fine']) and torch.equal(full['depth_fine'], local['depth_fine'])
+net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3)).to(dev)
+(net(torch.ones(4, 5, device=dev)) ** 2).mean().backward()
+before = [p.grad.clone() for p in net.parameters()]
+harness.allreduce_gradients(net.parameters(), 1, force=True); done.append('all_reduce(sum)')
+assert all(torch.equal(a, p.grad) for a, p in zip(before, net.parameters()))
+t = torch.tensor([3.25], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX); done.append('all_reduce(max)')
+assert float(t.item()) == 3.25
+mine = torch.tensor([1.0, 2.0], dtype=torch.float64, device=dev)
+table = [torch.empty_like(mine)]
+dist.all_gather(table, mine); done.append('all_gather')
+assert torch.equal(table[0], mine)
+torch.cuda.synchronize()
+print(json.dumps({'backend': dist.get_backend(), 'calls': done}))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return env
+
+
+def test_rccl_executes_every_collective_of_the_multi_gpu_path():
+    """Backend ``nccl`` (= RCCL) with ONE rank on the box's GPU: the process group bound to the device as in bench.py, then
+    every torch.distributed call the N > 1 paths make -- ``barrier``, ``gather`` (harness.gather_rays), ``all_reduce`` SUM of the
+    flattened gradients (harness.allreduce_gradients), ``all_reduce`` MAX (the max-over-ranks timing) and ``all_gather`` (the
+    per-rank table) -- on device tensors.  A fresh process, so the group's teardown is exercised too."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = _clean_env()
+    env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, '-c', _RCCL_WORKER, repo], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    record = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert record['backend'] == 'nccl'
+    assert record['calls'] == ['barrier', 'gather', 'all_reduce(sum)', 'all_reduce(max)', 'all_gather']
+
+
+def _plain_bench(*flags, timeout=900):
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), *flags], capture_output=True, text=True, timeout=timeout,
+                       env=_clean_env())
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_force_collective_runs_the_n_gpu_line_on_rccl():
+    """``python bench.py --gpus 1 --force-collective``: the N > 1 headline protocol on RCCL with one rank -- barriers in both
+    fences, one gather of the real renderer's device outputs per step (timed by its own events), the per-rank all-gather, the
+    max-over-ranks all-reduce, and BASELINE config 4's frame through ``harness.predict_frame``'s gather."""
+    line = _plain_bench('--gpus', '1', '--force-collective', '--steps', '4', '--warmup', '2', '--no-cpu-baseline')
+    assert line['n_gpus'] == 1 and line['data'] == 'synthetic' and line['dtype'] == 'f32'
+    c = line['collective']
+    assert c['backend'] == 'nccl' and c['ranks'] == 1 and c['bytes'] == 1024 * 16
+    assert len(c['per_rank']) == 1 and c['per_rank'][0]['step_ms_p50'] > 0 and c['per_rank'][0]['mlp_kernel_ms_per_step'] > 0
+    assert 0 < c['gather_ms']['p50'] < 5.0, c['gather_ms']
+    assert line['roofline']['launches'] == 8 and line['value'] > 1e4
+    frames = line['also_measured_frame']
+    assert frames['collective']['backend'] == 'nccl' and all(e['rays'] == 762048 and e['value'] > 1e4 for e in frames['entries'])
+
+
+def test_bench_training_force_collective_runs_the_gradient_all_reduce_on_rccl():
+    """``python bench.py --train --precision f16 --force-collective``: config 5's iteration with the ONE all-reduce of the
+    flattened 9.06 MB gradient buffer issued on RCCL (one rank) between the backward and the optimiser step."""
+    line = _plain_bench('--train', '--precision', 'f16', '--force-collective', '--steps', '3', '--warmup', '1')
+    c = line['collective']
+    assert c['backend'] == 'nccl' and c['ranks'] == 1 and c['bytes'] == 2265488 * 4 and len(c['per_rank']) == 1
+    assert line['timing']['short_batches'] == 0 and line['value'] > 1e4
+
+
+def test_bench_refuses_a_rank_without_a_gpu_of_its_own():
+    """One rank per GPU is enforced: the launcher's LOCAL_RANK=1 on a one-GPU box is an error before the process group exists
+    (until round 3 it wrapped around onto device 0 and RCCL failed late)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() != 1:
+        pytest.skip('needs a one-GPU box')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = _clean_env()
+    env.update(RANK='1', LOCAL_RANK='1', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and 'one rank per GPU' in r.stderr, r.stderr[-2000:]

@@ -304,6 +304,55 @@ def test_leaving_the_fp16_range_is_detected_not_silent(precision, mode):
     assert ops.range_status() == 0 and torch.isfinite(again['rgb_fine']).all()
 
 
+def test_an_fp32_mode_model_with_large_weights_does_not_trip_another_models_fp16_call():
+    """the weight-range bit used to be set by ``snerf_mlp_pack`` in the per-device flag for ANY model, so an fp32-mode
+    model holding |w| > 65504 (legitimate there) made the next fp16-mode call of a DIFFERENT model fail with a spurious
+    Fp16RangeError.  The bit now lives in the packed buffer and is reported only by an fp16-mode kernel that consumes it."""
+    cam = synth.camera('fern', 0)
+    batch = harness.frame_batch(cam, True, DEV, 200000, 64)
+
+    def make(precision):
+        cfg = synth.with_overrides(synth.make_configs('config2'), hip_precision=precision)
+        model = get_model(cfg, None)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
+        return model.to(DEV).eval()
+
+    big, small = make('fp32'), make('f16')
+    ops.range_status(clear=True)
+    with torch.no_grad():
+        big.coarse_model.pts_linears[3].weight[5, 9] = -7.0e4          # fine in fp32
+        a = big(batch)
+        torch.cuda.synchronize()
+        assert ops.range_status() == 0 and torch.isfinite(a['rgb_fine']).all()
+        b = small(batch)                                                # another model, fp16 mode: must not be refused
+        torch.cuda.synchronize()
+        assert ops.range_status() == 0 and torch.isfinite(b['rgb_fine']).all()
+
+
+def test_overflow_of_a_view_independent_mlps_last_activations_is_detected():
+    """in the 16-bit training forward the last trunk activations of a view-independent MLP (the views-augmentation
+    model: no views layer) are converted to fp16 and saved for the head weight gradients only -- no later product would turn
+    non-finite -- so they are watched directly."""
+    cfg = synth.training_configs('f16', num_rays=96, num_sparse=32)
+    model = get_model(cfg, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 9, 200.0, 8.0).items()})
+    model = model.to(DEV).train()
+    assert not cfg['model']['views_augmentation']['coarse_mlp']['use_view_dirs']
+    batch = harness.frame_batch(synth.camera('fern', 0), True, DEV, 200000, 64)
+    ops.range_status(clear=True)
+    with torch.no_grad():
+        model(batch)
+        torch.cuda.synchronize()
+        assert ops.range_status() == 0
+        last = cfg['model']['views_augmentation']['coarse_mlp']['points_net_depth'] - 1
+        model.views_aug_coarse_model.pts_linears[last].bias[3] = 1.0e5
+        model(batch)
+        torch.cuda.synchronize()
+    assert ops.range_status(clear=True) & ops.RANGE_ACTIVATION
+
+
 def test_graphed_training_step_reports_a_range_violation():
     """A graph replay bypasses the entry points that report the flag: GraphedTrainStep asks after every replay."""
     cfg = synth.training_configs('f16', num_rays=192, num_sparse=64)

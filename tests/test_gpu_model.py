@@ -45,7 +45,9 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 RGB_TOL, DEPTH_TOL = 1e-4, 1e-3
 MAX_OUTLIER_RAYS = 0.02          # fine colour / acc / NDC depth over tolerance; observed <= 0.8 % ('plain', 'consistent')
-MAX_OUTLIER_RAYS_DENSE = 0.05    # ... for two independent OPAQUE random fields ('dense'); observed 4.5 % (config 2, 4096 rays)
+MAX_OUTLIER_RAYS_DENSE = 0.05    # ... for two independent OPAQUE random fields ('dense').  Pinned to the reference's own noise
+#                                  (tests/golden/selfnoise.json, 4096 rays of config 2): the reference with relabelled hidden
+#                                  units puts 2.8 % of these rays over the bounds, its fp32 run against its fp64 run 4.2 %
 MAX_OUTLIER_RAYS_WORLD = 0.05    # world-space depth / depth_var of NDC scenes (weights x 1/(1-z) <= 1e3); observed <= 3.1 %
 MAX_UNMOVED_OVER = 0.001         # ... of which on rays whose fine depths agree with the reference's to 1e-5; observed <= 1/4096
 
@@ -58,8 +60,10 @@ def build(configs, golden, precision='fp32'):
     return model.to(DEV)
 
 
-def per_ray_violation(key, got, ref, acc_ref):
-    """bool (N,): rays on which `key` exceeds its bound.  None -> key not gated."""
+def per_ray_violation(key, got, ref, acc_ref, ndc=True):
+    """bool (N,): rays on which `key` exceeds its bound.  None -> key not gated.  ``ndc``: the scene is rendered in NDC, i.e.
+    its world-space depths are the NDC ones pushed through 1/(1 - z) and reach ~1e3 -- those (and only those) are bounded
+    relative to their magnitude; world depths of a non-NDC scene are gated at north_star's ABSOLUTE 1e-3 (round 4)."""
     base = key.replace('points_augmentation_', '').replace('views_augmentation_', '')
     a = got.detach().cpu().numpy().astype(numpy.float64)
     b = ref.astype(numpy.float64)
@@ -73,10 +77,14 @@ def per_ray_violation(key, got, ref, acc_ref):
     if base.startswith(('depth_var_ndc', 'depth_ndc')):
         return (d.max(1) > DEPTH_TOL) & (acc_ref > 1e-2)
     if base.startswith('depth_var'):
+        if not ndc:
+            return (d.max(1) > DEPTH_TOL) & (acc_ref > 1e-2)
         # un-normalised second moment sum w (z - depth)^2 of world depths up to ~1e3: a difference of large numbers
         # that no reference loss reads; bounded relatively, 10x looser
         return ((d / numpy.maximum(bm, 1.0)).max(1) > 10 * DEPTH_TOL) & (acc_ref > 1e-2)
     if base.startswith('depth_'):
+        if not ndc:
+            return (d.max(1) > DEPTH_TOL) & (acc_ref > 1e-2)
         return ((d / numpy.maximum(bm, 1.0)).max(1) > DEPTH_TOL) & (acc_ref > 1e-2)
     return None  # z_vals_*: checked separately
 
@@ -87,6 +95,7 @@ def check_outputs(out, ref, strict_fine, tag='', precision='fp32', dense=False):
         assert tuple(out[k].shape) == tuple(v.shape), k
         assert out[k].dtype == torch.float32 and out[k].device.type == 'cuda', k
         assert torch.isfinite(out[k]).all(), k
+    ndc = 'depth_ndc_coarse' in ref
     moved_rays = numpy.zeros(next(iter(ref.values())).shape[0], dtype=bool)
     if 'z_vals_fine' in ref:
         zr = ref['z_vals_fine']
@@ -96,7 +105,7 @@ def check_outputs(out, ref, strict_fine, tag='', precision='fp32', dense=False):
         level = 'fine' if k.endswith('_fine') else 'coarse'
         acc_key = next(c for c in (f'{p}acc_{level}' for p in ('points_augmentation_', 'views_augmentation_', ''))
                        if k.startswith(c.split('acc_')[0]) and c in ref)
-        bad = per_ray_violation(k, out[k], v, ref[acc_key].astype(numpy.float64))
+        bad = per_ray_violation(k, out[k], v, ref[acc_key].astype(numpy.float64), ndc)
         if bad is None:
             continue
         per_sample = v.ndim >= 2 and v.shape[1] > 3
@@ -214,7 +223,7 @@ def test_fine_pass_on_reference_samples(kind, profile):
     comp = ops.composite(sigma, rgb, z, md, ndc, False, b['rays_o'], b['rays_d'])
     acc = g['out_acc_fine'].astype(numpy.float64)
     for k, v in comp.items():
-        bad = per_ray_violation(f'{k}_fine', v, g[f'out_{k}_fine'], acc)
+        bad = per_ray_violation(f'{k}_fine', v, g[f'out_{k}_fine'], acc, ndc)
         assert bad is not None and not bad.any(), (k, util.linf(v, g[f'out_{k}_fine']))
     assert not per_ray_violation('raw_sigma_fine', sigma, g['out_raw_sigma_fine'], acc).any()
     assert not per_ray_violation('raw_rgb_fine', rgb, g['out_raw_rgb_fine'], acc).any()
@@ -435,50 +444,78 @@ def test_config4_re10k_full_frame_properties_and_eight_way_shards(resolution):
     assert numpy.array_equal(frame['image'].reshape(-1, 3), ref_img) and numpy.array_equal(frame['depth'].reshape(-1), ref_depth)
 
 
-_ORACLE_SLICES = {}
+K_SELF = 2.0          # allowance vs the committed fp32 reference outputs = K_SELF x the reference's own evaluation-order noise
+K_EXACT = 1.5         # allowance vs the reference in double precision = K_EXACT x the reference's own fp32 error against it
+SLACK_RAYS = 4        # + 4 rays of 4096 (0.1 %) on either gate: fractions of a few rays are counting noise
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
 @pytest.mark.parametrize('kind,profile', [('config2', 'dense'), ('config2', 'consistent'), ('config4', 'dense'), ('config4', 'consistent')])
-def test_frame_slice_against_the_oracle_on_this_host(kind, profile, precision):
+def test_frame_slice_against_committed_reference_outputs(kind, profile, precision):
     """A 4096-ray slice out of the middle of the BASELINE config 2 (fern 1008x756) and config 4 (RE10K camera at 1008x756)
-    frames, rays generated on the device, against the oracle evaluated on THIS box's CPU (no fixture: 40x more rays than the
-    goldens hold).  Gates: coarse outputs on every ray; fine colour / acc / NDC depth on all but <= 5 % of rays for the two
-    independent opaque fields ('dense'; observed 4.5 % on the fern rays, 0.1 % on the RE10K ones) and <= 2 % with consistent
-    geometry (observed 0.1 %), and in every case on (all but 0.1 % of) the rays whose resampled depths did not move -- the
-    outliers are sample_pdf's threshold, not the kernels.  The observed fractions are printed in the summary for
-    both parity precisions."""
+    frames, rays generated on the device, against the REFERENCE's outputs for exactly these rays
+    (tests/golden/slice_<config>_<profile>.npz, written by tools/make_golden_selfnoise.py) -- no CPU arithmetic of the GPU box
+    is involved (until round 3 the comparison was against the oracle evaluated on that box).  The allowances are pinned to the
+    reference's own irreproducibility, measured by the same tool (tests/golden/selfnoise.json): its fp32 CPU path is
+    bit-identical across thread counts, GEMM back ends, vector widths, chunk sizes and row order, so the figure that matters
+    is what ANOTHER SUMMATION ORDER of the same function does to it -- the reference with its hidden units relabelled --
+    and how far its fp32 run is from its own double-precision run.  Gates:
+      * coarse outputs: every ray at the full tolerance; coarse depths bit-equal;
+      * fine colour / opacity / NDC depth vs the committed fp32 outputs: rays over tolerance <= K_SELF x max(relabelled
+        reference vs reference, reference fp32 vs reference fp64) + 0.1 %, and (all but 0.1 % of) them on rays whose resampled
+        depths moved;
+      * the same outputs vs the reference in DOUBLE precision: rays over tolerance <= K_EXACT x the reference's own fp32 run
+        against it + 0.1 % -- the kernels are as close to the exact value as the reference is."""
+    import json
+    import os
     from simplenerf_amd import harness
     g = util.load(f'e2e_{kind}_{profile}.npz')
+    fixture = util.load(f'slice_{kind}_{profile}.npz')
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'selfnoise.json')) as f:
+        noise = json.load(f)['cases'][f'{kind}/{profile}']
     cfg = synth.make_configs(kind)
     cam = synth.camera('fern', 0) if kind == 'config2' else synth.camera('re10k', 0, resolution=(756, 1008))
-    h, w = cam['resolution']
-    first, count = (h // 2) * w + 37, 4096
+    first, count = int(fixture['first_ray']), int(fixture['count'])
     model = build(cfg, g, precision).eval()
     batch = harness.frame_batch(cam, True, DEV, first, count)
     with torch.no_grad():
         out = model(batch, retraw=True)
-    if (kind, profile) not in _ORACLE_SLICES:
-        params = util.golden_params(cfg, g)
-        with torch.no_grad():
-            _ORACLE_SLICES[(kind, profile)] = oracle.render(params, cfg, {k: v.cpu() for k, v in batch.items()}, training=False, retraw=True)
-    ref = {k: v.numpy() for k, v in _ORACLE_SLICES[(kind, profile)].items()}
+    ref = {k[4:]: v for k, v in fixture.items() if k.startswith('out_')}
+    exact = {k[4:]: v for k, v in fixture.items() if k.startswith('f64_')}
     assert float(ref['acc_fine'].mean()) > 0.05, 'the slice must not be empty space'
     acc = {lvl: ref[f'acc_{lvl}'].astype(numpy.float64) for lvl in ('coarse', 'fine')}
-    for k in ('rgb_coarse', 'acc_coarse', 'depth_ndc_coarse', 'alpha_coarse', 'weights_coarse'):
+    assert util.linf(out['z_vals_coarse'], ref['z_vals_coarse']) == 0.0       # same rays, same coarse depths, to the bit
+    for k in ('rgb_coarse', 'acc_coarse', 'depth_ndc_coarse', 'weights_coarse'):
         bad = per_ray_violation(k, out[k], ref[k], acc['coarse'])
         assert not bad.any(), (k, int(bad.sum()), util.linf(out[k], ref[k]))
     zr = ref['z_vals_fine']
-    moved_rays = (numpy.abs(out['z_vals_fine'].cpu().numpy() - zr) > 1e-5).any(1)
-    over = numpy.zeros(count, dtype=bool)
-    for k in ('rgb_fine', 'acc_fine', 'depth_ndc_fine'):
-        over |= per_ray_violation(k, out[k], ref[k], acc['fine'])
-    bound = MAX_OUTLIER_RAYS_DENSE if profile == 'dense' else MAX_OUTLIER_RAYS
-    util.observe(f'slice/{kind}/{profile}/{precision}', f'rays_over_tol / rays = {int(over.sum())}/{count} = {over.mean():.5f} '
-                 f'[{bound}], of them on rays whose fine depths did not move: {int((over & ~moved_rays).sum())} '
-                 f'[{"0" if profile == "consistent" else int(MAX_UNMOVED_OVER * count)}]; rays with a moved fine depth {int(moved_rays.sum())}')
-    assert over.mean() <= bound, float(over.mean())
-    assert (over & ~moved_rays).sum() <= (0 if profile == 'consistent' else MAX_UNMOVED_OVER * count), int((over & ~moved_rays).sum())
+    moved = numpy.abs(out['z_vals_fine'].cpu().numpy() - zr) > 1e-5
+    moved_rays = moved.any(1)
+
+    def over_tolerance(target):
+        flags = numpy.zeros(count, dtype=bool)
+        for k in ('rgb_fine', 'acc_fine', 'depth_ndc_fine'):
+            flags |= per_ray_violation(k, out[k], target[k], target['acc_fine'].astype(numpy.float64))
+        return flags
+
+    over, over_exact = over_tolerance(ref), over_tolerance(exact)
+    self_noise = max(noise['t8_unitperm']['rays_over_1e-4_rgb_acc_or_1e-3_ndc_depth'],
+                     noise['canonical_vs_f64']['rays_over_1e-4_rgb_acc_or_1e-3_ndc_depth'])
+    bound = K_SELF * self_noise + SLACK_RAYS / count
+    bound_exact = K_EXACT * noise['canonical_vs_f64']['rays_over_1e-4_rgb_acc_or_1e-3_ndc_depth'] + SLACK_RAYS / count
+    unmoved_allowed = 0 if profile == 'consistent' else int(MAX_UNMOVED_OVER * count)
+    util.observe(f'slice/{kind}/{profile}/{precision}',
+                 f'vs committed reference fp32: rays over tol {int(over.sum())}/{count} = {over.mean():.5f} [{bound:.5f} = {K_SELF} x '
+                 f'{self_noise:.5f} + {SLACK_RAYS} rays], of them with unmoved fine depths {int((over & ~moved_rays).sum())} '
+                 f'[{unmoved_allowed}]; vs reference fp64: {over_exact.mean():.5f} [{bound_exact:.5f}; the reference\'s own fp32 run: '
+                 f'{noise["canonical_vs_f64"]["rays_over_1e-4_rgb_acc_or_1e-3_ndc_depth"]:.5f}]; fine samples moved {moved.mean():.5f} '
+                 f'(relabelled reference: {noise["t8_unitperm"]["samples_moved"]:.5f}), rays with a moved depth {moved_rays.mean():.4f} '
+                 f'({noise["t8_unitperm"]["rays_with_a_moved_depth"]:.4f})')
+    assert over.mean() <= bound, (float(over.mean()), bound)
+    assert (over & ~moved_rays).sum() <= unmoved_allowed, int((over & ~moved_rays).sum())
+    assert over_exact.mean() <= bound_exact, (float(over_exact.mean()), bound_exact)
+    # the resampling itself moves no more samples than relabelling the reference's hidden units does (x K_SELF)
+    assert moved.mean() <= K_SELF * noise['t8_unitperm']['samples_moved'] + 1e-4, float(moved.mean())
 
 
 def oracle_display(rgb, depth):

@@ -346,3 +346,41 @@ def test_torch_library_binding_loads_and_rejects_cpu_tensors():
         snerf.render(cfg, descs, packed, rays, [None] * 9, [], [0] * 6, False, False)
     with pytest.raises(RuntimeError, match='cfg holds'):
         snerf.render(cfg[:3], descs, packed, rays, [None] * 9, [], [0] * 6, False, False)
+
+
+def test_graphed_step_count_follows_the_parameters_that_hold_gradients():
+    """ADVICE r3: ``Adam.next_count`` used to read the count of the FIRST parameter whether or not it takes part in the steps;
+    with a frozen / unused first parameter every graph replay was then fed step 1's bias-correction factors."""
+    import torch
+    from simplenerf_amd import optim
+    frozen, used = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(3))
+    opt = optim.Adam([frozen, used], lr=1e-3)
+    used.grad = torch.ones(3)
+    assert opt.next_count() == 1
+    for expected in (1, 2, 3):
+        assert opt.next_count() == expected
+        assert opt.count_step() == expected          # what a graph replay does after the captured step_at
+    assert opt.next_count() == 4 and opt._count(frozen) == 0
+    # one record serves every parameter of a replay: differing counts, betas or learning rates are refused
+    other = torch.nn.Parameter(torch.zeros(2))
+    other.grad = torch.ones(2)
+    opt.add_param_group({'params': [other]})
+    with pytest.raises(RuntimeError, match='same step count'):
+        opt.next_count()
+    opt.param_groups[1]['lr'] = 5e-4
+    with pytest.raises(RuntimeError, match='same betas and learning rate'):
+        opt.graph_factors(4, 1e-3)
+
+
+def test_torch_sum_and_cumsum_orders_that_the_resampling_kernel_reproduces():
+    """K5 (csrc/resample_device.h) adds sample_pdf's normaliser in torch.sum's order and runs its CDF as torch.cumsum does; both
+    orders are restated in numpy by tools/check_torch_sum_order.py -- if a torch build summed differently, this fails here (and
+    the bit-exact GPU resampling test would fail there)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'check_torch_sum_order.py')
+    spec = importlib.util.spec_from_file_location('check_torch_sum_order', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for n in (5, 62, 126, 190, 700):
+        assert mod.mismatches(n, rows=40) == (0, 0), n
