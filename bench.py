@@ -148,6 +148,34 @@ def launch_ranks(num_ranks: int, script=None) -> int:
     return 0 if not failed else next(c for c in codes if c != 0)
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """stdout carries exactly ONE line, the result: libraries write there too (RCCL prints a five-line version banner on
+    stdout when the first communicator is created), so the rank keeps the real stdout for ``emit`` and points descriptor 1 --
+    whatever C or Python code prints from here on -- at stderr."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (json.dumps(line) + '\n').encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
+
+
+def progress(text):
+    """one line on stderr per phase (stdout carries the ONE JSON line): a long default run shows where it is"""
+    print(f'[bench {time.strftime("%H:%M:%S")}] {text}', file=sys.stderr, flush=True)
+
+
 def _pkg():
     from simplenerf_amd import harness, ops, synth
     from simplenerf_amd.models.ModelFactory import get_model
@@ -171,42 +199,67 @@ def host_cores():
         return max(1, os.cpu_count() or 1)
 
 
-def cpu_baseline(configs, camera, first_ray, budget_seconds=9.0, max_runs=9):
-    """Oracle on the host CPU, same rays and weights as the GPU step.  BASELINE.md section 3's protocol --
-    ``torch.set_num_threads(os.cpu_count())``, one warm-up, best of the following passes -- plus, beside it, the same at 16
-    threads (the GPU box's per-GPU CPU share: with more threads than cores the process may use, the first leg oversubscribes).
-    Each leg is bounded: 1 warm-up + up to ``max_runs`` passes over the 1024 rays or ``budget_seconds`` of CPU work, whichever
-    comes first.  `value` is the FASTER leg (the baseline at its best), `cores` the threads of that leg."""
+CPU_LEG_TIMEOUT_S = 45.0
+
+
+def cpu_leg(kind, first_ray, threads, budget_seconds=9.0, max_runs=9):
+    """One leg of ``cpu_baseline`` (runs in a child process: ``bench.py --cpu-leg THREADS``): the oracle on the host CPU with
+    ``threads`` torch threads, same rays and weights as the GPU step; 1 warm-up + up to ``max_runs`` passes over the 1024 rays
+    or ``budget_seconds`` of CPU work, whichever comes first."""
     from oracle import nerf_oracle, raygen_oracle
     _, _, synth, get_model = _pkg()
+    configs = synth.make_configs(kind)
+    camera = synth.camera('fern', 0)
     shapes = {k: tuple(v.shape) for k, v in get_model(configs, None).state_dict().items()}
     params = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, sigma_gain=200.0, sigma_shift=8.0).items()}
     full = raygen_oracle.full_frame_batch(camera['resolution'], camera['intrinsic'], camera['pose'], camera['near'],
                                           camera['far'], True, camera['near_ndc'], camera['far_ndc'])
     batch = {k: torch.from_numpy(numpy.ascontiguousarray(v[first_ray:first_ray + RAYS_PER_GPU])) for k, v in full.items()}
+    torch.set_num_threads(threads)
+    times = []
+    with torch.no_grad():
+        nerf_oracle.render(params, configs, batch, training=False)        # warm-up
+        while len(times) < max_runs and (not times or sum(times) < budget_seconds):
+            t0 = time.perf_counter()
+            nerf_oracle.render(params, configs, batch, training=False)
+            times.append(time.perf_counter() - t0)
+    return {'threads': threads, 'value': RAYS_PER_GPU / min(times), 'unit': 'rays/s', 'runs': len(times),
+            'best_s': min(times), 'mean_s': sum(times) / len(times)}
 
-    def leg(threads):
-        torch.set_num_threads(threads)
-        times = []
-        with torch.no_grad():
-            nerf_oracle.render(params, configs, batch, training=False)        # warm-up
-            while len(times) < max_runs and (not times or sum(times) < budget_seconds):
-                t0 = time.perf_counter()
-                nerf_oracle.render(params, configs, batch, training=False)
-                times.append(time.perf_counter() - t0)
-        return {'threads': threads, 'value': RAYS_PER_GPU / min(times), 'unit': 'rays/s', 'runs': len(times),
-                'best_s': min(times), 'mean_s': sum(times) / len(times)}
 
+def cpu_baseline(kind, first_ray):
+    """The oracle timed on this host's cores, on the same 1024-ray batch as the GPU step.  BASELINE.md section 3's protocol --
+    ``torch.set_num_threads(os.cpu_count())``, one warm-up, best of the following passes -- plus, beside it, the same at 16
+    threads (the GPU box's per-GPU CPU share).  Each leg runs in a child process with a hard time limit: where the box gives
+    this job fewer cores than ``os.cpu_count()`` reports, the first leg oversubscribes them and one pass can take minutes
+    (round 4's first attempt ran it in-process and the whole bench was killed as silent) -- such a leg is reported as timed
+    out, which is itself the reason the 16-thread figure is the baseline there.  `value` is the FASTEST leg (the baseline at
+    its best), `cores` its thread count."""
     counts = []
     for n in (os.cpu_count() or 1, 16):
         if n not in counts:
             counts.append(n)
-    previous = torch.get_num_threads()
-    try:
-        legs = [leg(n) for n in counts]
-    finally:
-        torch.set_num_threads(previous)
-    best = max(legs, key=lambda r: r['value'])
+    legs = []
+    for n in counts:
+        cmd = [sys.executable, os.path.abspath(__file__), '--cpu-leg', str(n), '--cpu-leg-args', kind, str(first_ray)]
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+        env.update(OMP_NUM_THREADS=str(n), MKL_NUM_THREADS=str(n))
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=CPU_LEG_TIMEOUT_S, env=env)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            if r.returncode == 0 and lines:
+                legs.append(json.loads(lines[-1]))
+            else:
+                legs.append({'threads': n, 'failed': (r.stderr or r.stdout)[-300:]})
+        except subprocess.TimeoutExpired:
+            legs.append({'threads': n, 'timed_out_after_s': round(time.perf_counter() - t0, 1),
+                         'note': 'more threads than the cores this job may use: not a usable baseline on this host'})
+    done = [r for r in legs if 'value' in r]
+    if not done:
+        return {'value': None, 'unit': 'rays/s', 'cores': None, 'kind': 'port', 'legs': legs,
+                'host': {'os_cpu_count': os.cpu_count(), 'usable_cores': host_cores()}}
+    best = max(done, key=lambda r: r['value'])
     return {'value': best['value'], 'unit': 'rays/s', 'cores': best['threads'], 'kind': 'port',
             'sample': f"{RAYS_PER_GPU} rays of the same workload, best of {best['runs']} after 1 warm-up ({best['best_s']:.3f} s best, "
                       f"{best['mean_s']:.3f} s mean), torch {torch.__version__} CPU fp32, chunk 4096 / netchunk 16384",
@@ -575,7 +628,7 @@ def train_bench(args, rank, world, device, dist):
             line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(), 'bytes': 2265488 * 4,
                                   'pattern': 'one all-reduce of the flattened parameter gradients per iteration',
                                   'per_rank': [{'rank': i, 'step_ms_p50': r[0], 'elapsed_s': r[1]} for i, r in enumerate(ranks)]}
-        print(json.dumps(line), flush=True)
+        emit(line)
 
 
 # ---------------------------------------------------------------------------------------------- whole frames (configs 2, 4)
@@ -666,7 +719,7 @@ def frame_bench(args, rank, world, device, dist, make_renderer, data):
     if dist is not None:
         line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                               'bytes': per * FRAME_GATHER_BYTES, 'pattern': 'one gather of the five per-ray outputs to rank 0 per frame'}
-    print(json.dumps(line), flush=True)
+    emit(line)
 
 
 # ---------------------------------------------------------------------------------------------- headline
@@ -703,6 +756,8 @@ def render_bench(args, rank, world, device, dist, make_renderer, data):
 
     renderer = make_renderer(args.precision, 'headline')
     m = measure_headline(renderer, args.steps, args.warmup, fence, world)
+    if rank == 0:
+        progress(f'headline timed: {m["elapsed"] / args.steps * 1e3:.3f} ms/step')
     ranks = None
     if collective:
         # what each rank saw, so that a sub-linear point can be attributed: its own step time, the MLP kernels' share of
@@ -769,6 +824,7 @@ def render_bench(args, rank, world, device, dist, make_renderer, data):
                                'frac': s_tf / PEAK_FP32_MFMA_TFLOPS, 'timed_region_s': s['elapsed'],
                                'timing': step_summary(s['elapsed'], s['device_ms'], s['enqueue_ms'], sum(s['launch_ms'])),
                                'board': board_state(renderer, s_tf, PEAK_FP32_MFMA_TFLOPS)}
+        progress('sustained leg done')
         for key, precision, text in (
                 ('also_measured', 'f16x3', 'f16x3 (fp16 hi/lo split, 3 MFMA passes per product, fp32 accumulate; same parity tests)'),
                 ('also_measured_16bit', 'f16', 'f16 (one fp16 MFMA pass per product, fp32 accumulate; OUTSIDE the fp32 parity bar -- '
@@ -783,11 +839,15 @@ def render_bench(args, rank, world, device, dist, make_renderer, data):
                            'roofline': line['roofline'], 'timing': line['timing'],
                            'board': board_state(r, line['roofline']['achieved'], PRECISION_INFO[precision][0])}
             del r
+        progress('other precisions done')
         result['also_measured_frame'] = frame_records_single(make_renderer, fence)
+        progress('frames done')
         result['also_measured_train'] = training_record(device)
+        progress('training records done')
     if world == 1 and gpu and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(renderer.configs, renderer.camera, renderer.first)
-    print(json.dumps(result), flush=True)
+        result['cpu_baseline'] = cpu_baseline('headline', renderer.first)
+        progress('cpu baseline done')
+    emit(result)
 
 
 def visible_gpus():
@@ -824,7 +884,12 @@ def main(argv=None, renderer_cls=None, backend='nccl', share_devices=False, scri
                     help="arithmetic of the fused MLP kernel: fp32 MFMA; fp16 hi/lo split with 3 MFMAs per product "
                          "(fp32-grade results, same parity tests); or f16 = one fp16 MFMA per product with 16-bit saved "
                          "tensors (BASELINE config 5's 16-bit training mode, own tolerances: tests/test_gpu_f16.py)")
+    ap.add_argument('--cpu-leg', type=int, default=None, help=argparse.SUPPRESS)          # child of cpu_baseline: THREADS
+    ap.add_argument('--cpu-leg-args', nargs=2, default=None, help=argparse.SUPPRESS)       # workload kind, first ray
     args = ap.parse_args(argv)
+    if args.cpu_leg is not None:           # no GPU, no process group: one CPU leg, one JSON line
+        print(json.dumps(cpu_leg(args.cpu_leg_args[0], int(args.cpu_leg_args[1]), args.cpu_leg)), flush=True)
+        return
     if args.settle_seconds is not None:
         SETTLE_SECONDS = max(0.0, args.settle_seconds)
     if args.steps is None:
@@ -838,6 +903,7 @@ def main(argv=None, renderer_cls=None, backend='nccl', share_devices=False, scri
             raise SystemExit(f'--gpus {args.gpus}: this node has {visible_gpus()} GPU(s); RCCL needs one device per rank')
         raise SystemExit(launch_ranks(args.gpus, script))       # nothing above this line touches the GPU
 
+    claim_stdout()
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))

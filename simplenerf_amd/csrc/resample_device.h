@@ -99,18 +99,22 @@ __device__ __forceinline__ void resample_wave(const float* __restrict__ zc, cons
     // pdf = (w[1:-1] + 1e-5) / sum ; cdf = [0, cumsum(pdf)]  (:332-335) in the reference's own summation orders, so that
     // identical inputs give identical bits: torch.sum's vectorised order for the normaliser (torch_row_sum) and
     // torch.cumsum's for the running sum -- the CPU kernel accumulates a float row SEQUENTIALLY IN DOUBLE and rounds
-    // every entry to float (aten/src/ATen/native/cpu/ReduceOpsKernel.cpp, acc_type<float, false> = double).  The
-    // pdf is staged in cdf[1..m]; every lane then runs the same serial loop over it (broadcast LDS reads, 62-126 dependent
-    // fp64 adds: well under a microsecond per ray) and lane j % 64 stores entry j.
+    // every entry to float (aten/src/ATen/native/cpu/ReduceOpsKernel.cpp, acc_type<float, false> = double).  Every
+    // lane runs the same serial chain (62-126 dependent fp64 adds per ray), fed by readlane from the lane that holds the
+    // entry; lane j % 64 keeps entry j.
     const float denom_sum = torch_row_sum(wc + 1, m, lane);
     if (lane == 0) cdf[0] = 0.0f;
-    for (int j = lane; j < m; j += 64) cdf[j + 1] = __fdiv_rn(wc[j + 1] + 1e-5f, denom_sum);
-    snerf::wave_lds_sync();
     double run = 0.0;
-    for (int j = 0; j < m; ++j) {
-        run += (double)cdf[j + 1];
-        snerf::wave_lds_sync();          // every lane has read entry j before one of them overwrites it
-        if ((j & 63) == lane) cdf[j + 1] = (float)run;
+    for (int base = 0; base < m; base += 64) {          // 64 pdf entries at a time, one per lane, held in a register
+        const int j = base + lane;
+        const float mine = j < m ? __fdiv_rn(wc[j + 1] + 1e-5f, denom_sum) : 0.0f;
+        const int count = m - base < 64 ? m - base : 64;
+        float entry = 0.0f;
+        for (int k = 0; k < count; ++k) {               // the serial fp64 chain: readlane + add per entry, no memory traffic
+            run += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), k));
+            if (lane == k) entry = (float)run;
+        }
+        if (j < m) cdf[j + 1] = entry;
     }
     snerf::wave_lds_sync();
 

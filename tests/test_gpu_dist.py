@@ -218,8 +218,10 @@ def _plain_bench(*flags, timeout=900):
     r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), *flags], capture_output=True, text=True, timeout=timeout,
                        env=_clean_env())
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, r.stdout[-2000:]
+    # stdout is the ONE JSON line and nothing else (RCCL's version banner, printed on stdout when the first communicator is
+    # created, must not reach it)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), r.stdout[-2000:]
     return json.loads(lines[0])
 
 

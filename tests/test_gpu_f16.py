@@ -342,14 +342,14 @@ def test_overflow_of_a_view_independent_mlps_last_activations_is_detected():
     assert not cfg['model']['views_augmentation']['coarse_mlp']['use_view_dirs']
     batch = harness.frame_batch(synth.camera('fern', 0), True, DEV, 200000, 64)
     ops.range_status(clear=True)
+    model(batch)                  # (with autograd on: the STORING forward is the one that converts these activations)
+    torch.cuda.synchronize()
+    assert ops.range_status() == 0
+    last = cfg['model']['views_augmentation']['coarse_mlp']['points_net_depth'] - 1
     with torch.no_grad():
-        model(batch)
-        torch.cuda.synchronize()
-        assert ops.range_status() == 0
-        last = cfg['model']['views_augmentation']['coarse_mlp']['points_net_depth'] - 1
         model.views_aug_coarse_model.pts_linears[last].bias[3] = 1.0e5
-        model(batch)
-        torch.cuda.synchronize()
+    model(batch)
+    torch.cuda.synchronize()
     assert ops.range_status(clear=True) & ops.RANGE_ACTIVATION
 
 

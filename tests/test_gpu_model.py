@@ -444,8 +444,8 @@ def test_config4_re10k_full_frame_properties_and_eight_way_shards(resolution):
     assert numpy.array_equal(frame['image'].reshape(-1, 3), ref_img) and numpy.array_equal(frame['depth'].reshape(-1), ref_depth)
 
 
-K_SELF = 2.0          # allowance vs the committed fp32 reference outputs = K_SELF x the reference's own evaluation-order noise
-K_EXACT = 1.5         # allowance vs the reference in double precision = K_EXACT x the reference's own fp32 error against it
+K_SELF = 1.5          # allowance vs the committed fp32 reference outputs = K_SELF x the reference's own evaluation-order noise
+K_EXACT = 1.25        # allowance vs the reference in double precision = K_EXACT x the reference's own fp32 error against it
 SLACK_RAYS = 4        # + 4 rays of 4096 (0.1 %) on either gate: fractions of a few rays are counting noise
 
 
@@ -461,9 +461,10 @@ def test_frame_slice_against_committed_reference_outputs(kind, profile, precisio
     is what ANOTHER SUMMATION ORDER of the same function does to it -- the reference with its hidden units relabelled --
     and how far its fp32 run is from its own double-precision run.  Gates:
       * coarse outputs: every ray at the full tolerance; coarse depths bit-equal;
-      * fine colour / opacity / NDC depth vs the committed fp32 outputs: rays over tolerance <= K_SELF x max(relabelled
-        reference vs reference, reference fp32 vs reference fp64) + 0.1 %, and (all but 0.1 % of) them on rays whose resampled
-        depths moved;
+      * fine colour / opacity / NDC depth vs the committed fp32 outputs: rays over tolerance <= K_SELF x (relabelled
+        reference vs reference) + 0.1 %, and (all but 0.1 % of) them on rays whose resampled depths moved  [round 4, first
+        run: config 2 'dense' 2.9 % against the relabelled reference's 2.8 %; 4.5 % in round 3, before K5 summed in torch's
+        orders];
       * the same outputs vs the reference in DOUBLE precision: rays over tolerance <= K_EXACT x the reference's own fp32 run
         against it + 0.1 % -- the kernels are as close to the exact value as the reference is."""
     import json
@@ -499,8 +500,7 @@ def test_frame_slice_against_committed_reference_outputs(kind, profile, precisio
         return flags
 
     over, over_exact = over_tolerance(ref), over_tolerance(exact)
-    self_noise = max(noise['t8_unitperm']['rays_over_1e-4_rgb_acc_or_1e-3_ndc_depth'],
-                     noise['canonical_vs_f64']['rays_over_1e-4_rgb_acc_or_1e-3_ndc_depth'])
+    self_noise = noise['t8_unitperm']['rays_over_1e-4_rgb_acc_or_1e-3_ndc_depth']
     bound = K_SELF * self_noise + SLACK_RAYS / count
     bound_exact = K_EXACT * noise['canonical_vs_f64']['rays_over_1e-4_rgb_acc_or_1e-3_ndc_depth'] + SLACK_RAYS / count
     unmoved_allowed = 0 if profile == 'consistent' else int(MAX_UNMOVED_OVER * count)
