@@ -86,6 +86,9 @@ PRECISION_INFO = {
               'counts algorithmic FLOPs'),
     'f16': (PEAK_FP16_MFMA_TFLOPS, 'f16 (fp16 MFMA, fp32 accumulate)', 'mlp_forward_m16_kernel<1,8>',
             'one fp16 MFMA pass per product; NOT within the fp32 parity bar (sigma ~1e-3 relative)'),
+    'bf16': (PEAK_FP16_MFMA_TFLOPS, 'bf16 (bf16 MFMA, fp32 accumulate)', 'mlp_forward_m16_kernel<1,8,true>',
+             'one bf16 MFMA pass per product (BASELINE config 5\'s literal dtype; no range limit); NOT within the fp32 parity bar '
+             '(sigma ~1e-2 relative, tests/test_gpu_bf16.py)'),
 }
 
 # whole-frame workloads (BASELINE configs 2 and 4; SURVEY 8d resolves the resolutions): name -> (scene, camera kwargs, text)
@@ -524,7 +527,7 @@ def training_step(precision, rank, world, device, single_pass=False, graphed=Fal
 
 TRAIN_WORKLOAD = ('config 5: 2048 pixel + 2048 sparse-depth rows per GPU in two sub-batches, main coarse+fine + points-aug + '
                   'views-aug MLPs (64 + 192 samples), nine shipped losses, Adam, NeRF LR decay')
-TRAIN_DTYPE = {'fp32': 'f32', 'f16x3': 'f16x3', 'f16': 'f16 (bf16 layer gradients)'}
+TRAIN_DTYPE = {'fp32': 'f32', 'f16x3': 'f16x3', 'f16': 'f16 (bf16 layer gradients)', 'bf16': 'bf16'}
 
 
 def time_training(precision, device, steps, warmup, single_pass=False, board_seconds=0.0, graphed=False):
@@ -568,10 +571,12 @@ def training_record(device, steps=10, warmup=3):
     dominant = {'fp32': 'wgrad_kernel<2,8,false> (weight gradients); forward mlp_forward_kernel<8,4,true,false,true>',
                 'f16x3': 'wgrad_kernel<2,8,true> (weight gradients); chain mlp_backward_chain_f16x3_kernel<8,4,true,3,8>',
                 'f16': 'chain mlp_backward_chain_f16x3_kernel<8,4,true,1,8>; wgrad16_kernel<2,8> (weight gradients, HBM-bound, '
-                       '6.4 TB/s); forward mlp_forward_f16x3_kernel<8,4,true,false,true,1,8>'}
+                       '6.4 TB/s); forward mlp_forward_f16x3_kernel<8,4,true,false,true,1,8>',
+                'bf16': 'the f16 kernels instantiated for bf16 operands (<..., true>): v_mfma_f32_32x32x16_bf16'}
     out = {'workload': TRAIN_WORKLOAD, 'rows_per_gpu': 4096, 'steps': steps, 'warmup': warmup, 'modes': {}}
     # (f16x3 issues three fp16 MFMA passes per algorithmic product: its ceiling is a third of the fp16 peak)
-    for precision, peak in (('fp32', PEAK_FP32_MFMA_TFLOPS), ('f16x3', PEAK_FP16_MFMA_TFLOPS / 3), ('f16', PEAK_FP16_MFMA_TFLOPS)):
+    for precision, peak in (('fp32', PEAK_FP32_MFMA_TFLOPS), ('f16x3', PEAK_FP16_MFMA_TFLOPS / 3), ('f16', PEAK_FP16_MFMA_TFLOPS),
+                            ('bf16', PEAK_FP16_MFMA_TFLOPS)):
         ms, fwd_ms, bwd_ms, rows = time_training(precision, device, steps, warmup, board_seconds=1.0)
         tflops = rows * TRAIN_FLOP_PER_RAY / (ms * 1e-3) / 1e12
         out['modes'][precision] = {
@@ -828,7 +833,9 @@ def render_bench(args, rank, world, device, dist, make_renderer, data):
         for key, precision, text in (
                 ('also_measured', 'f16x3', 'f16x3 (fp16 hi/lo split, 3 MFMA passes per product, fp32 accumulate; same parity tests)'),
                 ('also_measured_16bit', 'f16', 'f16 (one fp16 MFMA pass per product, fp32 accumulate; OUTSIDE the fp32 parity bar -- '
-                 'colour ~1e-4, depth ~6e-4 from the fp32 path, tests/test_gpu_f16.py; BASELINE config 5 names this mode for training)')):
+                 'colour ~1e-4, depth ~6e-4 from the fp32 path, tests/test_gpu_f16.py; BASELINE config 5 names this mode for training)'),
+                ('also_measured_bf16', 'bf16', 'bf16 (one bf16 MFMA pass per product, fp32 accumulate; BASELINE config 5\'s literal dtype, no '
+                 'range limit; OUTSIDE the fp32 parity bar -- colour ~1e-3, tests/test_gpu_bf16.py)')):
             r = make_renderer(precision, 'headline')
             a = measure_headline(r, args.steps, args.warmup, fence, 1)
             line = headline_line(1, args.steps, args.warmup, precision, a['elapsed'], a['device_ms'], a['enqueue_ms'],
@@ -880,7 +887,7 @@ def main(argv=None, renderer_cls=None, backend='nccl', share_devices=False, scri
                     help='run the N > 1 protocol -- process group, barriers, the per-step gather (or gradient all-reduce), the '
                          'max-over-ranks reduction -- with whatever N is, including 1: every RCCL call of the multi-GPU line on a '
                          'one-GPU box')
-    ap.add_argument('--precision', choices=('fp32', 'f16x3', 'f16'), default='fp32',
+    ap.add_argument('--precision', choices=('fp32', 'f16x3', 'f16', 'bf16'), default='fp32',
                     help="arithmetic of the fused MLP kernel: fp32 MFMA; fp16 hi/lo split with 3 MFMAs per product "
                          "(fp32-grade results, same parity tests); or f16 = one fp16 MFMA per product with 16-bit saved "
                          "tensors (BASELINE config 5's 16-bit training mode, own tolerances: tests/test_gpu_f16.py)")

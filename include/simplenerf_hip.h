@@ -100,10 +100,14 @@ enum snerf_precision {
     SNERF_PRECISION_F16X3 = 1, /* every operand split into two fp16 (hi + lo, ~22 significand bits), three fp16 MFMAs per
                                   product (hi.hi + hi.lo + lo.hi), fp32 accumulate: fp32-grade results at 3/16 of the
                                   fp32-MFMA time */
-    SNERF_PRECISION_F16 = 2    /* 16-bit mode: one fp16 MFMA per product (11 significand bits per operand), fp32 accumulate,
+    SNERF_PRECISION_F16 = 2,   /* 16-bit mode: one fp16 MFMA per product (11 significand bits per operand), fp32 accumulate,
                                   fp32 master weights, biases, heads and outputs; training keeps activations as fp16 and
                                   layer gradients as bf16 (half the HBM traffic).  NOT within the fp32 parity bar: results
                                   agree with the fp32 path to ~1e-3 (tests/test_gpu_f16.py states the tolerances) */
+    SNERF_PRECISION_BF16 = 3   /* the same kernels on bf16 operands (v_mfma_f32_*_bf16, 8 significand bits, fp32's exponent
+                                  range): BASELINE config 5's literal dtype.  No range limit -- nothing below under "Range"
+                                  applies -- at 3 fewer significand bits than SNERF_PRECISION_F16; saved activations and layer
+                                  gradients both bf16.  Own tolerances (tests/test_gpu_bf16.py) */
 };
 /* Range: both fp16 modes hold hidden activations and weights as fp16 numbers (pairs), so their magnitudes must stay
  * below 65504 -- far above what a NeRF MLP on encoded inputs produces (trained hidden units are O(1..100)).  Exceeding it

@@ -25,6 +25,7 @@
 
 namespace snerf {
 int mlp_backward_chain_f16x3(const MlpPlan& plan, const ChainArgs& a, int products, hipStream_t stream);  // mlp_backward_f16.hip
+int mlp_backward_chain_bf16(const MlpPlan& plan, const ChainArgs& a, hipStream_t stream);                   // mlp_backward_bf16.hip
 }
 
 namespace {
@@ -520,7 +521,9 @@ constexpr int kWgrad16Buffers = 3;
 // reads, MFMAs and stores).  As four launches of their own register-tile classes each of them was mostly launch, ramp and
 // tail (20-50 us for a few MB of operands; 13 % of the 16-bit training iteration with the reduction, MFMA pipe 4-13 % busy).
 // The per-tile arithmetic and the chunking are unchanged, so the partial sums -- and the gradients -- are bit-identical.
-template <int NO, int NI, bool PARTIAL = false>
+// BF (SNERF_PRECISION_BF16): X is saved as bf16 too, so both fragments go to v_mfma_f32_32x32x16_bf16 as they are -- no
+// widening, no region scale (bf16 has the range), and the reduction applies no factor (WgradJob::half = 0).
+template <int NO, int NI, bool PARTIAL = false, bool BF = false>
 __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const unsigned short* __restrict__ grads,
                                                          const unsigned short* __restrict__ acts, float* __restrict__ partial,
                                                          const float* __restrict__ zeros) {
@@ -605,7 +608,7 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     // 4q+p of the group points at sample row q, feature columns 4p..4p+3 of the piece
     const int grp = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
     const unsigned lane_off = (grp & 1) * kPieceGap + 32 * (8 * (grp >> 1) + q4) + 16 * (p4 & 1) + 8 * (p4 >> 1);
-    const float gk = wgrad_scale(region_max(zeros, job.dy_row0 / 32));
+    const float gk = BF ? 1.0f : wgrad_scale(region_max(zeros, job.dy_row0 / 32));
 
     // Software pipeline over the 16-sample k-steps (two per block): the transposed reads of step t+1 are issued before the
     // MFMAs of step t, into the other fragment set, so the LDS latency and the bf16->fp16 conversion of the next step run
@@ -649,9 +652,12 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
                 const unsigned word = f.a[oo].d[w >> 1][w & 1];
                 const f32x2 v = {__uint_as_float(word << 16), __uint_as_float(word & 0xffff0000u)};
                 bsum[oo] += v[0] + v[1];
-                const f16x2 hcv = __builtin_convertvector(v * gk, f16x2);
-                ah[oo][2 * w] = hcv[0]; ah[oo][2 * w + 1] = hcv[1];
+                if constexpr (!BF) {
+                    const f16x2 hcv = __builtin_convertvector(v * gk, f16x2);
+                    ah[oo][2 * w] = hcv[0]; ah[oo][2 * w + 1] = hcv[1];
+                }
             }
+            if constexpr (BF) ah[oo] = f.a[oo].h;     // the bf16 fragment as read
         }
     };
     auto products = [&](const FragSet& f, const f16x8 (&ah)[NO]) {
@@ -660,7 +666,7 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
 #pragma unroll
             for (int ii = 0; ii < NI; ++ii) {
                 if (PARTIAL && (oo >= no_eff || ii >= ni_eff)) continue;
-                acc[oo][ii] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[oo], f.bx[ii].h, acc[oo][ii], 0, 0, 0);
+                acc[oo][ii] = mfma_32x32x16<BF>(ah[oo], f.bx[ii].h, acc[oo][ii]);
             }
     };
 
@@ -943,12 +949,12 @@ int launch_wgrad(const JobTable& table, const float* grads, const float* acts, f
 
 }  // namespace
 
-template <int NO, int NI, bool PARTIAL = false>
+template <int NO, int NI, bool PARTIAL = false, bool BF = false>
 int launch_wgrad16(const JobTable& table, const float* grads, const float* acts, float* partial, hipStream_t stream) {
     int max_tiles = 0;
     for (int j = 0; j < table.count; ++j) max_tiles = std::max(max_tiles, table.jobs[j].out_tiles + table.jobs[j].in_tiles);
     const size_t lds_bytes = (size_t)kWgrad16Buffers * max_tiles * kPairBytes;
-    auto kernel = wgrad16_kernel<NO, NI, PARTIAL>;
+    auto kernel = wgrad16_kernel<NO, NI, PARTIAL, BF>;
     static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
     const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), kWgrad16Buffers * 16 * kPairBytes, "mlp_backward");
     if (attr != SNERF_OK) return attr;
@@ -978,10 +984,12 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
                   num_params);
     for (int i = 0; i < num_params; ++i) SNERF_REQUIRE(param_grads[i], "mlp_backward: gradient tensor %d is NULL", i);
     SNERF_REQUIRE(num_rays >= 1 && num_samples >= 1, "mlp_backward: bad sizes n=%lld S=%d", num_rays, num_samples);
-    if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3 && precision != SNERF_PRECISION_F16)
+    if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3 && precision != SNERF_PRECISION_F16 &&
+        precision != SNERF_PRECISION_BF16)
         return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: precision %d not built", precision);
-    const bool f16 = precision == SNERF_PRECISION_F16;   // saved_acts must come from forward_train at the same precision
-    if (precision != SNERF_PRECISION_FP32) {   // the forward that saved these activations may have left the fp16 range
+    const bool bf16 = precision == SNERF_PRECISION_BF16;
+    const bool f16 = precision == SNERF_PRECISION_F16 || bf16;   // the 16-bit tile layouts; saved_acts must come from forward_train at the same precision
+    if (precision != SNERF_PRECISION_FP32 && !bf16) {   // the forward that saved these activations may have left the fp16 range
         const int range = snerf::report_range("mlp_backward");
         if (range != SNERF_OK) return range;
     }
@@ -1024,7 +1032,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     a.dy_max = nullptr;
     if (precision != SNERF_PRECISION_FP32) {
         a.dy_max = reinterpret_cast<unsigned*>(partial) + kRegionTableFloat0;
-        rc = snerf::mlp_backward_chain_f16x3(plan, a, f16 ? 1 : 3, s);
+        rc = bf16 ? snerf::mlp_backward_chain_bf16(plan, a, s) : snerf::mlp_backward_chain_f16x3(plan, a, f16 ? 1 : 3, s);
         if (rc != SNERF_OK) return rc;
     }
     switch (key) {
@@ -1043,7 +1051,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     for (WgradJob& job : jobs) {
         int no, ni;
         wave_tile(job, &no, &ni);
-        job.half = (f16 || (precision == SNERF_PRECISION_F16X3 && ni == 8)) ? 1 : 0;
+        job.half = ((f16 && !bf16) || (precision == SNERF_PRECISION_F16X3 && ni == 8)) ? 1 : 0;   // (bf16: no region scale)
     }
     // (the zero page and the gradient-max word were cleared before the chain kernel)
     JobTable table;  // all jobs, for the reduction
@@ -1084,7 +1092,8 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
             ++sub.count;
         }
         if (sub.count > 0) {
-            rc = launch_wgrad16<2, 2, true>(sub, grads, saved_acts, partial, s);
+            rc = bf16 ? launch_wgrad16<2, 2, true, true>(sub, grads, saved_acts, partial, s)
+                      : launch_wgrad16<2, 2, true>(sub, grads, saved_acts, partial, s);
             if (rc != SNERF_OK) return rc;
         }
     }
@@ -1102,7 +1111,16 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
         }
         if (sub.count == 0) continue;
         const bool x3 = precision == SNERF_PRECISION_F16X3;
-        if (f16) {
+        if (bf16) {
+            if (cls[0] == 2 && cls[1] == 8) rc = launch_wgrad16<2, 8, false, true>(sub, grads, saved_acts, partial, s);
+            else if (cls[0] == 2 && cls[1] == 2) rc = launch_wgrad16<2, 2, false, true>(sub, grads, saved_acts, partial, s);
+            else if (cls[0] == 2 && cls[1] == 1) rc = launch_wgrad16<2, 1, false, true>(sub, grads, saved_acts, partial, s);
+            else if (cls[0] == 1 && cls[1] == 8) rc = launch_wgrad16<1, 8, false, true>(sub, grads, saved_acts, partial, s);
+            else if (cls[0] == 1 && cls[1] == 4) rc = launch_wgrad16<1, 4, false, true>(sub, grads, saved_acts, partial, s);
+            else if (cls[0] == 1 && cls[1] == 2) rc = launch_wgrad16<1, 2, false, true>(sub, grads, saved_acts, partial, s);
+            else rc = launch_wgrad16<1, 1, false, true>(sub, grads, saved_acts, partial, s);
+        }
+        else if (f16) {
             if (cls[0] == 2 && cls[1] == 8) rc = launch_wgrad16<2, 8>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 2 && cls[1] == 2) rc = launch_wgrad16<2, 2>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 2 && cls[1] == 1) rc = launch_wgrad16<2, 1>(sub, grads, saved_acts, partial, s);

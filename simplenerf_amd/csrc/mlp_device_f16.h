@@ -11,6 +11,45 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 constexpr int kUnitBufFloats = 22 * 512;  // largest unit: 22 k-steps x 2 KiB (views layer of the points-aug MLP)
 constexpr int kUnitBuffers = 3;
 
+// ---- the two 16-bit operand formats of the single-product kernels -----------------------------------------------------------
+// SNERF_PRECISION_F16 multiplies fp16 operands (11 significand bits, |v| <= 65504: the range watch below), SNERF_PRECISION_BF16
+// bf16 operands (8 significand bits, fp32's exponent range: nothing to watch) -- BASELINE config 5's literal dtype.  Same MFMA
+// rate, same fragment layouts, same 16-bit saved tensors; what differs is the conversion instruction, the MFMA opcode and the
+// weight stream the kernel reads (mlp_plan.h: the bf16 streams hold one KiB per k-step, no lo fragments).  Operand registers
+// are typed f16x8 in both modes: a container of eight 16-bit patterns; `BF` says how to read them.
+template <bool BF>
+__device__ __forceinline__ f32x16 mfma_32x32x16(const f16x8& a, const f16x8& b, const f32x16& c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <bool BF>
+__device__ __forceinline__ f32x4 mfma_16x16x32(const f16x8& a, const f16x8& b, const f32x4& c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// two fp32 values -> the packed 16-bit pair (round to nearest even: v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32), ReLU optional.
+// fp16: relu(fp16(v)) == fp16(relu(v)), so the maximum follows the conversion as ONE packed instruction; bf16 has no packed
+// maximum, the two fp32 maxima come first.
+template <bool BF, bool RELU>
+__device__ __forceinline__ f16x2 pack_pair(f32x2 v) {
+    if constexpr (BF) {
+        if (RELU) v = {fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
+        return __builtin_bit_cast(f16x2, __builtin_convertvector(v, bf16x2));
+    } else {
+        f16x2 h = __builtin_convertvector(v, f16x2);
+        if (RELU) {
+            const f16x2 zero = {(_Float16)0.0f, (_Float16)0.0f};
+            h = __builtin_elementwise_max(h, zero);
+        }
+        return h;
+    }
+}
+template <bool BF>
+__device__ __forceinline__ _Float16 pack_one(float v) {
+    if constexpr (BF) return __builtin_bit_cast(_Float16, (__bf16)v);
+    else return (_Float16)v;
+}
+
 #define SNERF_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
 __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform in [0, 63]; the count must be an immediate
     switch (n) {
@@ -48,8 +87,10 @@ __device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform in [0,
 // what matters to kernels that also STORE between units -- the counted wait at unit i then leaves everything the wave issued
 // during the last D - 2 units in flight, not just the last one: vmcnt retires in order, so a store whose write acknowledgement
 // takes longer than one unit's matrix work (HBM under a 3 TB/s write stream: ~2 us) otherwise stalls the next acquire.
-template <int P, int NW = 4, int D = kUnitBuffers>
+// KF = floats per k-step in the STREAM: 512 (hi + lo fragment; the fp16 streams) or 256 (the bf16 streams: hi only).
+template <int P, int NW = 4, int D = kUnitBuffers, int KF = 512>
 struct UnitStreamT {
+    static_assert(KF == 512 || (KF == 256 && P == 1), "compact streams are single-product");
     static_assert(NW == 4 || (NW == 8 && P == 1), "8-wave rings are built for the single-product kernels only");
     static_assert(D >= 3 && D <= 6, "ring depth");
     static constexpr int kWaves = NW;
@@ -103,7 +144,7 @@ struct UnitStreamT {
         pend_dst = lds + into_slot * slot_floats + wave * 256 - NW * 256;
         pend_left = P == 3 ? ksteps >> 1 : (ksteps + NW - 1) / NW;
         issued = 0;
-        fetch_ptr += ksteps * 512;
+        fetch_ptr += ksteps * KF;
     }
     __device__ __forceinline__ void fetch(int ksteps, int into_slot) {
         begin_fetch(ksteps, into_slot);
@@ -281,7 +322,7 @@ __device__ __forceinline__ void lds_wait_all_but(f16x8& a) {
     if (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a)::"memory");
     if (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a)::"memory");
 }
-template <int NKS, int NB, typename Stream>
+template <int NKS, bool BF, int NB, typename Stream>
 __device__ __forceinline__ void seg_mfma1(f32x16& acc, const float*& p, const f16x8 (&bh)[NB], Stream& st) {
     static_assert(NB >= NKS, "operand array too short");
     constexpr int AHEAD = 4;
@@ -301,7 +342,7 @@ __device__ __forceinline__ void seg_mfma1(f32x16& acc, const float*& p, const f1
         else if (newer == 2) lds_wait_all_but<2>(cur);
         else if (newer == 1) lds_wait_all_but<1>(cur);
         else lds_wait_all_but<0>(cur);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bh[ks], acc, 0, 0, 0);
+        acc = mfma_32x32x16<BF>(cur, bh[ks], acc);
         if ((ks & (Stream::kWaves - 1)) == 0) st.fetch_piece();   // one KiB-piece per wave and kWaves k-steps
     }
     p += NKS * 256;
@@ -310,7 +351,7 @@ __device__ __forceinline__ void seg_mfma1(f32x16& acc, const float*& p, const f1
 // The same with `side(ks)` slotted behind the MFMA of every k-step (ks is a compile-time constant after unrolling): VALU work
 // that does not depend on this tile's accumulator issues while the matrix pipe runs the MFMA (32 cycles = eight VALU slots).
 // With one wave per SIMD nothing else fills those slots -- work placed BETWEEN tiles instead runs with the matrix pipe idle.
-template <int NKS, int NB, typename Stream, typename Side>
+template <int NKS, bool BF, int NB, typename Stream, typename Side>
 __device__ __forceinline__ void seg_mfma1_side(f32x16& acc, const float*& p, const f16x8 (&bh)[NB], Stream& st, Side&& side) {
     static_assert(NB >= NKS, "operand array too short");
     constexpr int AHEAD = 4;
@@ -330,7 +371,7 @@ __device__ __forceinline__ void seg_mfma1_side(f32x16& acc, const float*& p, con
         else if (newer == 2) lds_wait_all_but<2>(cur);
         else if (newer == 1) lds_wait_all_but<1>(cur);
         else lds_wait_all_but<0>(cur);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bh[ks], acc, 0, 0, 0);
+        acc = mfma_32x32x16<BF>(cur, bh[ks], acc);
         if ((ks & (Stream::kWaves - 1)) == 0) st.fetch_piece();
         side(ks);
     }
@@ -342,11 +383,11 @@ struct NoSide {
 };
 
 // P = 3: split-precision product (hi.hi + hi.lo + lo.hi); P = 1: hi.hi only.
-template <int P, int NKS, int NB, typename Stream>
+template <int P, int NKS, bool BF, int NB, typename Stream>
 __device__ __forceinline__ void seg_product(f32x16& acc, const float*& p, int unit_ks, const f16x8 (&bh)[NB],
                                             const f16x8 (&bl)[NB], Stream& st) {
     if constexpr (P == 3) seg_mfma<NKS>(acc, p, unit_ks, bh, bl, NoSide(), 8, st);
-    else seg_mfma1<NKS>(acc, p, bh, st);
+    else seg_mfma1<NKS, BF>(acc, p, bh, st);
 }
 
 __device__ __forceinline__ void tile_bias(f32x16& acc, const float* __restrict__ bias, int half) {
@@ -361,17 +402,12 @@ __device__ __forceinline__ void tile_bias(f32x16& acc, const float* __restrict__
 // Single-product kernels: only the hi operand exists, so the ReLU can follow the conversion as ONE packed fp16 maximum per
 // register pair (relu(fp16(v)) == fp16(relu(v)) bit for bit: rounding is monotone and keeps the sign) instead of one fp32
 // maximum per value before it -- 64 fewer VALU instructions per layer and wave.
-template <bool RELU>
+template <bool RELU, bool BF = false>
 __device__ __forceinline__ void convert_tile(const f32x16& acc, f16x8& h0, f16x8& h1) {
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-        f16x2 a = __builtin_convertvector(f32x2{acc[j], acc[j + 1]}, f16x2);
-        f16x2 b = __builtin_convertvector(f32x2{acc[8 + j], acc[9 + j]}, f16x2);
-        if (RELU) {
-            const f16x2 zero = {(_Float16)0.0f, (_Float16)0.0f};
-            a = __builtin_elementwise_max(a, zero);
-            b = __builtin_elementwise_max(b, zero);
-        }
+        const f16x2 a = pack_pair<BF, RELU>(f32x2{acc[j], acc[j + 1]});
+        const f16x2 b = pack_pair<BF, RELU>(f32x2{acc[8 + j], acc[9 + j]});
         h0[j] = a[0]; h0[j + 1] = a[1];
         h1[j] = b[0]; h1[j + 1] = b[1];
     }
@@ -413,7 +449,8 @@ __device__ __forceinline__ float tile_dot_relu(const f32x16& acc, const float* _
     return s;
 }
 
-template <int NREG, int NKS>
+// (BF: bf16 patterns in h, l unused -- the bf16 mode is single-product)
+template <int NREG, int NKS, bool BF = false>
 __device__ __forceinline__ void split_encoding(const float (&pe)[NREG], f16x8 (&h)[NKS], f16x8 (&l)[NKS]) {
     static_assert(NREG == NKS * 8, "8 encoding registers per k-step");
 #pragma unroll
@@ -421,9 +458,9 @@ __device__ __forceinline__ void split_encoding(const float (&pe)[NREG], f16x8 (&
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float v = pe[8 * ks + j];
-            const _Float16 hi = (_Float16)v;
+            const _Float16 hi = pack_one<BF>(v);
             h[ks][j] = hi;
-            l[ks][j] = (_Float16)(v - (float)hi);
+            l[ks][j] = BF ? (_Float16)0.0f : (_Float16)(v - (float)hi);
         }
 }
 

@@ -26,7 +26,8 @@
 
 namespace snerf {
 int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, int products, hipStream_t stream);  // mlp_forward_f16.hip
-int mlp_forward_m16(const MlpPlan& plan, const MlpArgs& m, int products, hipStream_t stream);  // mlp_forward_m16.hip; -1 = layout not built there
+int mlp_forward_m16(const MlpPlan& plan, const MlpArgs& m, int products, hipStream_t stream, bool bf16);  // mlp_forward_m16.hip; -1 = layout not built there
+int mlp_forward_bf16(const MlpPlan& plan, const MlpArgs& m, bool train, hipStream_t stream);              // mlp_forward_bf16.hip
 }
 
 namespace {
@@ -216,8 +217,10 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     SNERF_REQUIRE(!plan.view_dependent || view_dirs, "mlp_forward: this MLP needs view_dirs");
     SNERF_REQUIRE(num_rays >= 0 && num_samples >= 1, "mlp_forward: bad sizes n=%lld S=%d", num_rays, num_samples);
     SNERF_REQUIRE(!train || saved_acts, "mlp_forward_train: saved_acts is NULL");
-    if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3 && precision != SNERF_PRECISION_F16)
+    if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3 && precision != SNERF_PRECISION_F16 &&
+        precision != SNERF_PRECISION_BF16)
         return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: precision %d not built", precision);
+    const bool bf16 = precision == SNERF_PRECISION_BF16;
     if (vis.wanted()) {
         SNERF_REQUIRE(desc->predict_visibility, "mlp_forward_visibility: the descriptor has predict_visibility = 0");
         SNERF_REQUIRE(vis.num_other >= 0 && vis.num_other <= 64, "mlp_forward_visibility: %d secondary views", vis.num_other);
@@ -232,7 +235,7 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     MlpArgs a;
     a.range_flag = nullptr;
     a.weight_range = nullptr;
-    if (precision != SNERF_PRECISION_FP32) {    // fp16 modes: report an earlier launch's range violation, then arm the watch
+    if (precision != SNERF_PRECISION_FP32 && !bf16) {    // fp16 modes: report an earlier launch's range violation, then arm the watch
         const int range = snerf::report_range(train ? "mlp_forward_train" : "mlp_forward");
         if (range != SNERF_OK) return range;
         a.range_flag = snerf::range_flag();
@@ -255,14 +258,14 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
         // rendering with the fp16 modes: the 16x16x32 MFMA layout where it is built (more work per joule)
         // (A/B probes build with -DSNERF_PROBE_NO_M16; no run-time switch decides which kernel renders)
 #ifndef SNERF_PROBE_NO_M16
-        const int st16 = snerf::mlp_forward_m16(plan, a, precision == SNERF_PRECISION_F16X3 ? 3 : 1, s);
+        const int st16 = snerf::mlp_forward_m16(plan, a, precision == SNERF_PRECISION_F16X3 ? 3 : 1, s, bf16);
         if (st16 != -1) return st16;
 #endif
     }
     if (precision == SNERF_PRECISION_F16X3) return snerf::mlp_forward_f16x3(plan, a, train, 3, s);
-    if (precision == SNERF_PRECISION_F16) {
+    if (precision == SNERF_PRECISION_F16 || bf16) {
         a.act_rows = plan.act16_rows();  // 16-bit pieces: same row numbers, rows of 64 bytes (mlp_plan.h)
-        return snerf::mlp_forward_f16x3(plan, a, train, 1, s);
+        return bf16 ? snerf::mlp_forward_bf16(plan, a, train, s) : snerf::mlp_forward_f16x3(plan, a, train, 1, s);
     }
     const int key = plan.wt * 100 + plan.vt * 10 + (plan.sigma_pe ? 1 : 0);
     if (vis.wanted()) {

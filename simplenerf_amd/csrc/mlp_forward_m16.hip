@@ -45,7 +45,7 @@ struct M16Args {
 typedef f32x4 Tile16[2][2];   // [row half][sample half]
 
 __device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    return mfma_16x16x32<false>(a, b, c);
 }
 
 // acc += W[tile rows, NB k-blocks] . X; `p` walks the unit's fragments (lane offset applied); fragment 2c + r.
@@ -86,7 +86,7 @@ __device__ __forceinline__ void lds_pair_landed(f16x8& a, f16x8& b, int newer) {
     else if (newer == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b)::"memory");
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
 }
-template <int NB, typename Stream>
+template <int NB, typename Stream, bool BF>
 __device__ __forceinline__ void seg1_m16(Tile16& t, const float*& p, const f16x8 (&bh)[NB][2], Stream& st) {
     const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
     f16x8 a[3][2];   // k-blocks c, c+1, c+2 in rotation
@@ -104,18 +104,18 @@ __device__ __forceinline__ void seg1_m16(Tile16& t, const float*& p, const f16x8
         lds_pair_landed(a[c % 3][0], a[c % 3][1], newer);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            t[r][0] = mfma16(a[c % 3][r], bh[c][0], t[r][0]);
-            t[r][1] = mfma16(a[c % 3][r], bh[c][1], t[r][1]);
+            t[r][0] = mfma_16x16x32<BF>(a[c % 3][r], bh[c][0], t[r][0]);
+            t[r][1] = mfma_16x16x32<BF>(a[c % 3][r], bh[c][1], t[r][1]);
         }
         if (((2 * c) & (Stream::kWaves - 1)) == 0) st.fetch_piece();
     }
     p += 2 * NB * 256;
 }
-template <int P, int NB, typename Stream>
+template <int P, int NB, bool BF, typename Stream>
 __device__ __forceinline__ void seg_m16(Tile16& t, const float*& p, int unit_ks, const f16x8 (&bh)[NB][2], const f16x8 (&bl)[NB][2],
                                         Stream& st) {
     if constexpr (P == 3) seg3_m16<NB>(t, p, unit_ks, bh, bl, st);
-    else seg1_m16<NB>(t, p, bh, st);
+    else seg1_m16<NB, Stream, BF>(t, p, bh, st);
 }
 
 // rows 32u + 16r + 4g .. +3 of a per-feature vector (bias, head weights) for this lane's group g
@@ -142,7 +142,7 @@ __device__ __forceinline__ void tile_dot_relu16(const Tile16& t, const float* __
     asm volatile("" : "+v"(sum[0]), "+v"(sum[1]));
 }
 // finished out tile -> the operand fragments of k-block (= tile index) of the next layer, per sample half
-template <bool RELU, int P>
+template <bool RELU, int P, bool BF>
 __device__ __forceinline__ void tile_to_operand16(const Tile16& t, f16x8 (&h)[2], f16x8 (&l)[2]) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -152,11 +152,8 @@ __device__ __forceinline__ void tile_to_operand16(const Tile16& t, f16x8 (&h)[2]
             for (int q = 0; q < 4; q += 2) {
                 f32x2 a = {t[r][s][q], t[r][s][q + 1]};
                 if (RELU && P == 3) a = {fmaxf(a[0], 0.0f), fmaxf(a[1], 0.0f)};
-                f16x2 ah = __builtin_convertvector(a, f16x2);
-                if (RELU && P == 1) {   // relu(fp16(v)) == fp16(relu(v)): one packed maximum per pair
-                    const f16x2 zero = {(_Float16)0.0f, (_Float16)0.0f};
-                    ah = __builtin_elementwise_max(ah, zero);
-                }
+                // (P = 1, fp16: relu(fp16(v)) == fp16(relu(v)), one packed maximum per pair -- pack_pair)
+                const f16x2 ah = P == 1 ? pack_pair<BF, RELU>(a) : __builtin_convertvector(a, f16x2);
                 h[s][4 * r + q] = ah[0]; h[s][4 * r + q + 1] = ah[1];
                 if constexpr (P == 3) {
                     const f16x2 al = __builtin_convertvector(a - __builtin_convertvector(ah, f32x2), f16x2);
@@ -165,8 +162,9 @@ __device__ __forceinline__ void tile_to_operand16(const Tile16& t, f16x8 (&h)[2]
             }
 }
 
-template <int P, int DEPTH>
+template <int P, int DEPTH, bool BF = false>
 __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forward_m16_kernel(M16Args args) {
+    static_assert(!BF || P == 1, "bf16 operands: single-product kernels only");
     constexpr int NW = P == 1 ? 8 : 4, WT = 8, VT = 4, HB = WT;   // HB = k-blocks of a full-width activation
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const MlpArgs& a = args.m;
@@ -185,7 +183,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         const int v = idx - trunk_units;
         return v < WT ? 2 * HB : (v < WT + VT ? kViewsKs : 0);
     };
-    UnitStreamT<P, NW> st;
+    UnitStreamT<P, NW, kUnitBuffers, BF ? 256 : 512> st;
     st.start(a.packed + args.stream_offset, lds, ks_of(0), ks_of(1), lane, wave, args.slot_floats);
     int unit_idx = 0;
     auto next_unit = [&]() {
@@ -229,7 +227,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float val = pe[8 * ks + j];
-                    const _Float16 hi = (_Float16)val;
+                    const _Float16 hi = pack_one<BF>(val);
                     scratch[place(ks >> 1, ks, j)] = low ? (_Float16)(val - (float)hi) : hi;
                 }
 #pragma unroll
@@ -237,7 +235,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float val = pev[8 * ks + j];
-                    const _Float16 hi = (_Float16)val;
+                    const _Float16 hi = pack_one<BF>(val);
                     scratch[place(2, ks, j)] = low ? (_Float16)(val - (float)hi) : hi;
                 }
         };
@@ -275,18 +273,20 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
     Tile16 acc[WT];
     float head[2] = {0.0f, 0.0f};
     RangeWatch watch;   // one pre-activation per layer for each of this lane's two samples (mlp_device_f16.h)
-    auto probe_tile = [&](const Tile16& t) __attribute__((always_inline)) { watch.probe(t[0][0][0]); watch.probe(t[0][1][0]); };
+    auto probe_tile = [&](const Tile16& t) __attribute__((always_inline)) {
+        if constexpr (!BF) { watch.probe(t[0][0][0]); watch.probe(t[0][1][0]); }      // (bf16 has fp32's range: nothing to watch)
+    };
 
     // ---- trunk layer 0: encoding -> h ---------------------------------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < WT; ++u) {
         const float* unit = next_unit();
         tile_bias16(acc[u], bias + 32 * u, grp);
-        seg_m16<P, 2>(acc[u], unit, 4, pe_h, pe_l, st);
+        seg_m16<P, 2, BF>(acc[u], unit, 4, pe_h, pe_l, st);
         if (u == 0) probe_tile(acc[0]);           // non-finite iff an encoded input left the fp16 range
     }
 #pragma unroll
-    for (int u = 0; u < WT; ++u) tile_to_operand16<true, P>(acc[u], xh[u], xl[u]);
+    for (int u = 0; u < WT; ++u) tile_to_operand16<true, P, BF>(acc[u], xh[u], xl[u]);
 
     // ---- trunk layers 1 .. DEPTH-1 ---------------------------------------------------------------------------------------
     auto trunk_layer = [&](int l) __attribute__((always_inline)) {
@@ -296,13 +296,13 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
             const float* unit = next_unit();
             tile_bias16(acc[u], bl + 32 * u, grp);
             const int unit_ks = l == 5 ? 4 + 2 * HB : 2 * HB;
-            if (l == 5) seg_m16<P, 2>(acc[u], unit, unit_ks, pe_h, pe_l, st);   // skip connection [encoding | h]
-            seg_m16<P, HB>(acc[u], unit, unit_ks, xh, xl, st);
+            if (l == 5) seg_m16<P, 2, BF>(acc[u], unit, unit_ks, pe_h, pe_l, st);   // skip connection [encoding | h]
+            seg_m16<P, HB, BF>(acc[u], unit, unit_ks, xh, xl, st);
             if (u == 0) probe_tile(acc[0]);       // non-finite iff an activation of layer l-1 left the fp16 range
             if (l == DEPTH - 1) tile_dot_relu16(acc[u], wout + 32 * u, grp, head);
         }
 #pragma unroll
-        for (int u = 0; u < WT; ++u) tile_to_operand16<true, P>(acc[u], xh[u], xl[u]);
+        for (int u = 0; u < WT; ++u) tile_to_operand16<true, P, BF>(acc[u], xh[u], xl[u]);
     };
     static_for<1, DEPTH>([&](auto layer) __attribute__((always_inline)) { trunk_layer(decltype(layer)::value); });
 
@@ -312,11 +312,11 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
     for (int u = 0; u < WT; ++u) {
         const float* unit = next_unit();
         tile_bias16(acc[u], bf + 32 * u, grp);
-        seg_m16<P, HB>(acc[u], unit, 2 * HB, xh, xl, st);
+        seg_m16<P, HB, BF>(acc[u], unit, 2 * HB, xh, xl, st);
         if (u == 0) probe_tile(acc[0]);
     }
 #pragma unroll
-    for (int u = 0; u < WT; ++u) tile_to_operand16<false, P>(acc[u], xh[u], xl[u]);
+    for (int u = 0; u < WT; ++u) tile_to_operand16<false, P, BF>(acc[u], xh[u], xl[u]);
     // ---- views layer over [feature | view encoding], then the colour head ----------------------------------------------------
     const float* bv = consts + (a.views_bias - a.bias_offset);
     const float* wv = consts + (a.views_out_w - a.bias_offset);
@@ -326,14 +326,14 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
     for (int u = 0; u < VT; ++u) {
         const float* unit = next_unit();
         tile_bias16(acc[u], bv + 32 * u, grp);
-        seg_m16<P, HB>(acc[u], unit, kViewsKs, xh, xl, st);
-        seg_m16<P, 1>(acc[u], unit, kViewsKs, pev_h, pev_l, st);
+        seg_m16<P, HB, BF>(acc[u], unit, kViewsKs, xh, xl, st);
+        seg_m16<P, 1, BF>(acc[u], unit, kViewsKs, pev_h, pev_l, st);
         if (u == 0) probe_tile(acc[0]);           // the feature vector and the view encoding
 #pragma unroll
         for (int c = 0; c < 3; ++c) tile_dot_relu16(acc[u], wv + c * VT * 32 + 32 * u, grp, col[c]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a wave never ends with LDS-DMA in flight)
-    watch.report(a.range_flag, a.weight_range);
+    if constexpr (!BF) watch.report(a.range_flag, a.weight_range);
     SNERF_STAMP_END(forward_m16);
 
     // ---- outputs: the four lane groups hold partial sums over their rows ----------------------------------------------------
@@ -364,14 +364,14 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
     }
 }
 
-template <int P>
+template <int P, bool BF = false>
 int launch_m16(const M16Args& args, hipStream_t stream) {
     constexpr int NW = P == 1 ? 8 : 4;
     const long long blocks = (args.m.total + NW * 32 - 1) / (NW * 32);
     if (blocks > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: too many samples in one call");
     const size_t lds_bytes = sizeof(float) * (kUnitBuffers * (size_t)args.slot_floats + NW * 256 + (size_t)args.const_floats +
                                               (P == 1 ? NW * 6 * 256 : 0));
-    auto kernel = mlp_forward_m16_kernel<P, 8>;
+    auto kernel = mlp_forward_m16_kernel<P, 8, BF>;
     static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
     const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 2048 + 5120)), "mlp_forward");   // (P = 1: 72 + 8 + 20 + 48 KiB)
     if (attr != SNERF_OK) return attr;
@@ -384,11 +384,12 @@ int launch_m16(const M16Args& args, hipStream_t stream) {
 namespace snerf {
 
 // Inference with the fp16 modes for the layout this file builds; -1 = the caller uses mlp_forward_f16.hip.
-int mlp_forward_m16(const MlpPlan& plan, const MlpArgs& m, int products, hipStream_t stream) {
+// `bf16`: the single-product kernel on bf16 operands (SNERF_PRECISION_BF16), reading the compact bf16 copy of the stream.
+int mlp_forward_m16(const MlpPlan& plan, const MlpArgs& m, int products, hipStream_t stream, bool bf16) {
     if (!plan.view_dependent || plan.sigma_pe || plan.depth != 8 || plan.wt != 8 || plan.vt != 4 || plan.views_out_rows != 3) return -1;
     M16Args args;
     args.m = m;
-    args.stream_offset = plan.m16_offset;
+    args.stream_offset = bf16 ? plan.bf_m16_offset : plan.m16_offset;
     args.const_floats = (int)((plan.dgrad_offset - plan.bias_offset + 3) / 4 * 4);
     if (args.const_floats > 5120) return -1;
     int most_ks = 0;
@@ -396,6 +397,7 @@ int mlp_forward_m16(const MlpPlan& plan, const MlpArgs& m, int products, hipStre
     if (most_ks * 512 > kUnitBufFloats) return -1;
     // P = 3: the encodings' scratch (4 waves x 6 KiB) borrows the third ring slot (44 KiB)
     args.slot_floats = products == 3 ? kUnitBufFloats : (most_ks + 7) / 8 * 8 * 256;
+    if (bf16) return launch_m16<1, true>(args, stream);
     return products == 3 ? launch_m16<3>(args, stream) : launch_m16<1>(args, stream);
 }
 

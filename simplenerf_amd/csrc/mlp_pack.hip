@@ -78,6 +78,10 @@ __device__ __forceinline__ void out_store(_Float16* out, long long unit, int uni
     out[base] = hi;
     out[base + unit_ks * 512] = lo;
 }
+// compact bf16 unit (HalfStage::bf16): [ks][64 lanes x 8 bf16], one KiB per k-step, nothing else
+__device__ __forceinline__ void out_store_bf16(_Float16* out, long long unit, int unit_ks, int ks, int lane, int j, float v) {
+    out[unit * unit_ks * 512 + ks * 512 + lane * 8 + j] = __builtin_bit_cast(_Float16, (__bf16)v);
+}
 
 __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, float* __restrict__ packed) {
     const snerf::MlpPlan::HalfStage& st = table.stage[blockIdx.y];
@@ -119,6 +123,7 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
             const int out = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
             float tv = 0.0f;
             if (out < sg.out_dim && row < sg.feat_hi) tv = w[(long long)out * sg.ld + sg.col_offset + row];
+            if (st.bf16) { out_store_bf16(dst16, u, unit_ks, ks_unit, lane, slot, tv); continue; }
             const _Float16 thi = (_Float16)tv;
             out_store(dst16, u, unit_ks, ks_unit, lane, slot, thi, (_Float16)(tv - (float)thi));
             if (!(fabsf(tv) <= 65504.0f)) __hip_atomic_fetch_or(table.weight_range, snerf::kRangeWeight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -136,6 +141,7 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
         }
         float v = 0.0f;
         if (row < sg.out_dim && col >= 0 && col < sg.ld) v = w[(long long)row * sg.ld + col];
+        if (st.bf16) { out_store_bf16(dst16, u, unit_ks, ks_unit, lane, slot, v); continue; }     // (bf16 has fp32's range)
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         out_store(dst16, u, unit_ks, ks_unit, lane, slot, hi, lo);
@@ -205,11 +211,12 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
             n = 0;
             most = 0;
         };
-        for (const std::vector<snerf::MlpPlan::HalfStage>* list : {&plan.half_stages, &plan.half_dgrad_stages, &plan.m16_stages}) {
+        for (const std::vector<snerf::MlpPlan::HalfStage>* list : {&plan.half_stages, &plan.half_dgrad_stages, &plan.m16_stages,
+                                                                   &plan.bf_stages, &plan.bf_dgrad_stages, &plan.bf_m16_stages}) {
             for (const snerf::MlpPlan::HalfStage& st : *list) {
                 for (int k = 0; k < 3; ++k) table.w[n][k] = params[st.seg[k < st.nseg ? k : 0].param];
                 table.stage[n] = st;
-                table.m16[n] = list == &plan.m16_stages ? 1 : 0;
+                table.m16[n] = (list == &plan.m16_stages || list == &plan.bf_m16_stages) ? 1 : 0;
                 most = std::max(most, (long long)st.tiles * (st.unit_floats / 512) * 512);
                 if (++n == kStagesPerLaunch) flush();
             }

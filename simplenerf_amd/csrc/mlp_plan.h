@@ -40,6 +40,8 @@ struct MlpPlan {
         HalfSegment seg[3];
         long long dst;               // offset (floats) of the stage's first unit
         int unit_floats;             // 512 floats (2 KiB: hi + lo fragment) per k-step
+        int bf16;                    // 1: a unit of the compact bf16 streams -- ONE KiB per k-step (bf16(w), no lo fragment),
+                                     //    unit_floats / 2 floats in memory
     };
     std::vector<HalfStage> half_stages;
     long long half_offset = 0;       // start of the f16x3 stream inside the packed buffer
@@ -49,6 +51,10 @@ struct MlpPlan {
     // units and sizes, fragment f = 2c + r of a unit = rows 16r .. 16r+15 of the out tile x the 32 inputs of k-block c.
     std::vector<HalfStage> m16_stages;
     long long m16_offset = 0;
+    // SNERF_PRECISION_BF16: the three half streams once more with bf16 weights, compact (hi only): forward units, W^T units of
+    // the backward chain, and the 16x16x32 fragment order for inference (same condition as m16_stages).
+    std::vector<HalfStage> bf_stages, bf_dgrad_stages, bf_m16_stages;
+    long long bf_offset = 0, bf_dgrad_offset = 0, bf_m16_offset = 0;
     long long total_floats = 0;
     long long weight_range_word = 0;      // float offset of the buffer's fp16 weight-range word (see build_plan)
 
@@ -199,7 +205,7 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
         long long hoff = off;
         auto stage = [&](int tiles, std::initializer_list<MlpPlan::HalfSegment> segs) {
             MlpPlan::HalfStage st;
-            st.tiles = tiles; st.nseg = 0; st.dst = hoff;
+            st.tiles = tiles; st.nseg = 0; st.dst = hoff; st.bf16 = 0;
             int ks = 0;
             for (const auto& sg : segs) { st.seg[st.nseg++] = sg; ks += sg.ksteps; }
             st.unit_floats = ks * 512;
@@ -234,7 +240,7 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
         plan.half_dgrad_offset = hoff;
         auto tstage = [&](int param, int ld, int out_dim, int ksteps, int col_offset) {
             MlpPlan::HalfStage st;
-            st.tiles = plan.wt; st.nseg = 1; st.dst = hoff;
+            st.tiles = plan.wt; st.nseg = 1; st.dst = hoff; st.bf16 = 0;
             st.seg[0] = MlpPlan::HalfSegment{param, ld, out_dim, SEG_ACC, ksteps, col_offset, 0, plan.width, 0, 1};
             st.unit_floats = ksteps * 512;
             hoff += (long long)st.tiles * st.unit_floats;
@@ -264,6 +270,22 @@ inline int build_plan(const snerf_mlp_desc* d, MlpPlan* p) {
             }
             hoff += 24 * 512;  // prefetch runway
         }
+        // the bf16 copies (compact: unit_floats / 2 per unit)
+        auto compact = [&](const std::vector<MlpPlan::HalfStage>& from, std::vector<MlpPlan::HalfStage>& to) {
+            const long long first = hoff;
+            for (MlpPlan::HalfStage st : from) {
+                st.dst = hoff;
+                st.bf16 = 1;
+                hoff += (long long)st.tiles * (st.unit_floats / 2);
+                to.push_back(st);
+            }
+            hoff += 24 * 256;  // prefetch runway
+            return first;
+        };
+        plan.bf_offset = compact(plan.half_stages, plan.bf_stages);
+        plan.bf_dgrad_offset = compact(plan.half_dgrad_stages, plan.bf_dgrad_stages);
+        plan.bf_m16_offset = hoff;
+        if (m16_layout) plan.bf_m16_offset = compact(plan.m16_stages, plan.bf_m16_stages);
         off = hoff;
     }
     // one reserved block behind the streams: word 0 is OR-ed with kRangeWeight by snerf_mlp_pack when a weight of THIS buffer

@@ -177,15 +177,13 @@ def allreduce_gradients(parameters, world_size: int, group=None, force: bool = F
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(world_size)
-    offset = 0
-    for p in params:
-        n = p.numel()
-        piece = flat[offset:offset + n].view_as(p)
+    pieces = [piece.view_as(p) for piece, p in zip(flat.split([p.numel() for p in params]), params)]
+    held = [(p, piece) for p, piece in zip(params, pieces) if p.grad is not None]
+    if held:     # one multi-tensor copy back into the gradient buffers (their addresses stay: they may be a graph's static ones)
+        torch._foreach_copy_([p.grad for p, _ in held], [piece for _, piece in held])
+    for p, piece in zip(params, pieces):
         if p.grad is None:
             p.grad = piece.clone()
-        else:
-            p.grad.copy_(piece)
-        offset += n
 
 
 def train_one_iter(model, loss_computer, optimizer, input_batch: dict, sub_batch_size: Optional[int] = None,
@@ -377,7 +375,7 @@ class GraphedTrainStep:
         self.graph.replay()
         # a replay bypasses the entry points that report an fp16 range violation of an earlier launch: ask here (a host read
         # of a pinned word, no synchronisation -- like the entry points it sees launches that have finished)
-        if self.model.precision != ops.PRECISION_FP32 and ops.range_status(clear=True):
+        if self.model.precision in ops.FP16_RANGE_PRECISIONS and ops.range_status(clear=True):
             raise ops.Fp16RangeError("GraphedTrainStep: an earlier replay met a value outside the fp16 range (|v| > 65504); its "
                                      "gradients are invalid -- use hip_precision 'fp32' for this model")
         return self.totals
@@ -396,14 +394,24 @@ class GraphedIteration:
     ``train_one_iter`` iterations (tests/test_gpu_optim.py).
 
     A short batch at the end of an epoch (other tensor shapes) runs eagerly into the graph's static gradient buffers, as
-    ``GraphedTrainStep`` does; the graph is re-captured when ``LossComputer.get_loss_weight`` changes the loss weights.  Single
-    process (the gradient all-reduce of a multi-rank run is not captured).  The host may run at most ``slots - 1`` replays ahead
-    of the device: the slot about to be overwritten is guarded by an event."""
+    ``GraphedTrainStep`` does; the graph is re-captured when ``LossComputer.get_loss_weight`` changes the loss weights.  The host
+    may run at most ``slots - 1`` replays ahead of the device: the slot about to be overwritten is guarded by an event.
+
+    Several ranks (round 4): ``batcher`` built with (rank, world_size) hands every rank its slice of the same global batch, and
+    the ONE all-reduce of the flattened gradients (``allreduce_gradients``) is captured between the last sub-batch's backward
+    and the Adam update -- RCCL collectives record into a HIP graph like kernels, so a replay still costs the host one record
+    and one launch.  It needs the ``nccl`` backend (gloo's collectives run on the host and cannot be captured);
+    ``force_collective`` captures the all-reduce with a single rank too (the test of exactly that on a one-GPU box)."""
 
     def __init__(self, model, loss_computer, optimizer, batcher, lr_decayer=None, sub_batch_size: Optional[int] = None,
-                 slots: int = 8, warmup: int = 1):
-        if getattr(batcher, 'world_size', 1) != 1:
-            raise NotImplementedError('GraphedIteration is a single-process path (use GraphedTrainStep + allreduce_gradients)')
+                 slots: int = 8, warmup: int = 1, group=None, force_collective: bool = False):
+        self.world = int(getattr(batcher, 'world_size', 1))
+        self.group, self.force_collective = group, bool(force_collective)
+        if self.world > 1 or self.force_collective:
+            import torch.distributed as dist
+            if not dist.is_initialized() or dist.get_backend(group) != 'nccl':
+                raise NotImplementedError("GraphedIteration over several ranks captures the gradient all-reduce: it needs an initialised "
+                                          "'nccl' (RCCL) process group -- with gloo use GraphedTrainStep + allreduce_gradients")
         if len(optimizer.param_groups) != 1:
             raise NotImplementedError('GraphedIteration replays ONE (step size, bias correction) record: a single parameter group')
         self.model, self.losses, self.opt, self.batcher, self.decayer = model, loss_computer, optimizer, batcher, lr_decayer
@@ -444,6 +452,7 @@ class GraphedIteration:
             self.ring.advance()
         batch = self.batcher.get_next_batch(iter_num, at=self.ring.current)
         totals = self._passes(batch, self.ring.current)
+        allreduce_gradients(self.model.parameters(), self.world, self.group, self.force_collective)
         if whole:
             self.opt.step_at(self.ring.current)
         return totals
@@ -485,6 +494,7 @@ class GraphedIteration:
                 if p.grad is not None:
                     p.grad.zero_()
             totals = self._passes(self.batcher.get_next_batch(iter_num, positions=positions), None)
+            allreduce_gradients(self.model.parameters(), self.world, self.group, self.force_collective)
             self.opt.step()
             return totals
         key = self._weights(iter_num)
@@ -505,7 +515,7 @@ class GraphedIteration:
         event.record()
         self.events[slot] = event
         self.opt.count_step()
-        if self.model.precision != ops.PRECISION_FP32 and ops.range_status(clear=True):
+        if self.model.precision in ops.FP16_RANGE_PRECISIONS and ops.range_status(clear=True):
             raise ops.Fp16RangeError("GraphedIteration: an earlier replay met a value outside the fp16 range (|v| > 65504); its "
                                      "update is invalid -- use hip_precision 'fp32' for this model")
         return self.totals

@@ -1,0 +1,213 @@
+"""The bf16 mode (SNERF_PRECISION_BF16, configs['model']['hip_precision'] = 'bf16') on a real MI355X -- BASELINE config 5's
+literal dtype: the single-product kernels of the 16-bit mode on bf16 operands (v_mfma_f32_32x32x16_bf16 /
+v_mfma_f32_16x16x32_bf16, fp32 accumulate, fp32 master weights / biases / heads / outputs), activations and layer gradients
+saved as bf16.  8 significand bits per operand (fp16: 11) and fp32's exponent range: there is NO range limit -- the case that
+makes both fp16 modes raise Fp16RangeError renders here -- at three bits less precision.  Like 'f16' it is outside
+north_star's 1e-4 / 1e-3 bar (that is what 'fp32' and 'f16x3' are for); its tolerances are stated here, each a few times what
+is observed (printed in pytest's summary):
+
+    MLP outputs vs the fp32 oracle        sigma 4e-2 relative to max, rgb 2e-3 absolute
+    parameter gradients vs autograd        40 % relative L2 per tensor on the 315-sample spiky-gradient case (flipped ReLU masks)
+    rendered colour / NDC depth vs fp32    8e-3 / 4e-2 on 2048 headline rays
+    training batch vs fp32 (9 losses)      every loss value 4e-2 relative, every accumulated parameter gradient 25 % relative L2
+    short training run                     same PSNR as the fp32 run to 1.5 dB
+
+Exact properties are tested exactly: results are bit-reproducible, the storing and the plain forward give the same bits where
+they are the same kernel, and a hidden unit of 1e5 or a weight of -7e4 renders without complaint and close to fp32."""
+import math
+
+import numpy
+import pytest
+import torch
+
+from oracle import nerf_oracle as oracle
+from simplenerf_amd import harness, ops, optim, synth
+from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
+from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
+from simplenerf_amd.lr_decayers.LearningRateDecayerFactory import get_lr_decayer
+from simplenerf_amd.models.ModelFactory import get_model
+from tests import util
+from tests.test_gpu_f16 import mlp_case, synthetic_model
+from tests.test_gpu_grads import rel_l2
+from tests.test_gpu_kernels import abi_param_list
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+BF16 = ops.PRECISIONS['bf16']
+
+
+@pytest.mark.parametrize('layout', ['main', 'ptsaug', 'viewsaug'])
+@pytest.mark.parametrize('size', [(8, 256, 128), (4, 128, 64)])
+def test_bf16_mlp_against_oracle(layout, size):
+    cfg, sd, inputs, (g_sigma, g_rgb) = mlp_case(layout, size)
+    o, dd, v, z, noise = inputs
+    params = {k: torch.from_numpy(v_).clone().requires_grad_(True) for k, v_ in sd.items()}
+    ref = oracle.run_mlp(params, '', cfg, oracle.ray_points(o, dd, z), v, None, noise)
+    ((ref['sigma'] * g_sigma).sum() + (ref['rgb'] * g_rgb).sum()).backward()
+    plist = abi_param_list({k: torch.from_numpy(v_).to(DEV) for k, v_ in sd.items()})
+    mlp = ops.PackedMlp(cfg, DEV)
+    mlp.pack(plist)
+    dev = [t.to(DEV) for t in inputs]
+    sigma_eval, rgb_eval = mlp.forward(*dev, BF16)
+    sigma, rgb, saved = mlp.forward_train(*dev, BF16)
+    m16 = layout == 'main' and size == (8, 256, 128)       # inference of this layout runs on the 16x16x32 kernel
+    if not m16:
+        assert torch.equal(sigma, sigma_eval) and torch.equal(rgb, rgb_eval)
+    e_sigma, e_rgb = util.rel_linf(sigma, ref['sigma']), util.linf(rgb, ref['rgb'])
+    e_sigma_eval, e_rgb_eval = util.rel_linf(sigma_eval, ref['sigma']), util.linf(rgb_eval, ref['rgb'])
+    assert max(e_sigma, e_sigma_eval) < 4e-2 and max(e_rgb, e_rgb_eval) < 2e-3, (e_sigma, e_rgb, e_sigma_eval, e_rgb_eval)
+    shapes = [tuple(p.shape) for p in plist]
+    grads = mlp.backward(saved, sigma, rgb, g_sigma.to(DEV), g_rgb.to(DEV), shapes, BF16)
+    again = mlp.backward(saved, sigma, rgb, g_sigma.to(DEV), g_rgb.to(DEV), shapes, BF16)
+    names = [k for k in abi_param_list({k: k for k in sd})]
+    worst = 0.0
+    for name, got, twice in zip(names, grads, again):
+        assert torch.equal(got, twice), name                          # fixed-order reductions
+        assert got.shape == params[name].grad.shape and torch.isfinite(got).all()
+        worst = max(worst, rel_l2(got, params[name].grad))
+    util.observe(f'bf16/mlp/{layout}/{size[0]}x{size[1]}', f'sigma rel {max(e_sigma, e_sigma_eval):.1e} [4e-2], rgb {max(e_rgb, e_rgb_eval):.1e} '
+                 f'[2e-3], worst gradient rel L2 {worst:.3f} [0.40]')
+    assert worst < 0.40, worst
+
+
+def test_bf16_backward_is_linear_in_the_loss_scale():
+    """The chain renormalises per sample by powers of two and the bf16 weight-gradient products take dY as stored: scaling
+    the upstream gradient by 2^-30 scales every parameter gradient by exactly 2^-30."""
+    cfg, sd, inputs, (g_sigma, g_rgb) = mlp_case('main', (8, 256, 128))
+    plist = abi_param_list({k: torch.from_numpy(v_).to(DEV) for k, v_ in sd.items()})
+    mlp = ops.PackedMlp(cfg, DEV)
+    mlp.pack(plist)
+    sigma, rgb, saved = mlp.forward_train(*[t.to(DEV) for t in inputs], BF16)
+    shapes = [tuple(p.shape) for p in plist]
+    ref = mlp.backward(saved, sigma, rgb, g_sigma.to(DEV), g_rgb.to(DEV), shapes, BF16)
+    k = 2.0 ** -30
+    small = mlp.backward(saved, sigma, rgb, (g_sigma * k).to(DEV), (g_rgb * k).to(DEV), shapes, BF16)
+    for a, b in zip(ref, small):
+        assert torch.equal(a * k, b)
+
+
+def test_bf16_render_close_to_fp32():
+    cfg = synth.make_configs('headline')
+    cam = synth.camera('fern', 0)
+    batch = harness.frame_batch(cam, True, DEV, 95000, 2048)
+    with torch.no_grad():
+        ref = synthetic_model(cfg, 'fp32').eval()(batch)
+        got = synthetic_model(cfg, 'bf16').eval()(batch)
+        again = synthetic_model(cfg, 'bf16').eval()(batch)
+    assert all(torch.equal(got[k], again[k]) for k in got)
+    worst = {k: util.linf(got[k], ref[k]) for k in ('rgb_coarse', 'rgb_fine', 'depth_ndc_coarse', 'depth_ndc_fine')}
+    util.observe('bf16/render', ', '.join(f'{k} {v:.1e}' for k, v in worst.items()) + ' [rgb 8e-3, NDC depth 4e-2]')
+    assert worst['rgb_coarse'] < 8e-3 and worst['rgb_fine'] < 8e-3
+    assert worst['depth_ndc_coarse'] < 4e-2 and worst['depth_ndc_fine'] < 4e-2      # NDC depth range is [0, 1]
+
+
+def test_bf16_training_batch_close_to_fp32():
+    """One reference-shaped training batch (four MLPs, nine losses) against the fp32 path, bit-reproducible."""
+    def run(precision):
+        cfg = synth.training_configs(precision, num_rays=1024, num_sparse=256)
+        cfg['sub_batch_size'] = 1280
+        cfg['losses'] = synth.loss_configs(iter_weighted=False)
+        model = synthetic_model(cfg, precision).train()
+        batch = BatchAssembler(cfg, synth.training_scene(0, 3, 96, 128, sparse_fraction=0.02), DEV).get_next_batch(0)
+        losses = LossComputer(cfg)
+        out = model(batch)
+        terms = losses.compute_losses(batch, out)
+        terms['TotalLoss'].backward()
+        values = {k: float((v['loss_value'] if isinstance(v, dict) else v).detach()) for k, v in terms.items()}
+        return values, {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    ref_loss, ref_grads = run('fp32')
+    got_loss, got_grads = run('bf16')
+    again_loss, again_grads = run('bf16')
+    assert got_loss == again_loss and all(torch.equal(got_grads[k], again_grads[k]) for k in got_grads)
+    worst_loss = max(abs(got_loss[k] - v) / max(abs(v), 1e-6) for k, v in ref_loss.items())
+    worst_grad = max(rel_l2(got_grads[k], ref_grads[k]) for k in ref_grads)
+    util.observe('bf16/training_batch', f'worst loss value rel {worst_loss:.1e} [4e-2], worst gradient rel L2 {worst_grad:.3f} [0.25]')
+    assert worst_loss <= 4e-2 and worst_grad <= 0.25
+
+
+def test_bf16_has_no_range_limit():
+    """What makes both fp16 modes raise Fp16RangeError (tests/test_gpu_f16.py): a hidden unit driven to 1e5 and a weight of
+    -7e4.  bf16 carries fp32's exponent: the model renders, eval and training, finite and close to the fp32 mode, and the
+    range flag stays clear."""
+    cam = synth.camera('fern', 0)
+    batch = harness.frame_batch(cam, True, DEV, 200000, 64)
+
+    def make(precision):
+        cfg = synth.with_overrides(synth.make_configs('config2'), hip_precision=precision)
+        model = get_model(cfg, None)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
+        model = model.to(DEV)
+        with torch.no_grad():
+            model.coarse_model.pts_linears[2].bias[17] = 1.0e5
+            model.coarse_model.pts_linears[3].weight[5, 9] = -7.0e4
+        return model
+
+    ops.range_status(clear=True)
+    ref_model, model = make('fp32'), make('bf16')
+    for training in (False, True):
+        with torch.no_grad():
+            ref = ref_model.train(training)(batch)
+        got = model.train(training)(batch)          # (training: with autograd on, the storing forward)
+        torch.cuda.synchronize()
+        assert ops.range_status() == 0
+        assert all(torch.isfinite(v).all() for v in got.values())
+        # one unit of 1e5 dominates its layer: relative agreement of the pre-activation magnitudes is what bf16 gives
+        assert util.linf(got['rgb_coarse'], ref['rgb_coarse']) < 5e-2, util.linf(got['rgb_coarse'], ref['rgb_coarse'])
+
+
+def test_bf16_training_run_tracks_fp32():
+    """150 iterations of the whole training step on the synthetic plane scene in both precisions: same convergence."""
+    def run(precision):
+        cfg = synth.training_configs(precision, num_rays=1024, num_sparse=256)
+        cfg['sub_batch_size'] = 1280
+        cfg['losses'] = synth.loss_configs(iter_weighted=False)
+        scene = synth.training_scene(0, 3, 96, 128, sparse_fraction=0.02)
+        torch.manual_seed(0)
+        model = get_model(cfg, None).to(DEV).train()
+        batcher, losses = BatchAssembler(cfg, scene, DEV), LossComputer(cfg)
+        opt = optim.Adam(list(model.parameters()), lr=cfg['optimizer']['lr_initial'], betas=(0.9, 0.999))
+        decayer = get_lr_decayer(cfg)
+        for it in range(150):
+            for group in opt.param_groups:
+                group['lr'] = decayer.get_updated_learning_rate(it)
+            totals = harness.train_one_iter(model, losses, opt, batcher.get_next_batch(it), cfg['sub_batch_size'])
+        assert math.isfinite(float(totals['TotalLoss']))
+        cam = {'resolution': scene['resolution'], 'intrinsic': scene['intrinsics'][0], 'pose': scene['poses'][0],
+               'near': scene['near'], 'far': scene['far'], 'near_ndc': 0.0, 'far_ndc': 1.0}
+        model.eval()
+        rgb = harness.render_frame(model, cam, True, torch.device(DEV), keys=('rgb_fine',))['rgb_fine']
+        target = torch.as_tensor(scene['images'][0]).reshape(-1, 3).to(DEV)
+        return -10 * math.log10(max(float(torch.mean((rgb - target) ** 2)), 1e-12))
+
+    ref, got = run('fp32'), run('bf16')
+    util.observe('bf16/training_run', f'PSNR after 150 iterations: fp32 {ref:.2f} dB, bf16 {got:.2f} dB [within 1.5 dB]')
+    assert ref > 10.0 and abs(got - ref) < 1.5, (ref, got)
+
+
+def test_graphed_whole_iteration_in_bf16_equals_the_eager_iteration():
+    """harness.GraphedIteration in the bf16 mode: six replays, every parameter bit-identical to the eager trainer iteration."""
+    cfg = synth.training_configs('bf16', num_rays=192, num_sparse=64)
+    cfg['sub_batch_size'] = 128
+    cfg['losses'] = synth.loss_configs(iter_weighted=False)
+    scene = synth.training_scene(0, 3, 48, 64, sparse_fraction=0.5)
+    models = []
+    for _ in range(2):
+        m = get_model(cfg, None)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 9, 200.0, 8.0).items()})
+        models.append(m.to(DEV).train())
+    eager, graphed = models
+    batch_e, batch_g = BatchAssembler(cfg, scene, DEV), BatchAssembler(cfg, scene, DEV)
+    losses, decayer = LossComputer(cfg), get_lr_decayer(cfg)
+    opt_e, opt_g = optim.Adam(list(eager.parameters()), lr=5e-4), optim.Adam(list(graphed.parameters()), lr=5e-4)
+    step = harness.GraphedIteration(graphed, losses, opt_g, batch_g, decayer, sub_batch_size=128, slots=4)
+    for it in range(20000, 20006):
+        for group in opt_e.param_groups:
+            group['lr'] = decayer.get_updated_learning_rate(it)
+        ref = harness.train_one_iter(eager, losses, opt_e, batch_e.get_next_batch(it), 128)
+        got = step(it)
+        assert float(got['TotalLoss']) == float(ref['TotalLoss']), it
+    for (name, a), b in zip(eager.named_parameters(), graphed.parameters()):
+        assert torch.equal(a, b), name

@@ -57,6 +57,9 @@ def main():
                                   'hbm_bytes': hbm, 'mfma_busy_fraction': busy,
                                   'GRBM_GUI_ACTIVE': mean('GRBM_GUI_ACTIVE', g), 'SQ_BUSY_CYCLES': mean('SQ_BUSY_CYCLES', g)})
     out['mlp_forward_hbm_bytes_per_launch'] = total / len(grids)
+    import subprocess
+    head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__)))
+    out['commit'] = (sys.argv[3] if len(sys.argv) > 3 else head.stdout.strip()) or 'unrecorded'      # the tree the passes ran on
     with open(dst, 'w') as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != 'source'}, indent=1))

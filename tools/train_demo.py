@@ -3,7 +3,9 @@
 every stage on the device (BatchAssembler -> SimpleNeRFHip -> LossComputer -> optim.Adam with the NeRF decay), a few
 hundred iterations.  Prints the loss curve and the PSNR of a training view rendered before and after.
     python tools/train_demo.py [iterations]            (SNERF_PREC=f16x3 for the split-precision kernels, f16 for the 16-bit mode;
-                                                        SNERF_GRAPH=1 replays the pass from one HIP graph)"""
+                                                        SNERF_GRAPH=1 replays the pass from one HIP graph; SNERF_SEED=n: initial
+                                                        weights, epoch order and training draws of seed n)
+tools/train_seeds.py runs it over seeds x precisions and writes the spread."""
 import json
 import math
 import os
@@ -33,14 +35,14 @@ def psnr_of_view(model, scene, view):
     return -10 * math.log10(max(mse, 1e-12))
 
 
-def main():
-    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    precision = os.environ.get('SNERF_PREC', 'fp32')
-    cfg = synth.training_configs(precision, num_rays=1024, num_sparse=256)
+def run(iters=300, precision='fp32', graph=False, seed=0):
+    """-> the record ``main`` prints.  ``seed`` selects the initial weights (torch.manual_seed), the epoch order and the training
+    draws (configs['seed']); the scene is the same for every seed."""
+    cfg = synth.training_configs(precision, num_rays=1024, num_sparse=256, seed=seed)
     cfg['sub_batch_size'] = 1280
     cfg['losses'] = synth.loss_configs(iter_weighted=False)      # consistency losses on from the first iteration
     scene = synth.training_scene(0, 3, 96, 128, sparse_fraction=0.02)
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     model = get_model(cfg, None).to(DEV).train()
     batcher = BatchAssembler(cfg, scene, DEV)
     losses = LossComputer(cfg)
@@ -49,7 +51,7 @@ def main():
     before = psnr_of_view(model, scene, 0)
     curve = []
     graphed = None
-    if os.environ.get('SNERF_GRAPH') == '1':
+    if graph:
         graphed = harness.GraphedTrainStep(model, losses, batcher.get_next_batch(0), sub_batch_size=cfg['sub_batch_size'])
         batcher = BatchAssembler(cfg, scene, DEV)       # restart the index stream after the sample batch
     worst = 0.0
@@ -72,8 +74,15 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     after = psnr_of_view(model, scene, 0)
-    print(json.dumps({'precision': precision, 'graph': graphed is not None, 'iterations': iters, 'seconds': dt, 'psnr_view0_before': before,
-                      'psnr_view0_after': after, 'curve': curve}, indent=1))
+    views = [psnr_of_view(model, scene, v) for v in range(len(scene['poses']))]
+    return {'precision': precision, 'graph': graphed is not None, 'seed': seed, 'iterations': iters, 'seconds': dt,
+            'psnr_view0_before': before, 'psnr_view0_after': after, 'psnr_all_views_after': views, 'curve': curve}
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    print(json.dumps(run(iters, os.environ.get('SNERF_PREC', 'fp32'), os.environ.get('SNERF_GRAPH') == '1',
+                         int(os.environ.get('SNERF_SEED', '0'))), indent=1))
 
 
 if __name__ == '__main__':
