@@ -6,11 +6,14 @@ makes both fp16 modes raise Fp16RangeError renders here -- at three bits less pr
 north_star's 1e-4 / 1e-3 bar (that is what 'fp32' and 'f16x3' are for); its tolerances are stated here, each a few times what
 is observed (printed in pytest's summary):
 
-    MLP outputs vs the fp32 oracle        sigma 4e-2 relative to max, rgb 2e-3 absolute
-    parameter gradients vs autograd        40 % relative L2 per tensor on the 315-sample spiky-gradient case (flipped ReLU masks)
-    rendered colour / NDC depth vs fp32    8e-3 / 4e-2 on 2048 headline rays
-    training batch vs fp32 (9 losses)      every loss value 4e-2 relative, every accumulated parameter gradient 25 % relative L2
-    short training run                     same PSNR as the fp32 run to 1.5 dB
+    MLP outputs vs the fp32 oracle        sigma 2e-2 relative to max, rgb 5e-4 absolute     (observed 8.8e-3 / 1.9e-4)
+    parameter gradients vs autograd        25 % relative L2 per tensor on the 315-sample spiky-gradient case, 75 % for the
+                                           8 x 256 main MLP, where flipped ReLU masks of a handful of samples dominate
+                                           (observed 7-13 % / 53 %; the fp16 mode: 1-8 % -- bf16 rounds 8 x coarser)
+    rendered colour / NDC depth vs fp32    4e-3 / 5e-3 on 2048 headline rays                 (observed 1.3e-3 / 1.5e-3)
+    training batch vs fp32 (9 losses)      every loss value 4e-2 relative, every accumulated parameter gradient 20 %
+                                           relative L2                                      (observed 1.7e-2 / 8.3 %)
+    short training run                     same PSNR as the fp32 run to 1 dB                 (observed 0.01 dB)
 
 Exact properties are tested exactly: results are bit-reproducible, the storing and the plain forward give the same bits where
 they are the same kernel, and a hidden unit of 1e5 or a weight of -7e4 renders without complaint and close to fp32."""
@@ -55,7 +58,7 @@ def test_bf16_mlp_against_oracle(layout, size):
         assert torch.equal(sigma, sigma_eval) and torch.equal(rgb, rgb_eval)
     e_sigma, e_rgb = util.rel_linf(sigma, ref['sigma']), util.linf(rgb, ref['rgb'])
     e_sigma_eval, e_rgb_eval = util.rel_linf(sigma_eval, ref['sigma']), util.linf(rgb_eval, ref['rgb'])
-    assert max(e_sigma, e_sigma_eval) < 4e-2 and max(e_rgb, e_rgb_eval) < 2e-3, (e_sigma, e_rgb, e_sigma_eval, e_rgb_eval)
+    assert max(e_sigma, e_sigma_eval) < 2e-2 and max(e_rgb, e_rgb_eval) < 5e-4, (e_sigma, e_rgb, e_sigma_eval, e_rgb_eval)
     shapes = [tuple(p.shape) for p in plist]
     grads = mlp.backward(saved, sigma, rgb, g_sigma.to(DEV), g_rgb.to(DEV), shapes, BF16)
     again = mlp.backward(saved, sigma, rgb, g_sigma.to(DEV), g_rgb.to(DEV), shapes, BF16)
@@ -65,9 +68,10 @@ def test_bf16_mlp_against_oracle(layout, size):
         assert torch.equal(got, twice), name                          # fixed-order reductions
         assert got.shape == params[name].grad.shape and torch.isfinite(got).all()
         worst = max(worst, rel_l2(got, params[name].grad))
-    util.observe(f'bf16/mlp/{layout}/{size[0]}x{size[1]}', f'sigma rel {max(e_sigma, e_sigma_eval):.1e} [4e-2], rgb {max(e_rgb, e_rgb_eval):.1e} '
-                 f'[2e-3], worst gradient rel L2 {worst:.3f} [0.40]')
-    assert worst < 0.40, worst
+    bound = 0.75 if m16 else 0.25
+    util.observe(f'bf16/mlp/{layout}/{size[0]}x{size[1]}', f'sigma rel {max(e_sigma, e_sigma_eval):.1e} [2e-2], rgb {max(e_rgb, e_rgb_eval):.1e} '
+                 f'[5e-4], worst gradient rel L2 {worst:.3f} [{bound}]')
+    assert worst < bound, worst
 
 
 def test_bf16_backward_is_linear_in_the_loss_scale():
@@ -96,9 +100,9 @@ def test_bf16_render_close_to_fp32():
         again = synthetic_model(cfg, 'bf16').eval()(batch)
     assert all(torch.equal(got[k], again[k]) for k in got)
     worst = {k: util.linf(got[k], ref[k]) for k in ('rgb_coarse', 'rgb_fine', 'depth_ndc_coarse', 'depth_ndc_fine')}
-    util.observe('bf16/render', ', '.join(f'{k} {v:.1e}' for k, v in worst.items()) + ' [rgb 8e-3, NDC depth 4e-2]')
-    assert worst['rgb_coarse'] < 8e-3 and worst['rgb_fine'] < 8e-3
-    assert worst['depth_ndc_coarse'] < 4e-2 and worst['depth_ndc_fine'] < 4e-2      # NDC depth range is [0, 1]
+    util.observe('bf16/render', ', '.join(f'{k} {v:.1e}' for k, v in worst.items()) + ' [rgb 4e-3, NDC depth 5e-3]')
+    assert worst['rgb_coarse'] < 4e-3 and worst['rgb_fine'] < 4e-3
+    assert worst['depth_ndc_coarse'] < 5e-3 and worst['depth_ndc_fine'] < 5e-3      # NDC depth range is [0, 1]
 
 
 def test_bf16_training_batch_close_to_fp32():
@@ -122,8 +126,8 @@ def test_bf16_training_batch_close_to_fp32():
     assert got_loss == again_loss and all(torch.equal(got_grads[k], again_grads[k]) for k in got_grads)
     worst_loss = max(abs(got_loss[k] - v) / max(abs(v), 1e-6) for k, v in ref_loss.items())
     worst_grad = max(rel_l2(got_grads[k], ref_grads[k]) for k in ref_grads)
-    util.observe('bf16/training_batch', f'worst loss value rel {worst_loss:.1e} [4e-2], worst gradient rel L2 {worst_grad:.3f} [0.25]')
-    assert worst_loss <= 4e-2 and worst_grad <= 0.25
+    util.observe('bf16/training_batch', f'worst loss value rel {worst_loss:.1e} [4e-2], worst gradient rel L2 {worst_grad:.3f} [0.20]')
+    assert worst_loss <= 4e-2 and worst_grad <= 0.20
 
 
 def test_bf16_has_no_range_limit():
@@ -182,8 +186,8 @@ def test_bf16_training_run_tracks_fp32():
         return -10 * math.log10(max(float(torch.mean((rgb - target) ** 2)), 1e-12))
 
     ref, got = run('fp32'), run('bf16')
-    util.observe('bf16/training_run', f'PSNR after 150 iterations: fp32 {ref:.2f} dB, bf16 {got:.2f} dB [within 1.5 dB]')
-    assert ref > 10.0 and abs(got - ref) < 1.5, (ref, got)
+    util.observe('bf16/training_run', f'PSNR after 150 iterations: fp32 {ref:.2f} dB, bf16 {got:.2f} dB [within 1 dB]')
+    assert ref > 10.0 and abs(got - ref) < 1.0, (ref, got)
 
 
 def test_graphed_whole_iteration_in_bf16_equals_the_eager_iteration():
