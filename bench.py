@@ -185,9 +185,9 @@ def _pkg():
     return harness, ops, synth, get_model
 
 
-def synthetic_model(configs, seed, device, precision='fp32'):
+def synthetic_model(configs, seed, device, precision='fp32', fused=False):
     _, _, synth, get_model = _pkg()
-    configs = synth.with_overrides(configs, hip_precision=precision)
+    configs = synth.with_overrides(configs, hip_precision=precision, hip_fused_render=bool(fused))
     model = get_model(configs, None)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed, sigma_gain=200.0, sigma_shift=8.0).items()})
@@ -415,14 +415,15 @@ class HipRenderer:
     """The product path for one rank: the drop-in model on this rank's GPU."""
     gpu = True
 
-    def __init__(self, precision, device, rank, world, kind='headline', collective=None):
+    def __init__(self, precision, device, rank, world, kind='headline', collective=None, fused=False):
         harness, ops, synth, _ = _pkg()
         self.harness, self.ops, self.synth = harness, ops, synth
         self.precision, self.device, self.rank, self.world = precision, device, rank, world
+        self.fused = bool(fused)         # configs['model']['hip_fused_render']: the render as one launch (csrc/render_fused.hip)
         self.collective = world > 1 if collective is None else collective      # True with one rank under --force-collective
         self.gather_marks = None         # [(before, after)] per step while the gather is being timed
         self.configs = synth.with_overrides(synth.make_configs(kind), hip_precision=precision)
-        self.model = synthetic_model(synth.make_configs(kind), 7, device, precision)
+        self.model = synthetic_model(synth.make_configs(kind), 7, device, precision, fused)
         self.camera = synth.camera('fern', 0)
         h, w = self.camera['resolution']
         # rank r renders pixels [base + r*1024, base + (r+1)*1024) from the middle of the frame
@@ -846,6 +847,16 @@ def render_bench(args, rank, world, device, dist, make_renderer, data):
                            'roofline': line['roofline'], 'timing': line['timing'],
                            'board': board_state(r, line['roofline']['achieved'], PRECISION_INFO[precision][0])}
             del r
+        # the same fp32 step with the whole render as ONE launch (the ray group's sample tile stays in LDS: render_fused.hip)
+        r = HipRenderer('fp32', device, rank, world, 'headline', collective=False, fused=True)
+        a = measure_headline(r, args.steps, args.warmup, fence, 1)
+        line = headline_line(1, args.steps, args.warmup, 'fp32', a['elapsed'], a['device_ms'], a['enqueue_ms'],
+                             a['launch_ms'], a['launch_samples'], a['dropped'], a['settle_info'])
+        line['roofline']['kernel'] = 'render_fused_kernel<8,4,2,4> (K2 + K3 coarse + K4 + K5 + K3 fine + K4 in one launch)'
+        result['also_measured_fused'] = {'what': "configs['model']['hip_fused_render'] = True: bit-identical outputs (tests/test_gpu_fused.py), "
+                                                 'one launch per step instead of six', 'value': line['value'], 'unit': 'rays/s',
+                                         'ms_per_step': line['ms_per_step'], 'roofline': line['roofline'], 'timing': line['timing']}
+        del r
         progress('other precisions done')
         result['also_measured_frame'] = frame_records_single(make_renderer, fence)
         progress('frames done')

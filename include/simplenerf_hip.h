@@ -32,7 +32,7 @@ enum snerf_status {
 
 /* ABI version of this header; bumped on any signature change (new enum values such as SNERF_PRECISION_F16 extend a
  * version without changing it: older callers never pass them). */
-#define SNERF_ABI_VERSION 7
+#define SNERF_ABI_VERSION 8
 int snerf_abi_version(void);
 const char* snerf_last_error(void);
 
@@ -252,6 +252,11 @@ typedef struct snerf_render_config {
     int num_fine;         /* fine_mlp.num_samples, or 0 when the model has no fine MLP */
     int precision;        /* enum snerf_precision, for every MLP of the call */
     int keep_activations; /* != 0: training forward (snerf_mlp_forward_train); level outputs need `saved_acts` */
+    int fused;            /* != 0: an eval-mode render of a plain coarse + fine model (levels 0 and 3 only, fp32, 64+128 or
+                             128+128 samples, no noise / visibility / fine-depth override) runs as ONE launch that keeps each
+                             ray group's sample tile in LDS from the coarse depths to the fine colour (csrc/render_fused.hip);
+                             bit-identical outputs; `sigma` / `raw_rgb` of the two levels may then be NULL (not produced).
+                             Any other call takes the stage-by-stage path as if the flag were 0 */
 } snerf_render_config;
 
 typedef struct snerf_render_mlp {

@@ -12,7 +12,7 @@ from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_s
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsimplenerf_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 ITERATION_WORDS = 8      # struct snerf_iteration as 64-bit words (include/simplenerf_train.h)
@@ -45,7 +45,7 @@ RENDER_LEVELS = 6
 class RenderConfig(ctypes.Structure):
     """struct snerf_render_config"""
     _fields_ = [(name, c_int) for name in ('ndc', 'white_bkgd', 'lindisp', 'num_coarse', 'num_fine', 'precision',
-                                           'keep_activations')]
+                                           'keep_activations', 'fused')]
 
 
 class RenderMlp(ctypes.Structure):

@@ -6,6 +6,11 @@
 
 #include "snerf_common.h"
 
+namespace snerf {   // render_fused.hip: the whole eval-mode render of a plain coarse + fine model as one launch
+int render_forward_fused(const snerf_render_config* cfg, const snerf_render_mlp* mlps, const snerf_render_rays* rays, long long n,
+                         const snerf_render_outputs* out, hipStream_t stream, int* eligible);
+}
+
 namespace snerf {   // composite.hip: K4 + K5 of the main coarse level as one launch
 int composite_resample(const float* sigma, const float* rgb, const float* depths, const float* march_dirs, const float* rays_o,
                        const float* rays_d, long long num_rays, int num_samples, int ndc, int white_bkgd, float* out_rgb,
@@ -37,8 +42,9 @@ int check_common(const snerf_render_config* cfg, const snerf_render_mlp* mlps, c
         if (!mlps[l].desc) continue;
         const snerf_render_level_out& o = out->level[l];
         SNERF_REQUIRE(mlps[l].packed, "%s: level %d has no packed weights", who, l);
-        SNERF_REQUIRE(o.rgb && o.acc && o.depth && o.depth_var && o.sigma && o.raw_rgb,
-                      "%s: level %d: rgb / acc / depth / depth_var / sigma / raw_rgb are required", who, l);
+        SNERF_REQUIRE(o.rgb && o.acc && o.depth && o.depth_var, "%s: level %d: rgb / acc / depth / depth_var are required", who, l);
+        SNERF_REQUIRE((o.sigma && o.raw_rgb) || (cfg->fused && !cfg->keep_activations),
+                      "%s: level %d: sigma / raw_rgb are required (optional only for a fused eval-mode render)", who, l);
         SNERF_REQUIRE(!cfg->ndc || (o.depth_ndc && o.depth_var_ndc), "%s: level %d: NDC depth outputs are required", who, l);
         SNERF_REQUIRE(!cfg->keep_activations || o.saved_acts, "%s: level %d: saved_acts is required with keep_activations", who, l);
         SNERF_REQUIRE(!mlps[l].desc->use_view_dirs || rays->view_dirs, "%s: level %d uses view directions but view_dirs is NULL", who, l);
@@ -71,6 +77,14 @@ extern "C" int snerf_render_forward(const snerf_render_config* cfg, const snerf_
     if (rc != SNERF_OK) return rc;
     if (num_rays == 0) return SNERF_OK;
     const long long n = num_rays;
+    if (cfg->fused) {
+        int eligible = 0;
+        rc = snerf::render_forward_fused(cfg, mlps, rays, n, out, (hipStream_t)stream, &eligible);
+        if (eligible) return rc;
+        for (int l = 0; l < SNERF_RENDER_LEVELS; ++l)       // not a call the fused kernel is built for: the stage-by-stage path
+            SNERF_REQUIRE(!mlps[l].desc || (out->level[l].sigma && out->level[l].raw_rgb),
+                          "render_forward: level %d: sigma / raw_rgb are required (this call is outside the fused kernel's scope)", l);
+    }
     const Marching m = cfg->ndc ? Marching{rays->rays_o_ndc, rays->rays_d_ndc} : Marching{rays->rays_o, rays->rays_d};
     const bool fine = mlps[SNERF_LEVEL_MAIN_FINE].desc != nullptr;
     float* coarse_weights = out->level[0].weights;

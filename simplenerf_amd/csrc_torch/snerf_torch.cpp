@@ -33,8 +33,9 @@ using torch::autograd::variable_list;
 
 constexpr int kLevels = SNERF_RENDER_LEVELS;
 constexpr int kDescInts = 10;   // fields of snerf_mlp_desc, in declaration order
-// cfg ints: ndc, white_bkgd, lindisp, num_coarse, num_fine, precision, per-sample mask (1 alpha | 2 visibility | 4 weights)
-constexpr int kCfgInts = 7;
+// cfg ints: ndc, white_bkgd, lindisp, num_coarse, num_fine, precision, per-sample mask (1 alpha | 2 visibility | 4 weights),
+// fused (eval-mode renders of a plain coarse + fine model as one launch, snerf_render_config::fused)
+constexpr int kCfgInts = 8;
 // rays: rays_o, rays_d, view_dirs, rays_o_ndc, rays_d_ndc, near, far, rays_o2
 enum { R_O, R_D, R_VIEW, R_O_NDC, R_D_NDC, R_NEAR, R_FAR, R_O2, kRays };
 // draws: t_rand, u, sigma noise of the six levels, fine-depth override
@@ -123,6 +124,7 @@ std::vector<Tensor> run_forward(RenderCall& c, at::IntArrayRef cfg, at::IntArray
     c.cfg.ndc = (int)cfg[0]; c.cfg.white_bkgd = (int)cfg[1]; c.cfg.lindisp = (int)cfg[2]; c.cfg.num_coarse = (int)cfg[3];
     c.cfg.num_fine = (int)cfg[4]; c.cfg.precision = (int)cfg[5]; c.cfg.keep_activations = keep_activations ? 1 : 0;
     c.per_sample = (int)cfg[6];
+    c.cfg.fused = (int)cfg[7] && !keep_activations ? 1 : 0;
     const bool ndc = c.cfg.ndc != 0;
     const std::optional<Tensor> rays_o = rays.get(R_O);
     TORCH_CHECK(rays_o.has_value() && rays_o->defined() && rays_o->dim() == 2, "snerf::render: rays_o (n,3) is required");

@@ -227,6 +227,9 @@ class SimpleNeRFHip(torch.nn.Module):
         if precision not in ops.PRECISIONS:
             raise KeyError(f"model.hip_precision must be one of {sorted(ops.PRECISIONS)}, got {precision!r}")
         self.precision = ops.PRECISIONS[precision]
+        # eval-mode renders of a plain coarse + fine model as ONE launch with the ray group's sample tile in LDS
+        # (csrc/render_fused.hip; bit-identical outputs; calls outside its scope take the stage-by-stage path)
+        self.fused_render = bool(mcfg.get('hip_fused_render', False))
         self._packed: Dict[str, tuple] = {}
         self._draws: Optional[dict] = None
         self.seed = int(configs.get('seed', 0))
@@ -335,7 +338,7 @@ class SimpleNeRFHip(torch.nn.Module):
         """ops.RenderCall (ctypes over the C ABI) + the Python autograd.Function."""
         mcfg = self.configs['model']
         call = ops.RenderCall(packed, self.ndc, bool(mcfg['white_bkgd']), bool(mcfg['lindisp']), s_c, s_f, self.precision,
-                              keep_activations=with_grad, per_sample=per_sample)
+                              keep_activations=with_grad, per_sample=per_sample, fused=self.fused_render)
         if not with_grad:
             return call.forward(batch, draws)
         params = [p for name in present if name for p in getattr(self, name).abi_params()]
@@ -367,7 +370,8 @@ class SimpleNeRFHip(torch.nn.Module):
                                                       d.view_dependent_rgb, d.predict_visibility]
             self._desc_ints[key] = descs
         mask = (1 if 'alpha' in per_sample else 0) | (2 if 'visibility' in per_sample else 0) | (4 if 'weights' in per_sample else 0)
-        cfg = [int(self.ndc), int(bool(mcfg['white_bkgd'])), int(bool(mcfg['lindisp'])), s_c, s_f, self.precision, mask]
+        cfg = [int(self.ndc), int(bool(mcfg['white_bkgd'])), int(bool(mcfg['lindisp'])), s_c, s_f, self.precision, mask,
+               int(self.fused_render)]
         near, far = (batch['near_ndc'], batch['far_ndc']) if self.ndc else (batch['near'], batch['far'])
         predicts = any(m is not None and m.desc.predict_visibility for m in packed)
         rays = [batch['rays_o'], batch['rays_d'], batch.get('view_dirs'), batch.get('rays_o_ndc') if self.ndc else None,

@@ -283,14 +283,14 @@ class RenderCall:
     PER_RAY = (('rgb', 3), ('acc', 1), ('depth', 1), ('depth_var', 1), ('depth_ndc', 1), ('depth_var_ndc', 1))
 
     def __init__(self, mlps: List[Optional['PackedMlp']], ndc: bool, white_bkgd: bool, lindisp: bool, num_coarse: int,
-                 num_fine: int, precision: int, keep_activations: bool, per_sample=('alpha',)):
+                 num_fine: int, precision: int, keep_activations: bool, per_sample=('alpha',), fused: bool = False):
         lib = _lib.load()
         self.lib = lib
         self.mlps = list(mlps) + [None] * (_lib.RENDER_LEVELS - len(mlps))
         self.ndc, self.keep = bool(ndc), bool(keep_activations)
         self.num_coarse, self.num_fine = int(num_coarse), int(num_fine) if self.mlps[3] is not None else 0
         self.cfg = _lib.RenderConfig(int(bool(ndc)), int(bool(white_bkgd)), int(bool(lindisp)), self.num_coarse, self.num_fine,
-                                     int(precision), int(self.keep))
+                                     int(precision), int(self.keep), int(bool(fused) and not self.keep))
         self.c_mlps = (_lib.RenderMlp * _lib.RENDER_LEVELS)()
         for l, m in enumerate(self.mlps):
             if m is not None:
