@@ -187,7 +187,7 @@ int main() {
         // ---- the one-call render ops: coarse + fine pass of that MLP (same weights at both levels) in ONE call, against
         // the same stages issued one by one; then render_backward twice, the second time accumulating
         const int Sc = 16, Sf = 16, Sm = Sc + Sf;
-        snerf_render_config cfg = {1, 0, 0, Sc, Sf, SNERF_PRECISION_FP32, 1};
+        snerf_render_config cfg = {1, 0, 0, Sc, Sf, SNERF_PRECISION_FP32, 1, 0};
         snerf_render_mlp mlps[SNERF_RENDER_LEVELS] = {};
         mlps[SNERF_LEVEL_MAIN_COARSE] = {&desc, packed};
         mlps[SNERF_LEVEL_MAIN_FINE] = {&desc, packed};
@@ -254,6 +254,43 @@ int main() {
         double cn = 0.0;
         for (float v : gcoarse) { CHECK(std::isfinite(v)); cn += (double)v * v; }
         CHECK(cn > 0.0);
+        // ---- the fused render kernel (snerf_render_config::fused): an eval-mode 64 + 128 render as ONE launch against the same
+        // call taking the stage-by-stage path -- every output bit-identical
+        {
+            const int Fc = 64, Ff = 128, Fm = Fc + Ff;
+            snerf_render_outputs fo[2] = {};
+            for (int k = 0; k < 2; ++k) {
+                fo[k].depths_coarse = dev<float>(n * Fc); fo[k].depths_fine = dev<float>(n * Fm);
+                for (int l : {0, 3}) {
+                    const int s = l == 0 ? Fc : Fm;
+                    snerf_render_level_out& lo = fo[k].level[l];
+                    lo.rgb = dev<float>(3 * n); lo.acc = dev<float>(n); lo.depth = dev<float>(n); lo.depth_var = dev<float>(n);
+                    lo.depth_ndc = dev<float>(n); lo.depth_var_ndc = dev<float>(n); lo.alpha = dev<float>(n * s);
+                    lo.weights = dev<float>(n * s); lo.sigma = dev<float>(n * s); lo.raw_rgb = dev<float>(3 * n * s);
+                }
+                snerf_render_config fcfg = {1, 0, 0, Fc, Ff, SNERF_PRECISION_FP32, 0, k};
+                float* fwork = dev<float>(snerf_render_workspace_floats(&fcfg, n));
+                SNERF_OK_(snerf_render_forward(&fcfg, mlps, &rr, n, &fo[k], fwork, nullptr));
+            }
+            HIP_OK(hipDeviceSynchronize());
+            auto same = [&](const float* a, const float* b, size_t count) {
+                auto ha = host(a, count), hb = host(b, count);
+                for (size_t i = 0; i < count; ++i) CHECK(ha[i] == hb[i]);
+            };
+            same(fo[0].depths_coarse, fo[1].depths_coarse, n * Fc);
+            same(fo[0].depths_fine, fo[1].depths_fine, n * Fm);
+            for (int l : {0, 3}) {
+                const size_t s = l == 0 ? Fc : Fm;
+                same(fo[0].level[l].rgb, fo[1].level[l].rgb, 3 * n); same(fo[0].level[l].acc, fo[1].level[l].acc, n);
+                same(fo[0].level[l].depth, fo[1].level[l].depth, n); same(fo[0].level[l].depth_var_ndc, fo[1].level[l].depth_var_ndc, n);
+                same(fo[0].level[l].alpha, fo[1].level[l].alpha, n * s); same(fo[0].level[l].weights, fo[1].level[l].weights, n * s);
+                same(fo[0].level[l].sigma, fo[1].level[l].sigma, n * s); same(fo[0].level[l].raw_rgb, fo[1].level[l].raw_rgb, 3 * n * s);
+            }
+            auto acc = host(fo[1].level[3].acc, n);
+            double mean = 0.0;
+            for (float v : acc) mean += v;
+            CHECK(mean / n > 1e-3);      // not an empty render
+        }
         rr.view_dirs = nullptr;
         CHECK(snerf_render_forward(&cfg, mlps, &rr, n, &ro, rwork, nullptr) == SNERF_E_INVALID);
     }

@@ -339,7 +339,7 @@ def test_torch_library_binding_loads_and_rejects_cpu_tensors():
     d = ops.mlp_desc(synth.mlp_config(64))
     descs = [d.points_net_depth, d.points_net_width, d.views_net_depth, d.views_net_width, d.points_pe_degree, d.views_pe_degree,
              d.sigma_pe_degree, d.use_view_dirs, d.view_dependent_rgb, d.predict_visibility] + [0] * 50
-    cfg = [0, 0, 0, 64, 0, 0, 1]
+    cfg = [0, 0, 0, 64, 0, 0, 1, 0]
     rays = [torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 3), None, None, torch.ones(4, 1), torch.ones(4, 1), None]
     packed = [torch.zeros(8)] + [None] * 5
     with pytest.raises(RuntimeError, match='GPU'):
