@@ -18,6 +18,7 @@
 // Bound: MFMA fp32; algorithmic FLOPs = 2x the forward's (dgrad + wgrad).  HBM per sample: reads ~10 KB of saved
 // activations + ~10 KB of dY tiles twice (B1 writes, B2 reads) -- about 40 KB/sample, i.e. ~2.5 TB/s at the full MFMA
 // rate: under the HBM roofline, overlapped with the matrix work.
+#include "mlp_generic.h"
 #include <algorithm>
 
 #include "clock_stamp.h"
@@ -966,7 +967,12 @@ int launch_wgrad16(const JobTable& table, const float* grads, const float* acts,
 
 extern "C" size_t snerf_mlp_backward_workspace_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples) {
     snerf::MlpPlan plan;
-    if (snerf::build_plan(desc, &plan) != SNERF_OK || num_rays < 0 || num_samples < 1) return 0;
+    snerf::GenericPlan layered;
+    const int plan_status = snerf::build_plan(desc, &plan);
+    if (num_rays < 0 || num_samples < 1) return 0;
+    if (plan_status == SNERF_E_UNSUPPORTED && snerf::generic_takes(desc, &layered))
+        return snerf::generic_backward_workspace_floats(layered, num_rays * num_samples);
+    if (plan_status != SNERF_OK) return 0;
     return (size_t)std::max(plan_workspace(plan, num_rays * num_samples, false).total_floats,
                             plan_workspace(plan, num_rays * num_samples, true).total_floats);
 }
@@ -977,6 +983,15 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
                                   int num_params, int precision, int accumulate, snerf_stream_t stream) {
     snerf::MlpPlan plan;
     const int st = snerf::build_plan(desc, &plan);
+    snerf::GenericPlan layered;
+    if (st == SNERF_E_UNSUPPORTED && snerf::generic_takes(desc, &layered)) {     // a shape of the layered path (mlp_generic.hip)
+        SNERF_REQUIRE(packed && saved_acts && sigma && rgb && d_sigma && d_rgb && workspace && param_grads, "mlp_backward: NULL pointer");
+        SNERF_REQUIRE(num_params == layered.num_params, "mlp_backward: expected %d gradient tensors, got %d", layered.num_params, num_params);
+        for (int i = 0; i < num_params; ++i) SNERF_REQUIRE(param_grads[i], "mlp_backward: gradient tensor %d is NULL", i);
+        SNERF_REQUIRE(num_rays >= 1 && num_samples >= 1, "mlp_backward: bad sizes n=%lld S=%d", num_rays, num_samples);
+        return snerf::generic_backward(layered, packed, saved_acts, sigma, rgb, d_sigma, d_rgb, num_rays * num_samples, workspace,
+                                       param_grads, precision, accumulate, (hipStream_t)stream);
+    }
     if (st != SNERF_OK) return st;
     SNERF_REQUIRE(packed && saved_acts && sigma && rgb && d_sigma && d_rgb && workspace && param_grads,
                   "mlp_backward: NULL pointer");

@@ -23,6 +23,7 @@
 // Bound: MFMA (fp32, 256 FLOP/clk/CU).  Algorithmic work 2*MAC of the Linear layers: 1 186 816 FLOP per sample for
 // the 8x256 view-dependent MLP.  HBM traffic per sample: 4 B depth read + 16 B written; weights (2.4 MB) stay in L2.
 #include "mlp_forward_body.h"
+#include "mlp_generic.h"
 
 namespace snerf {
 int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, int products, hipStream_t stream);  // mlp_forward_f16.hip
@@ -69,6 +70,17 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
                         snerf_stream_t stream, const VisibilityIo& vis = VisibilityIo()) {
     snerf::MlpPlan plan;
     const int st = snerf::build_plan(desc, &plan);
+    snerf::GenericPlan layered;
+    if (st == SNERF_E_UNSUPPORTED && snerf::generic_takes(desc, &layered)) {     // a shape of the layered path (mlp_generic.hip)
+        SNERF_REQUIRE(packed && origins && dirs && depths && sigma && rgb, "mlp_forward: NULL pointer");
+        SNERF_REQUIRE(!layered.view_dep || view_dirs, "mlp_forward: this MLP needs view_dirs");
+        SNERF_REQUIRE(num_rays >= 0 && num_samples >= 1, "mlp_forward: bad sizes n=%lld S=%d", num_rays, num_samples);
+        SNERF_REQUIRE(!train || saved_acts, "mlp_forward_train: saved_acts is NULL");
+        SNERF_REQUIRE(!vis.wanted(), "mlp_forward_visibility: not built for this MLP shape");
+        if (num_rays == 0) return SNERF_OK;
+        return snerf::generic_forward(layered, packed, origins, dirs, view_dirs, depths, num_rays, num_samples, sigma_noise, sigma,
+                                      rgb, train ? saved_acts : nullptr, precision, (hipStream_t)stream);
+    }
     if (st != SNERF_OK) return st;
     SNERF_REQUIRE(packed && origins && dirs && depths && sigma && rgb, "mlp_forward: NULL pointer");
     SNERF_REQUIRE(!plan.view_dependent || view_dirs, "mlp_forward: this MLP needs view_dirs");
@@ -175,7 +187,11 @@ extern "C" int snerf_mlp_forward_visibility(const snerf_mlp_desc* desc, const fl
 
 extern "C" size_t snerf_mlp_saved_floats(const snerf_mlp_desc* desc, long long num_rays, int num_samples) {
     snerf::MlpPlan plan;
-    if (snerf::build_plan(desc, &plan) != SNERF_OK || num_rays < 0 || num_samples < 1) return 0;
+    snerf::GenericPlan layered;
+    const int st = snerf::build_plan(desc, &plan);
+    if (num_rays < 0 || num_samples < 1) return 0;
+    if (st == SNERF_E_UNSUPPORTED && snerf::generic_takes(desc, &layered)) return snerf::generic_saved_floats(layered, num_rays * num_samples);
+    if (st != SNERF_OK) return 0;
     const long long blocks = (num_rays * num_samples + 255) / 256 * 8;  // whole workgroups of up to 8 wave blocks
     return (size_t)(blocks * plan.act_rows() * 32);
 }

@@ -1,0 +1,544 @@
+// The layered path of the NeRF MLP for shapes the register-resident fused kernels are not built for: any points_net_width
+// (64, 96, 512, ...), any views_net_width, views_net_depth > 1, any depth -- everything MLP.__init__ can build
+// (src/models/SimpleNeRF01.py:567-609) except predict_visibility.  Same C ABI, same parameter tensors, same semantics; the
+// fused kernels keep every shape they cover (mlp_plan.h build_plan), this file takes the rest so that the reference's config
+// keys are honoured instead of refused.
+//
+// Design.  A 512-wide layer does not fit the register-resident chain (16 accumulator tiles + 16 operand tiles per wave > the
+// 512-register file), so activations live in memory here: one row per sample in an [N][row] fp32 matrix
+//     [ encoding | view encoding | H_0 ... (the skip layer's input stored as ONE block [encoding | H_4]) ... H_D-1 |
+//       views input block [feature | rest of the encoding | view encoding] | HV_0 ... | pts_output | views_output ]
+// and every Linear layer is one launch of ONE strided GEMM kernel on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32
+// FMA chains, the parity arithmetic): C(m,n) = sum_k A(m,k) B(k,n) with row / column strides for all three matrices, so the
+// forward (X . W^T), the input gradient (dZ . W), the weight gradient (dZ^T . X, split over the samples with a fixed-order
+// reduction) and the concatenations (column offsets into the row) are the same kernel.  64 x 64 output tile per 256-thread
+// workgroup, K staged through LDS 32 at a time with the next stage's global loads in flight.  Bias, ReLU, the ReLU mask of the
+// backward and accumulation are epilogue options.
+//
+// Bound: MFMA fp32 for the wide layers (2 x 4 B x width per sample and layer over HBM against 2 x width^2 FLOP: MFMA-bound from
+// width ~100 up), at the efficiency of a plain LDS-tiled GEMM -- a fallback for generality, not the headline path.
+// Always fp32 arithmetic: the fp16 / bf16 modes are refused for these shapes.  The inference entry point has no workspace
+// argument in the ABI, so this path keeps a per-device scratch arena for it (allocated on first use, grown when needed: a
+// FIRST generic inference call inside a graph capture fails with SNERF_E_HIP).
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "mlp_device.h"
+#include "mlp_generic.h"
+
+namespace {
+
+using snerf::GenericPlan;
+
+// ---------------------------------------------------------------------------------------------------------------- GEMM
+struct GemmArgs {
+    const float* A; long long a_rs, a_cs;
+    const float* B; long long b_rs, b_cs;
+    float* C; long long c_rs, c_cs;
+    const float* bias;                         // per column n, or NULL
+    const float* mask; long long mask_rs;      // C(m,n) *= (mask[m * mask_rs + n] > 0), or NULL (ReLU gate of the backward)
+    int M, N, K;
+    int relu, accumulate;
+    long long k_chunk;                         // split-K: blockIdx.z owns k in [z * k_chunk, min(K, (z+1) * k_chunk)) and writes
+    long long split_stride;                    // C + z * split_stride (a partial-sum buffer); 0 = no split
+};
+
+constexpr int kBM = 64, kBN = 64, kBK = 32, kPad = 1;
+
+__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
+    __shared__ float As[2][kBK][kBM + kPad];
+    __shared__ float Bs[2][kBK][kBN + kPad];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+    const long long k_lo = g.split_stride ? (long long)blockIdx.z * g.k_chunk : 0;
+    const long long k_hi = g.split_stride ? (k_lo + g.k_chunk < g.K ? k_lo + g.k_chunk : g.K) : g.K;
+    float* C = g.C + (g.split_stride ? (long long)blockIdx.z * g.split_stride : 0);
+
+    // thread -> elements of a stage: 8 of A (kBM x kBK) and 8 of B (kBK x kBN), walking the contiguous dimension first
+    const bool a_m_major = g.a_rs == 1;        // A contiguous along m (the transposed operand of the weight gradient)
+    const bool b_n_major = g.b_cs == 1;
+    float ra[8], rb[8];
+    auto load_stage = [&](long long k0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = tid + 256 * e;
+            const int am = a_m_major ? (idx & (kBM - 1)) : (idx / kBK), ak = a_m_major ? (idx / kBM) : (idx & (kBK - 1));
+            const long long m = m0 + am, k = k0 + ak;
+            ra[e] = (m < g.M && k < k_hi) ? g.A[m * g.a_rs + k * g.a_cs] : 0.0f;
+            const int bn = b_n_major ? (idx & (kBN - 1)) : (idx / kBK), bk = b_n_major ? (idx / kBN) : (idx & (kBK - 1));
+            const long long n = n0 + bn, kb = k0 + bk;
+            rb[e] = (n < g.N && kb < k_hi) ? g.B[kb * g.b_rs + n * g.b_cs] : 0.0f;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = tid + 256 * e;
+            const int am = a_m_major ? (idx & (kBM - 1)) : (idx / kBK), ak = a_m_major ? (idx / kBM) : (idx & (kBK - 1));
+            As[buf][ak][am] = ra[e];
+            const int bn = b_n_major ? (idx & (kBN - 1)) : (idx / kBK), bk = b_n_major ? (idx / kBN) : (idx & (kBK - 1));
+            Bs[buf][bk][bn] = rb[e];
+        }
+    };
+
+    // wave (wm, wn) owns the 32 x 32 sub-tile; MFMA operands: A(m = lane & 31, k = lane >> 5), B(k = lane >> 5, n = lane & 31)
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, i = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    if (k_lo < k_hi) {
+        load_stage(k_lo);
+        store_stage(0);
+        __syncthreads();
+        int buf = 0;
+        for (long long k0 = k_lo; k0 < k_hi; k0 += kBK) {
+            const bool more = k0 + kBK < k_hi;
+            if (more) load_stage(k0 + kBK);                     // in flight during this stage's MFMAs
+#pragma unroll
+            for (int p = 0; p < kBK / 2; ++p)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][2 * p + h][wm + i], Bs[buf][2 * p + h][wn + i], acc, 0, 0, 0);
+            if (more) {
+                store_stage(buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+            }
+        }
+    }
+    // D layout: lane (i = column, h), register r -> row (r & 3) + 8 (r >> 2) + 4 h of the 32 x 32 tile
+    const long long n = n0 + wn + i;
+    if (n >= g.N) return;
+    const float bias = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long long m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= g.M) continue;
+        float v = acc[r] + bias;
+        float* dst = C + m * g.c_rs + n * g.c_cs;
+        if (g.accumulate) v += *dst;
+        if (g.relu) v = fmaxf(v, 0.0f);
+        if (g.mask) v = g.mask[m * g.mask_rs + n] > 0.0f ? v : 0.0f;
+        *dst = v;
+    }
+}
+
+// out[m][n] (+)= sum_z partial[z][m][n] in z order (bit-reproducible)
+__global__ void __launch_bounds__(256) reduce_splits_kernel(const float* __restrict__ partial, long long split_stride, int splits,
+                                                            long long count, float* __restrict__ out, int accumulate) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
+        float s = accumulate ? out[e] : 0.0f;
+        for (int z = 0; z < splits; ++z) s += partial[z * split_stride + e];
+        out[e] = s;
+    }
+}
+
+// column sums of dZ (N x cols, row stride ld) over a chunk of rows: partial[z][col]
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ dz, long long ld, long long rows, int cols,
+                                                     long long rows_per_split, float* __restrict__ partial) {
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const long long lo = (long long)blockIdx.y * rows_per_split, hi = lo + rows_per_split < rows ? lo + rows_per_split : rows;
+    float s = 0.0f;
+    if (col < cols)
+        for (long long r = lo + part; r < hi; r += 4) s += dz[r * ld + col];
+    __shared__ float sh[4][64];
+    sh[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && col < cols) partial[(long long)blockIdx.y * cols + col] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------------ encoding + heads
+// [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...] (PositionalEncoder :533-557) with the fused kernels' exact range reduction
+__device__ __forceinline__ void encode_row(const float (&x)[3], int degree, float* __restrict__ row) {
+    constexpr double kInvTwoPi = 0.15915494309189533576888;
+    for (int d = 0; d < 3; ++d) row[d] = x[d];
+    for (int k = 0; k < degree; ++k)
+        for (int d = 0; d < 3; ++d) {
+            float s, c;
+            sincos_turns((double)x[d] * kInvTwoPi * (double)(1 << k), s, c);
+            row[3 + 6 * k + d] = s;
+            row[3 + 6 * k + 3 + d] = c;
+        }
+}
+
+struct EncodeArgs {
+    const float *origins, *dirs, *view_dirs, *depths;
+    float* acts; long long row;
+    long long total; int samples;
+    int points_degree, views_degree, pe_full, pts_in, views_pe;
+    int c_pe, c_pev, c_x5, c_v0_extra, c_v0_views;       // -1 = block absent
+};
+
+__global__ void __launch_bounds__(256) encode_kernel(EncodeArgs a) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < a.total; s += stride) {
+        const long long ray = s / a.samples;
+        const float z = a.depths[s];
+        float x[3];
+        for (int k = 0; k < 3; ++k) x[k] = a.origins[ray * 3 + k] + a.dirs[ray * 3 + k] * z;   // mul, then add (:140-142)
+        float* row = a.acts + s * a.row;
+        encode_row(x, a.points_degree, row + a.c_pe);
+        if (a.c_x5 >= 0)
+            for (int c = 0; c < a.pts_in; ++c) row[a.c_x5 + c] = row[a.c_pe + c];
+        if (a.c_v0_extra >= 0)
+            for (int c = a.pts_in; c < a.pe_full; ++c) row[a.c_v0_extra + (c - a.pts_in)] = row[a.c_pe + c];
+        if (a.views_pe > 0) {
+            float v[3];
+            for (int k = 0; k < 3; ++k) v[k] = a.view_dirs[ray * 3 + k];
+            encode_row(v, a.views_degree, row + a.c_pev);
+            for (int c = 0; c < a.views_pe; ++c) row[a.c_v0_views + c] = row[a.c_pev + c];
+        }
+    }
+}
+
+// pts_output / views_output rows -> sigma (N), rgb (N,3) (:664-681, :703-706)
+__global__ void __launch_bounds__(256) heads_kernel(const float* __restrict__ acts, long long row, int c_out, int c_vout, int view_dep,
+                                                    const float* __restrict__ noise, long long total, float* __restrict__ sigma,
+                                                    float* __restrict__ rgb) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) {
+        const float* r = acts + s * row;
+        float sg = r[c_out];
+        if (noise) sg += noise[s];
+        sigma[s] = fmaxf(sg, 0.0f);
+        const float* col = view_dep ? r + c_vout : r + c_out + 1;
+        for (int c = 0; c < 3; ++c) rgb[s * 3 + c] = sigmoidf(col[c]);
+    }
+}
+
+// d sigma, d rgb -> gradients of the two head pre-activations: dout (N,4) and dvout (N,4), zero-padded
+__global__ void __launch_bounds__(256) heads_backward_kernel(const float* __restrict__ sigma, const float* __restrict__ rgb,
+                                                             const float* __restrict__ d_sigma, const float* __restrict__ d_rgb,
+                                                             long long total, int view_dep, float* __restrict__ dout,
+                                                             float* __restrict__ dvout) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) {
+        float col[3];
+        for (int c = 0; c < 3; ++c) {
+            const float v = rgb[s * 3 + c];
+            col[c] = d_rgb[s * 3 + c] * (v * (1.0f - v));
+        }
+        dout[s * 4] = sigma[s] > 0.0f ? d_sigma[s] : 0.0f;
+        for (int c = 0; c < 3; ++c) {
+            dout[s * 4 + 1 + c] = view_dep ? 0.0f : col[c];
+            if (view_dep) dvout[s * 4 + c] = col[c];
+        }
+        if (view_dep) dvout[s * 4 + 3] = 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256) copy_kernel(float* __restrict__ dst, const float* __restrict__ src, long long count) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------ host side
+int launch_gemm(const GemmArgs& g, int splits, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return SNERF_OK;
+    const dim3 grid((g.N + kBN - 1) / kBN, (g.M + kBM - 1) / kBM, splits > 0 ? splits : 1);
+    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, g);
+    return snerf::check_launch("mlp_generic(gemm)");
+}
+
+// Y[rows, out] = act(X[rows, in] . W[out, in]^T + b): X, Y are column blocks of the activation matrix
+int linear_forward(const float* acts_in, float* acts_out, long long row, long long rows, int in, int out, const float* w,
+                   const float* b, bool relu, hipStream_t s) {
+    GemmArgs g = {};
+    g.A = acts_in; g.a_rs = row; g.a_cs = 1;
+    g.B = w; g.b_rs = 1; g.b_cs = in;
+    g.C = acts_out; g.c_rs = row; g.c_cs = 1;
+    g.bias = b; g.M = (int)rows; g.N = out; g.K = in; g.relu = relu ? 1 : 0;
+    return launch_gemm(g, 0, s);
+}
+
+// per-device scratch of the inference entry point (the ABI gives it no workspace argument)
+struct Arena { float* base = nullptr; size_t floats = 0; };
+std::mutex g_arena_mutex;
+Arena g_arena[64];
+
+int arena(size_t floats, float** out) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return snerf::fail(SNERF_E_HIP, "mlp_forward(layered): no current HIP device");
+    std::lock_guard<std::mutex> lock(g_arena_mutex);
+    Arena& a = g_arena[device];
+    if (a.floats < floats) {
+        if (a.base) {
+            (void)hipDeviceSynchronize();     // an earlier call's kernels may still read it
+            (void)hipFree(a.base);
+            a.base = nullptr; a.floats = 0;
+        }
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, floats * sizeof(float));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return snerf::fail(SNERF_E_HIP, "mlp_forward(layered): scratch of %zu MB: %s (a first call of this path must not be inside a "
+                                            "graph capture)", floats * sizeof(float) >> 20, hipGetErrorString(e));
+        }
+        a.base = static_cast<float*>(p); a.floats = floats;
+    }
+    *out = a.base;
+    return SNERF_OK;
+}
+
+constexpr long long kInferenceChunk = 65536;     // samples per pass of the inference entry point (bounds its scratch)
+
+// forward over `total` consecutive samples starting at sample `first` of the call; acts has `total` rows
+int forward_rows(const GenericPlan& p, const float* packed, const float* origins, const float* dirs, const float* view_dirs,
+                 const float* depths, long long first, long long total, int samples, const float* noise, float* sigma, float* rgb,
+                 float* acts, hipStream_t s) {
+    EncodeArgs e = {};
+    e.origins = origins + (first / samples) * 3; e.dirs = dirs + (first / samples) * 3;
+    e.view_dirs = view_dirs ? view_dirs + (first / samples) * 3 : nullptr;
+    // (the chunk starts at a ray boundary: kInferenceChunk is rounded to whole rays by the caller)
+    e.depths = depths + first; e.acts = acts; e.row = p.row; e.total = total; e.samples = samples;
+    e.points_degree = p.points_degree; e.views_degree = p.views_degree; e.pe_full = p.pe_full; e.pts_in = p.pts_in;
+    e.views_pe = p.view_dep ? p.views_pe : 0;
+    e.c_pe = p.c_pe; e.c_pev = p.c_pev; e.c_x5 = p.c_x5; e.c_v0_extra = p.view_dep && p.extra > 0 ? p.c_v0 + p.width : -1;
+    e.c_v0_views = p.view_dep ? p.c_v0 + p.width + p.extra : -1;
+    hipLaunchKernelGGL(encode_kernel, dim3(snerf::stride_grid(total, 256)), dim3(256), 0, s, e);
+    int rc = snerf::check_launch("mlp_generic(encode)");
+    if (rc != SNERF_OK) return rc;
+    for (int l = 0; l < p.depth; ++l) {
+        rc = linear_forward(acts + p.layer_in_col(l), acts + p.c_h[l], p.row, total, p.layer_in_dim(l), p.width,
+                            packed + p.w_off[2 * l], packed + p.w_off[2 * l + 1], true, s);
+        if (rc != SNERF_OK) return rc;
+    }
+    const int po = 2 * p.depth;
+    rc = linear_forward(acts + p.c_h[p.depth - 1], acts + p.c_out, p.row, total, p.width, p.pts_out_rows, packed + p.w_off[po],
+                        packed + p.w_off[po + 1], false, s);
+    if (rc != SNERF_OK) return rc;
+    if (p.view_dep) {
+        rc = linear_forward(acts + p.c_h[p.depth - 1], acts + p.c_v0, p.row, total, p.width, p.width, packed + p.w_off[po + 2],
+                            packed + p.w_off[po + 3], false, s);                                   // feature: no activation (:683)
+        if (rc != SNERF_OK) return rc;
+        for (int j = 0; j < p.views_depth; ++j) {
+            rc = linear_forward(acts + (j == 0 ? p.c_v0 : p.c_hv[j - 1]), acts + p.c_hv[j], p.row, total,
+                                j == 0 ? p.views_in : p.views_width, p.views_width, packed + p.w_off[po + 4 + 2 * j],
+                                packed + p.w_off[po + 5 + 2 * j], true, s);
+            if (rc != SNERF_OK) return rc;
+        }
+        const int pv = po + 4 + 2 * p.views_depth;
+        rc = linear_forward(acts + p.c_hv[p.views_depth - 1], acts + p.c_vout, p.row, total, p.views_width, 3, packed + p.w_off[pv],
+                            packed + p.w_off[pv + 1], false, s);
+        if (rc != SNERF_OK) return rc;
+    }
+    hipLaunchKernelGGL(heads_kernel, dim3(snerf::stride_grid(total, 256)), dim3(256), 0, s, acts, p.row, p.c_out, p.c_vout,
+                       p.view_dep ? 1 : 0, noise ? noise + first : nullptr, total, sigma + first, rgb + first * 3);
+    return snerf::check_launch("mlp_generic(heads)");
+}
+
+}  // namespace
+
+namespace snerf {
+
+int generic_plan(const snerf_mlp_desc* d, GenericPlan* out) {
+    if (!d) return fail(SNERF_E_INVALID, "mlp: NULL descriptor");
+    GenericPlan p;
+    p.depth = d->points_net_depth; p.width = d->points_net_width;
+    p.view_dep = d->view_dependent_rgb != 0;
+    p.views_depth = p.view_dep ? d->views_net_depth : 0;
+    p.views_width = p.view_dep ? d->views_net_width : 0;
+    p.points_degree = d->points_pe_degree; p.views_degree = p.view_dep ? d->views_pe_degree : 0;
+    if (p.width < 1 || p.width > 4096) return fail(SNERF_E_UNSUPPORTED, "mlp: points_net_width %d outside 1..4096", p.width);
+    if (p.depth < 1 || p.depth == 5 || p.depth > 64)
+        return fail(SNERF_E_UNSUPPORTED, "mlp: points_net_depth %d unsupported (the reference itself cannot build depth 5: the skip "
+                                         "concat would feed pts_output_linear)", p.depth);
+    if (p.points_degree < 1 || p.points_degree > 16) return fail(SNERF_E_UNSUPPORTED, "mlp: points positional-encoding degree %d outside 1..16", p.points_degree);
+    if (d->predict_visibility) return fail(SNERF_E_UNSUPPORTED, "mlp: predict_visibility is built for the fused shapes only (widths 128/256, views 64/128)");
+    if (p.view_dep) {
+        if (!d->use_view_dirs) return fail(SNERF_E_UNSUPPORTED, "mlp: view_dependent_rgb without use_view_dirs");
+        if (p.views_depth < 1 || p.views_depth > 16) return fail(SNERF_E_UNSUPPORTED, "mlp: views_net_depth %d outside 1..16", p.views_depth);
+        if (p.views_width < 1 || p.views_width > 4096) return fail(SNERF_E_UNSUPPORTED, "mlp: views_net_width %d outside 1..4096", p.views_width);
+        if (p.views_degree < 1 || p.views_degree > 16) return fail(SNERF_E_UNSUPPORTED, "mlp: views positional-encoding degree %d outside 1..16", p.views_degree);
+    }
+    p.pe_full = 3 + 6 * p.points_degree;
+    p.pts_in = p.pe_full;
+    if (d->sigma_pe_degree >= 0) {
+        if (d->sigma_pe_degree > p.points_degree) return fail(SNERF_E_UNSUPPORTED, "mlp: sigma encoding degree %d exceeds the points degree %d", d->sigma_pe_degree, p.points_degree);
+        if (!p.view_dep) return fail(SNERF_E_UNSUPPORTED, "mlp: points_sigma_positional_encoding_degree needs view-dependent colour");
+        p.pts_in = (2 * d->sigma_pe_degree + 1) * 3;
+    }
+    p.extra = p.pe_full - p.pts_in;
+    p.views_pe = p.view_dep ? 3 + 6 * p.views_degree : 0;
+    p.views_in = p.width + p.extra + p.views_pe;
+    p.pts_out_rows = p.view_dep ? 1 : 4;
+    p.num_params = 2 * p.depth + 2 + (p.view_dep ? 2 + 2 * p.views_depth + 2 : 0);
+    // parameter offsets in the "packed" buffer (a plain concatenation in ABI order)
+    long long off = 0;
+    auto param = [&](long long count) { p.w_off.push_back(off); p.w_count.push_back(count); off += (count + 3) / 4 * 4; };
+    for (int l = 0; l < p.depth; ++l) { param((long long)p.width * p.layer_in_dim(l)); param(p.width); }
+    param((long long)p.pts_out_rows * p.width); param(p.pts_out_rows);
+    if (p.view_dep) {
+        param((long long)p.width * p.width); param(p.width);
+        for (int j = 0; j < p.views_depth; ++j) { param((long long)p.views_width * (j == 0 ? p.views_in : p.views_width)); param(p.views_width); }
+        param(3LL * p.views_width); param(3);
+    }
+    p.packed_floats = off;
+    // activation row
+    int c = 0;
+    p.c_pe = c; c += p.pe_full;
+    p.c_pev = c; c += p.views_pe;
+    p.c_x5 = -1;
+    p.c_h.assign(p.depth, 0);
+    for (int l = 0; l < p.depth; ++l) {
+        if (l == 4 && p.depth > 5) { p.c_x5 = c; c += p.pts_in; }      // [encoding | H_4]: the skip layer's input (:662-663)
+        p.c_h[l] = c; c += p.width;
+    }
+    p.c_v0 = c; if (p.view_dep) c += p.views_in;
+    p.c_hv.assign(p.views_depth, 0);
+    for (int j = 0; j < p.views_depth; ++j) { p.c_hv[j] = c; c += p.views_width; }
+    p.c_out = c; c += 4;
+    p.c_vout = c; c += 4;
+    p.row = (c + 3) / 4 * 4;
+    *out = p;
+    return SNERF_OK;
+}
+
+int generic_pack(const GenericPlan& p, const float* const* params, float* packed, hipStream_t s) {
+    for (int i = 0; i < p.num_params; ++i) {
+        hipLaunchKernelGGL(copy_kernel, dim3(stride_grid(p.w_count[i], 256)), dim3(256), 0, s, packed + p.w_off[i], params[i], p.w_count[i]);
+        const int rc = check_launch("mlp_pack(layered)");
+        if (rc != SNERF_OK) return rc;
+    }
+    return SNERF_OK;
+}
+
+size_t generic_saved_floats(const GenericPlan& p, long long total) { return (size_t)total * (size_t)p.row; }
+
+int generic_forward(const GenericPlan& p, const float* packed, const float* origins, const float* dirs, const float* view_dirs,
+                    const float* depths, long long num_rays, int num_samples, const float* noise, float* sigma, float* rgb,
+                    float* saved_acts, int precision, hipStream_t s) {
+    if (precision != SNERF_PRECISION_FP32)
+        return fail(SNERF_E_UNSUPPORTED, "mlp_forward: this MLP shape (width %d, views %d x %d) runs on the layered fp32 path only; "
+                                         "hip_precision must be 'fp32'", p.width, p.views_depth, p.views_width);
+    const long long total = num_rays * num_samples;
+    ProfileScope timed(SNERF_PROFILE_MLP_FORWARD, s, total);
+    if (saved_acts)     // training: every layer's input is kept, the whole call in one pass
+        return forward_rows(p, packed, origins, dirs, view_dirs, depths, 0, total, num_samples, noise, sigma, rgb, saved_acts, s);
+    const long long rays_per_chunk = std::max(1LL, kInferenceChunk / num_samples);
+    float* scratch = nullptr;
+    const int rc = arena((size_t)std::min(num_rays, rays_per_chunk) * num_samples * p.row, &scratch);
+    if (rc != SNERF_OK) return rc;
+    for (long long ray = 0; ray < num_rays; ray += rays_per_chunk) {
+        const long long rays = std::min(rays_per_chunk, num_rays - ray);
+        const int st = forward_rows(p, packed, origins, dirs, view_dirs, depths, ray * num_samples, rays * num_samples, num_samples,
+                                    noise, sigma, rgb, scratch, s);
+        if (st != SNERF_OK) return st;
+    }
+    return SNERF_OK;
+}
+
+// workspace: dZ ping-pong (2 x N x widest) | d heads (2 x N x 4) | split-K partial sums
+static int wgrad_splits(long long total) { return (int)std::min<long long>(64, std::max<long long>(1, total / 8192)); }
+
+size_t generic_backward_workspace_floats(const GenericPlan& p, long long total) {
+    const long long widest = std::max({p.width, p.views_width, p.views_in, p.pts_in + p.width});
+    const long long biggest = std::max({(long long)p.width * (p.pts_in + p.width), (long long)p.views_width * p.views_in,
+                                        (long long)p.views_width * p.views_width, (long long)p.width * p.width});
+    return (size_t)(2 * total * widest + 8 * total + (long long)wgrad_splits(total) * (biggest + widest) + 64);
+}
+
+int generic_backward(const GenericPlan& p, const float* packed, const float* acts, const float* sigma, const float* rgb,
+                     const float* d_sigma, const float* d_rgb, long long total, float* workspace, float* const* grads, int precision,
+                     int accumulate, hipStream_t s) {
+    if (precision != SNERF_PRECISION_FP32)
+        return fail(SNERF_E_UNSUPPORTED, "mlp_backward: this MLP shape runs on the layered fp32 path only; hip_precision must be 'fp32'");
+    ProfileScope timed(SNERF_PROFILE_MLP_BACKWARD, s, total);
+    const long long widest = std::max({p.width, p.views_width, p.views_in, p.pts_in + p.width});
+    float* ping = workspace;
+    float* pong = workspace + total * widest;
+    float* dout = workspace + 2 * total * widest;
+    float* dvout = dout + 4 * total;
+    float* partial = dvout + 4 * total;
+    const int splits = wgrad_splits(total);
+    const long long k_chunk = (total + splits - 1) / splits;
+
+    hipLaunchKernelGGL(heads_backward_kernel, dim3(stride_grid(total, 256)), dim3(256), 0, s, sigma, rgb, d_sigma, d_rgb, total,
+                       p.view_dep ? 1 : 0, dout, dvout);
+    int rc = check_launch("mlp_generic(heads backward)");
+    if (rc != SNERF_OK) return rc;
+
+    // dW = dZ^T . X (split over the samples, fixed-order reduction), db = column sums of dZ
+    auto weight_grad = [&](const float* dz, long long dz_ld, int out, const float* x, int in, float* gw, float* gb) -> int {
+        GemmArgs g = {};
+        g.A = dz; g.a_rs = 1; g.a_cs = dz_ld;           // A(m = out feature, k = sample) = dZ[k][m]
+        g.B = x; g.b_rs = p.row; g.b_cs = 1;            // B(k = sample, n = in feature)
+        g.C = partial; g.c_rs = in; g.c_cs = 1;
+        g.M = out; g.N = in; g.K = (int)total; g.k_chunk = k_chunk; g.split_stride = (long long)out * in;
+        int st = launch_gemm(g, splits, s);
+        if (st != SNERF_OK) return st;
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3(stride_grid((long long)out * in, 256)), dim3(256), 0, s, partial,
+                           (long long)out * in, splits, (long long)out * in, gw, accumulate);
+        st = check_launch("mlp_generic(reduce)");
+        if (st != SNERF_OK) return st;
+        float* bpart = partial + (long long)splits * out * in;
+        hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64, splits), dim3(256), 0, s, dz, dz_ld, total, out, k_chunk, bpart);
+        st = check_launch("mlp_generic(bias sums)");
+        if (st != SNERF_OK) return st;
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3(1), dim3(256), 0, s, bpart, (long long)out, splits, (long long)out, gb, accumulate);
+        return check_launch("mlp_generic(reduce bias)");
+    };
+    // dX[:, cols] (+)= dZ . W[:, col0 : col0 + cols], then gated by the ReLU of the layer that produced X
+    auto input_grad = [&](const float* dz, long long dz_ld, int out, const float* w, int w_ld, int col0, int cols, float* dx,
+                          long long dx_ld, bool add, const float* gate) -> int {
+        GemmArgs g = {};
+        g.A = dz; g.a_rs = dz_ld; g.a_cs = 1;
+        g.B = w + col0; g.b_rs = w_ld; g.b_cs = 1;
+        g.C = dx; g.c_rs = dx_ld; g.c_cs = 1;
+        g.M = (int)total; g.N = cols; g.K = out; g.accumulate = add ? 1 : 0;
+        g.mask = gate; g.mask_rs = p.row;
+        return launch_gemm(g, 0, s);
+    };
+
+    const int po = 2 * p.depth;
+    float* dh = ping;        // gradient of the trunk's last activation H_D-1, then dZ of each trunk layer in turn
+    float* other = pong;
+    const float* h_last = acts + p.c_h[p.depth - 1];
+    if (p.view_dep) {
+        const int pv = po + 4 + 2 * p.views_depth;
+        // views head and views layers, last first
+        rc = weight_grad(dvout, 4, 3, acts + p.c_hv[p.views_depth - 1], p.views_width, grads[pv], grads[pv + 1]);
+        if (rc != SNERF_OK) return rc;
+        rc = input_grad(dvout, 4, 3, packed + p.w_off[pv], p.views_width, 0, p.views_width, other, p.views_width, false,
+                        acts + p.c_hv[p.views_depth - 1]);
+        if (rc != SNERF_OK) return rc;
+        float* dzv = other; float* spare = dh;
+        for (int j = p.views_depth - 1; j >= 0; --j) {
+            const int in = j == 0 ? p.views_in : p.views_width;
+            const float* x = acts + (j == 0 ? p.c_v0 : p.c_hv[j - 1]);
+            rc = weight_grad(dzv, p.views_width, p.views_width, x, in, grads[po + 4 + 2 * j], grads[po + 5 + 2 * j]);
+            if (rc != SNERF_OK) return rc;
+            // j > 0: d HV_j-1, gated by its ReLU; j == 0: d feature = the first `width` columns of the views input (no activation)
+            rc = input_grad(dzv, p.views_width, p.views_width, packed + p.w_off[po + 4 + 2 * j], in, 0, j == 0 ? p.width : p.views_width,
+                            spare, j == 0 ? p.width : p.views_width, false, j == 0 ? nullptr : acts + p.c_hv[j - 1]);
+            if (rc != SNERF_OK) return rc;
+            std::swap(dzv, spare);
+        }
+        float* dfeature = dzv;          // (N, width)
+        float* dlast = spare;
+        rc = weight_grad(dfeature, p.width, p.width, h_last, p.width, grads[po + 2], grads[po + 3]);
+        if (rc != SNERF_OK) return rc;
+        rc = input_grad(dfeature, p.width, p.width, packed + p.w_off[po + 2], p.width, 0, p.width, dlast, p.width, false, nullptr);
+        if (rc != SNERF_OK) return rc;
+        dh = dlast; other = dfeature;
+    }
+    // density head (and the view-independent colour rows): dW_out, and its contribution to d H_D-1, then the ReLU gate
+    rc = weight_grad(dout, 4, p.pts_out_rows, h_last, p.width, grads[po], grads[po + 1]);
+    if (rc != SNERF_OK) return rc;
+    rc = input_grad(dout, 4, p.pts_out_rows, packed + p.w_off[po], p.width, 0, p.width, dh, p.width, p.view_dep, h_last);
+    if (rc != SNERF_OK) return rc;
+    // trunk, last layer first: dh holds dZ_l
+    for (int l = p.depth - 1; l >= 0; --l) {
+        const int in = p.layer_in_dim(l);
+        rc = weight_grad(dh, p.width, p.width, acts + p.layer_in_col(l), in, grads[2 * l], grads[2 * l + 1]);
+        if (rc != SNERF_OK) return rc;
+        if (l == 0) break;
+        const int col0 = in - p.width;       // the skip layer's input is [encoding | H_l-1]: only the H columns carry on
+        rc = input_grad(dh, p.width, p.width, packed + p.w_off[2 * l], in, col0, p.width, other, p.width, false, acts + p.c_h[l - 1]);
+        if (rc != SNERF_OK) return rc;
+        std::swap(dh, other);
+    }
+    return SNERF_OK;
+}
+
+}  // namespace snerf

@@ -1,6 +1,7 @@
 // Weight packer: reference-layout parameters (nn.Linear weight (out,in) row-major + bias) -> the MFMA-operand-
 // ordered stream described in mlp_layout.h.  A pure permutation with zero fill; HBM-bound and tiny (2.4 MB per
 // 8x256 MLP), run once per parameter update.
+#include "mlp_generic.h"
 #include <algorithm>
 
 #include "mlp_plan.h"
@@ -153,15 +154,23 @@ __global__ void __launch_bounds__(256) pack_half_stage_kernel(StageTable table, 
 
 }  // namespace
 
+// (a shape the fused kernels are not built for goes to the layered path, mlp_generic.hip: its "packed" buffer is a plain
+// concatenation of the parameters)
 extern "C" int snerf_mlp_num_params(const snerf_mlp_desc* desc) {
     snerf::MlpPlan plan;
-    if (snerf::build_plan(desc, &plan) != SNERF_OK) return 0;
+    snerf::GenericPlan layered;
+    const int st = snerf::build_plan(desc, &plan);
+    if (st == SNERF_E_UNSUPPORTED && snerf::generic_takes(desc, &layered)) return layered.num_params;
+    if (st != SNERF_OK) return 0;
     return plan.num_params;
 }
 
 extern "C" size_t snerf_mlp_packed_floats(const snerf_mlp_desc* desc) {
     snerf::MlpPlan plan;
-    if (snerf::build_plan(desc, &plan) != SNERF_OK) return 0;
+    snerf::GenericPlan layered;
+    const int st = snerf::build_plan(desc, &plan);
+    if (st == SNERF_E_UNSUPPORTED && snerf::generic_takes(desc, &layered)) return (size_t)layered.packed_floats;
+    if (st != SNERF_OK) return 0;
     return (size_t)plan.total_floats;
 }
 
@@ -169,6 +178,13 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
                               snerf_stream_t stream) {
     snerf::MlpPlan plan;
     const int st = snerf::build_plan(desc, &plan);
+    snerf::GenericPlan layered;
+    if (st == SNERF_E_UNSUPPORTED && snerf::generic_takes(desc, &layered)) {
+        SNERF_REQUIRE(params && packed, "mlp_pack: NULL pointer");
+        SNERF_REQUIRE(num_params == layered.num_params, "mlp_pack: expected %d parameter tensors, got %d", layered.num_params, num_params);
+        for (int i = 0; i < num_params; ++i) SNERF_REQUIRE(params[i], "mlp_pack: parameter %d is NULL", i);
+        return snerf::generic_pack(layered, params, packed, (hipStream_t)stream);
+    }
     if (st != SNERF_OK) return st;
     SNERF_REQUIRE(params && packed, "mlp_pack: NULL pointer");
     SNERF_REQUIRE(num_params == plan.num_params, "mlp_pack: expected %d parameter tensors, got %d", plan.num_params,

@@ -120,8 +120,10 @@ class MlpParameters(torch.nn.Module):
             out += [layer.weight, layer.bias]
         out += [self.pts_output_linear.weight, self.pts_output_linear.bias]
         if self.view_dependent:
-            out += [self.feature_linear.weight, self.feature_linear.bias, self.views_linears[0].weight,
-                    self.views_linears[0].bias, self.views_output_linear.weight, self.views_output_linear.bias]
+            out += [self.feature_linear.weight, self.feature_linear.bias]
+            for layer in self.views_linears:          # (views_net_depth > 1: the layered path, csrc/mlp_generic.hip)
+                out += [layer.weight, layer.bias]
+            out += [self.views_output_linear.weight, self.views_output_linear.bias]
         return out
 
     def forward(self, *args, **kwargs):

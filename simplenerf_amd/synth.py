@@ -27,10 +27,10 @@ CAMERAS_JSON = os.path.join(os.path.dirname(_HERE), 'tests', 'golden', 'cameras.
 # --------------------------------------------------------------------------------------
 def mlp_config(num_samples: Optional[int] = None, depth: int = 8, width: int = 256, views_width: int = 128,
                use_view_dirs: bool = True, view_dependent_rgb: bool = True,
-               sigma_pe_degree: Optional[int] = None, predict_visibility: bool = False) -> dict:
+               sigma_pe_degree: Optional[int] = None, predict_visibility: bool = False, views_depth: int = 1) -> dict:
     cfg = {
         'points_net_depth': depth,
-        'views_net_depth': 1,
+        'views_net_depth': views_depth,
         'points_net_width': width,
         'views_net_width': views_width,
         'points_positional_encoding_degree': 10,
@@ -369,6 +369,10 @@ def abi_param_list(params: dict, prefix: str = ''):
         i += 1
     names += ['pts_output_linear.weight', 'pts_output_linear.bias']
     if f'{prefix}feature_linear.weight' in params:
-        names += ['feature_linear.weight', 'feature_linear.bias', 'views_linears.0.weight', 'views_linears.0.bias',
-                  'views_output_linear.weight', 'views_output_linear.bias']
+        names += ['feature_linear.weight', 'feature_linear.bias']
+        j = 0
+        while f'{prefix}views_linears.{j}.weight' in params:
+            names += [f'views_linears.{j}.weight', f'views_linears.{j}.bias']
+            j += 1
+        names += ['views_output_linear.weight', 'views_output_linear.bias']
     return [params[prefix + n] for n in names]
