@@ -285,6 +285,24 @@ def pmc_traffic(precision):
     return record.get('mlp_forward_hbm_bytes_per_launch'), source
 
 
+def pmc_train_traffic(precision):
+    """HBM bytes per training iteration (config 5) from a separate rocprofv3 --pmc run of `bench.py --train` (profiles/
+    pmc_traffic_train_<precision>.json: tools/pmc_passes.sh + tools/collect_pmc_kernels.py --iterations N) -- the training
+    step is HBM-bound in the 16-bit modes, so this, not the MFMA fraction, is its limiter.  -> dict or None"""
+    name = f'pmc_traffic_train_{precision}.json'
+    path = os.path.join(REPO, 'profiles', name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        record = json.load(f)
+    if 'hbm_gb_per_iteration' not in record:
+        return None
+    return {'hbm_gb_per_iteration': record['hbm_gb_per_iteration'],
+            'source': f"profiles/{name}: separate rocprofv3 --pmc passes of `bench.py --train --precision {precision}` over "
+                      f"{record.get('iterations')} iterations (FETCH_SIZE | WRITE_SIZE, gfx950 correction), collected at commit "
+                      f"{record.get('commit', 'unrecorded')} -- NOT measured in this run"}
+
+
 # ---------------------------------------------------------------------------------------------- timing protocol
 class _Mark:
     """A point on the launch stream: a HIP event on torch's current stream (the stream every library call of this
@@ -587,6 +605,9 @@ def training_record(device, steps=10, warmup=3):
             'mlp_forward_ms_per_step': fwd_ms, 'mlp_backward_ms_per_step': bwd_ms,
             'mlp_share_of_step': (fwd_ms + bwd_ms) / ms, 'dominant_kernels': dominant[precision],
             'timing': time_training.timing}
+        traffic = pmc_train_traffic(precision)
+        if traffic:      # HBM bytes per iteration and the time they alone would take at the 6.3 TB/s the board delivers
+            out['modes'][precision]['traffic'] = dict(traffic, hbm_floor_ms_at_6p3_tb_s=traffic['hbm_gb_per_iteration'] / 6.3)
     # the same iteration issued two other ways, 16-bit mode (what changes is the host side and the launch count, not the
     # kernels): ONE model pass over the 4096 rows with the losses still normalised per 2048-row sub-batch
     # (harness.train_one_iter single_pass: same objective, the reference sub-batches only for device memory), and the
@@ -630,6 +651,15 @@ def train_bench(args, rank, world, device, dist):
             'algorithmic_tflops': per_gpu * TRAIN_FLOP_PER_RAY * world * args.steps / elapsed / 1e12,
             'timing': step_summary(elapsed, device_ms, enqueue_ms, None)}
         line['timing']['short_batches'] = step.short_batches   # timed iterations with fewer than rows_per_gpu rows (epoch ends)
+        traffic = pmc_train_traffic(args.precision)
+        line['roofline'] = {'bound': 'hbm' if args.precision in ('f16', 'bf16') else 'mfma',
+                            'achieved': line['algorithmic_tflops'] / world,
+                            'peak': {'fp32': PEAK_FP32_MFMA_TFLOPS, 'f16x3': PEAK_FP16_MFMA_TFLOPS / 3}.get(args.precision, PEAK_FP16_MFMA_TFLOPS),
+                            'unit': 'TFLOP/s', 'traffic': None if traffic is None else traffic['hbm_gb_per_iteration'] * 1e9,
+                            'traffic_source': None if traffic is None else traffic['source'],
+                            'note': 'whole-iteration wall time against the MFMA peak of the mode; in the 16-bit modes the iteration is '
+                                    'HBM-bound: `traffic` (bytes per iteration, all kernels) / 6.3 TB/s is its floor'}
+        line['roofline']['frac'] = line['roofline']['achieved'] / line['roofline']['peak']
         if dist is not None:
             line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(), 'bytes': 2265488 * 4,
                                   'pattern': 'one all-reduce of the flattened parameter gradients per iteration',

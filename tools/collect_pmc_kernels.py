@@ -8,6 +8,8 @@ On the GPU box, one pass per counter set (--pmc never together with the trace do
         rocprofv3 --pmc $set --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/<tag>_${set%% *} -o p -- python3 <command>
     done
 here:  python tools/collect_pmc_kernels.py gpurun_out/<tag> profiles/<name>.json "<command, for the record>" [kernel-name filter ...]
+       [--iterations N]    the command ran N iterations of the step: adds `hbm_gb_per_iteration` = sum over ALL kernels of
+                           (HBM bytes per dispatch x dispatches) / N -- what `bench.py --train` reports as its `traffic`
 
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of a wide streaming read, WRITE_SIZE is
 exact -- MI355X_MICROARCH.md, HBM).  Fractions: MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs);
@@ -40,11 +42,20 @@ def load(path):
 def main():
     tag, dst, command = sys.argv[1], sys.argv[2], sys.argv[3]
     filters = sys.argv[4:]
+    iterations = None
+    if '--iterations' in filters:
+        at = filters.index('--iterations')
+        iterations = int(filters[at + 1])
+        filters = filters[:at] + filters[at + 2:]
     sq, sq_t = load(f'{tag}_SQ_VALU_MFMA_BUSY_CYCLES/p_counter_collection.csv')
     fetch, _ = load(f'{tag}_FETCH_SIZE/p_counter_collection.csv')
     write, _ = load(f'{tag}_WRITE_SIZE/p_counter_collection.csv')
     mean = lambda xs: sum(xs) / len(xs)
     rows = []
+    every_kernel_bytes = 0.0
+    for k in fetch:
+        if k in write:
+            every_kernel_bytes += (2 * sum(fetch[k]['FETCH_SIZE']) + sum(write[k]['WRITE_SIZE'])) * 1024
     for k in sq:
         if filters and not any(f in k for f in filters):
             continue
@@ -64,6 +75,13 @@ def main():
     out = {'source': f'rocprofv3 --pmc <set> --kernel-trace -- python3 {command}  (three passes: SQ set | FETCH_SIZE | WRITE_SIZE; '
                      'durations from the SQ pass, averages over the dispatches of each kernel); folded by tools/collect_pmc_kernels.py',
            'correction': 'HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (see pmc_traffic.json)', 'kernels': rows}
+    import os
+    import subprocess
+    head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__)))
+    out['commit'] = head.stdout.strip() or 'unrecorded'
+    if iterations:
+        out['iterations'] = iterations
+        out['hbm_gb_per_iteration'] = every_kernel_bytes / iterations / 1e9
     with open(dst, 'w') as f:
         json.dump(out, f, indent=1)
     for r in rows:
