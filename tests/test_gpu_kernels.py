@@ -131,8 +131,11 @@ def test_mlp_forward_noise_tail_and_multi_sample():
 
 
 def test_mlp_unsupported_config_fails_loudly():
+    # (a width off the fused kernels' set is no longer refused: since round 4 it runs on the layered path, tests/test_gpu_generic.py)
     with pytest.raises(NotImplementedError, match='not built'):
-        ops.PackedMlp(synth.mlp_config(64, width=192), DEV)
+        ops.PackedMlp(synth.mlp_config(64, depth=5), DEV)                 # the reference itself cannot build depth 5
+    with pytest.raises(NotImplementedError, match='predict_visibility'):
+        ops.PackedMlp(synth.mlp_config(64, width=192, predict_visibility=True), DEV)
     with pytest.raises(RuntimeError, match='GPU'):
         ops.coarse_depths(torch.zeros(4, 1), torch.ones(4, 1), 8)
 
