@@ -583,10 +583,16 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
             if (q < dy_pieces_real) {
                 src = reinterpret_cast<const char*>(grads + ((b0 * job.grad_rows + job.dy_row0) * 32 + q * 512));
                 stride = (long long)job.grad_rows * 64;
+#ifdef SNERF_PROBE_HALF_DY     // traffic ablation (WRONG results): every second dY piece of a wide operand comes from the zero page
+                if (job.out_tiles >= 4 && (q & 1)) { src = reinterpret_cast<const char*>(zeros + 192); stride = 0; }
+#endif
             }
         } else if (q - pieces_dy < x_pieces_real) {
             src = reinterpret_cast<const char*>(acts + ((b0 * job.act_rows + job.x_row0) * 32 + (q - pieces_dy) * 512));
             stride = (long long)job.act_rows * 64;
+#ifdef SNERF_PROBE_HALF_X      // traffic ablation (WRONG results): every second X piece of a wide operand comes from the zero page
+            if (job.in_tiles >= 4 && ((q - pieces_dy) & 1)) { src = reinterpret_cast<const char*>(zeros + 192); stride = 0; }
+#endif
         }
         piece_src[k] = src;
         piece_stride[k] = stride;

@@ -122,6 +122,9 @@ __device__ __forceinline__ void store_dy(const f32x16 (&acc)[U], float* __restri
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
+#ifdef SNERF_PROBE_HALF_DY     // traffic ablation (tools/probes/build_variant.py; WRONG results): the bytes an fp8 dY tile would take
+                if (s == 1) continue;
+#endif
                 bf16x8 v;
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
@@ -356,7 +359,11 @@ __global__ void __launch_bounds__(chain_waves(P, VIEWDEP, DEPTH) * 64, chain_wav
 #ifdef SNERF_ABL_CHAIN_NOSTORE   // timing ablation: the epilogue's arithmetic, but nothing written
             if (pr == 7 && t == 0 && stage[0] == (__bf16)123.0f)
 #else
-            if ((pr & 3) == 3)   // eight values staged: one 16-byte store (read once, by the weight-gradient kernel)
+            if ((pr & 3) == 3
+#ifdef SNERF_PROBE_HALF_DY
+                && pr == 3
+#endif
+                )   // eight values staged: one 16-byte store (read once, by the weight-gradient kernel)
 #endif
             {
                 __builtin_nontemporal_store(stage, reinterpret_cast<bf16x8*>(rows16 + (long long)row0 * 32 + (2 * t + (pr >> 2)) * 512 + slot8));

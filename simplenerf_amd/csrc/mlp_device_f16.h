@@ -527,7 +527,12 @@ __device__ __forceinline__ void store_pieces(const f16x8 (&frag)[NB], _Float16* 
 #pragma unroll
     // non-temporal: the saved tensors (GBs per pass) are read back only by the backward kernels, long after they have left
     // every cache; the plain store policy cost the storing forward 7 % and the backward 9 % (r02, A/B builds)
-    for (int s = 0; s < NKS; ++s) __builtin_nontemporal_store(frag[s], reinterpret_cast<f16x8*>(rows + s * 512 + slot * 8));
+    for (int s = 0; s < NKS; ++s) {
+#ifdef SNERF_PROBE_HALF_X      // traffic ablation (tools/probes/build_variant.py; WRONG results): the bytes an fp8 X tile would take
+        if (NKS >= 8 && (s & 1)) continue;
+#endif
+        __builtin_nontemporal_store(frag[s], reinterpret_cast<f16x8*>(rows + s * 512 + slot * 8));
+    }
 }
 
 // One finished accumulator tile -> rows 32u .. 32u+31 of a [feature][32-sample] fp32 tile (training: saved activations).

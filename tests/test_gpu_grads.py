@@ -164,9 +164,10 @@ def test_f16x3_chain_arithmetic_with_identical_masks():
 
 
 # ---------------------------------------------------------------- whole model
-@pytest.mark.parametrize('kind,profile', [('config3', 'consistent'), ('config2', 'consistent'), ('headline_world', 'dense'),
-                                          ('config1', 'dense')])
-@pytest.mark.parametrize('fine_depths', ['own', 'oracle'])
+# (config 1 has no fine pass: its fine depths cannot be the oracle's -- not a case, rather than a skipped one)
+@pytest.mark.parametrize('kind,profile,fine_depths', [(k, p, f) for k, p in (('config3', 'consistent'), ('config2', 'consistent'),
+                                                                             ('headline_world', 'dense'), ('config1', 'dense'))
+                                                      for f in ('own', 'oracle') if not (k == 'config1' and f == 'oracle')])
 @pytest.mark.parametrize('precision', ['fp32', 'f16x3'])
 def test_model_gradients_match_reference(kind, profile, fine_depths, precision):
     """loss.backward() through the drop-in model vs (a) autograd through the oracle, every element, and (b) the
@@ -187,8 +188,6 @@ def test_model_gradients_match_reference(kind, profile, fine_depths, precision):
     model = model.to(DEV).train()
     batch = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
     if fine_depths == 'oracle':
-        if 'z_vals_fine' not in ref_out:
-            pytest.skip('no fine pass')
         model.set_random_draws({'z_vals_fine': ref_out['z_vals_fine'].detach()})
     out = model(batch)
     loss = util.grad_loss(out)
