@@ -63,7 +63,11 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
             print(r.stderr, flush=True)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+        # the heavy translation units first (the fp16-format kernels instantiate dozens of templates each), all cores busy
+        heavy = ('mlp_forward_f16x3', 'mlp_forward_f16.', 'mlp_forward_bf16', 'mlp_backward.', 'mlp_backward_f16', 'mlp_backward_bf16', 'mlp_forward.',
+                 'mlp_forward_m16', 'render_fused')
+        jobs.sort(key=lambda cmd: next((i for i, name in enumerate(heavy) if name in cmd[-3]), len(heavy)))
+        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, len(jobs))) as pool:
             list(pool.map(run, jobs))
     if jobs or force or _stale(output, objs):
         run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', output])

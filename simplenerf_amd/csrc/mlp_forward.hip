@@ -26,7 +26,12 @@
 #include "mlp_generic.h"
 
 namespace snerf {
-int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, int products, hipStream_t stream);  // mlp_forward_f16.hip
+int mlp_forward_f16_split(const MlpPlan& plan, const MlpArgs& m, bool train, hipStream_t stream);    // mlp_forward_f16x3.hip
+int mlp_forward_f16_single(const MlpPlan& plan, const MlpArgs& m, bool train, hipStream_t stream);   // mlp_forward_f16.hip
+// products = 3: SNERF_PRECISION_F16X3; 1: SNERF_PRECISION_F16
+inline int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, int products, hipStream_t stream) {
+    return products == 3 ? mlp_forward_f16_split(plan, m, train, stream) : mlp_forward_f16_single(plan, m, train, stream);
+}
 int mlp_forward_m16(const MlpPlan& plan, const MlpArgs& m, int products, hipStream_t stream, bool bf16);  // mlp_forward_m16.hip; -1 = layout not built there
 int mlp_forward_bf16(const MlpPlan& plan, const MlpArgs& m, bool train, hipStream_t stream);              // mlp_forward_bf16.hip
 }

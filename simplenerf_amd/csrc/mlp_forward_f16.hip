@@ -1,12 +1,12 @@
-// Entry point of the fp16 formats of the fused PE + MLP forward (kernel: mlp_forward_half_kernel.h).
+// Entry point of the fp16 single-product format (SNERF_PRECISION_F16) of the fused PE + MLP forward (kernel:
+// mlp_forward_half_kernel.h).  The split-precision format lives in mlp_forward_f16x3.hip, the bf16 one in mlp_forward_bf16.hip:
+// three translation units, so that the template instantiations compile side by side.
 #include "mlp_forward_half_kernel.h"
 
 namespace snerf {
 
-// Called by snerf_mlp_forward for SNERF_PRECISION_F16X3 (products = 3) and SNERF_PRECISION_F16 (products = 1).
-int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, int products, hipStream_t stream) {
-    return products == 3 ? dispatch_half<3>(plan, m, train, plan.half_offset, stream)
-                         : dispatch_half<1>(plan, m, train, plan.half_offset, stream);
+int mlp_forward_f16_single(const MlpPlan& plan, const MlpArgs& m, bool train, hipStream_t stream) {
+    return dispatch_half<1>(plan, m, train, plan.half_offset, stream);
 }
 
 }  // namespace snerf
