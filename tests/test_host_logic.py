@@ -1,6 +1,8 @@
 """CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol, the plugin factory
 follows the reference's naming rule, and the parameter container reproduces the reference's state_dict layout."""
 import ctypes
+
+import numpy
 import os
 import re
 
@@ -33,9 +35,20 @@ def test_descriptor_queries_need_no_gpu():
     assert lib.snerf_mlp_packed_floats(ctypes.byref(d)) > 593408  # at least the MAC count of the main MLP
     d = ops.mlp_desc(synth.mlp_config(64, use_view_dirs=False, view_dependent_rgb=False))
     assert lib.snerf_mlp_num_params(ctypes.byref(d)) == 18
-    bad = ops.mlp_desc(synth.mlp_config(64, width=192))
+    # a shape outside the fused kernels' set goes to the layered path (round 4): its "packed" buffer is the parameters themselves
+    layered = synth.mlp_config(64, width=192, views_width=96, views_depth=2)
+    d = ops.mlp_desc(layered)
+    from tests import util
+    shapes = util.mlp_param_shapes(layered)
+    assert lib.snerf_mlp_num_params(ctypes.byref(d)) == len(shapes) == 26
+    count = sum(-(-int(numpy.prod(s)) // 4) * 4 for s in shapes.values())         # each tensor padded to 16 bytes
+    assert lib.snerf_mlp_packed_floats(ctypes.byref(d)) == count
+    assert lib.snerf_mlp_saved_floats(ctypes.byref(d), 10, 7) > 70 * (8 * 192 + 63)
+    bad = ops.mlp_desc(synth.mlp_config(64, depth=5))                              # the reference itself cannot build depth 5
     assert lib.snerf_mlp_packed_floats(ctypes.byref(bad)) == 0
-    assert b'points_net_width' in lib.snerf_last_error()
+    assert b'points_net_depth' in lib.snerf_last_error()
+    bad = ops.mlp_desc(synth.mlp_config(64, width=192, predict_visibility=True))
+    assert lib.snerf_mlp_num_params(ctypes.byref(bad)) == 0 and b'predict_visibility' in lib.snerf_last_error()
 
 
 def test_invalid_arguments_return_errors_without_touching_the_gpu():
