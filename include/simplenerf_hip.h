@@ -104,6 +104,12 @@ enum snerf_precision {
                                   fp32 master weights, biases, heads and outputs; training keeps activations as fp16 and
                                   layer gradients as bf16 (half the HBM traffic).  NOT within the fp32 parity bar: results
                                   agree with the fp32 path to ~1e-3 (tests/test_gpu_f16.py states the tolerances) */
+    SNERF_PRECISION_F16S8 = 4, /* SNERF_PRECISION_F16 with the saved trunk activations h_1 .. h_D-1 kept as fp8 e4m3 (half their bytes
+                                  on the way out and back in): they are read back only as the X operand of the weight-gradient
+                                  contraction over ~10^6 samples, where a 2^-4 rounding error per element averages out; values above
+                                  448 are clamped there.  Rendering, the training forward's arithmetic and the backward chain are
+                                  SNERF_PRECISION_F16's; only the weight gradients differ (<= 1e-2 relative L2,
+                                  tests/test_gpu_f16.py) */
     SNERF_PRECISION_BF16 = 3   /* the same kernels on bf16 operands (v_mfma_f32_*_bf16, 8 significand bits, fp32's exponent
                                   range): BASELINE config 5's literal dtype.  No range limit -- nothing below under "Range"
                                   applies -- at 3 fewer significand bits than SNERF_PRECISION_F16; saved activations and layer

@@ -171,6 +171,7 @@ struct WgradJob {
                                         // tile in REGISTER order -- column p of the product is encoding index
                                         // pe_index(p) and only indices in [feat_lo, feat_hi) belong to this job
     int feat_lo, feat_hi;
+    int x8;                             // SNERF_PRECISION_F16S8: X is an 8-bit (fp8 e4m3) tile image (mlp_device_f16.h store_pieces8)
 };
 
 // Encoding index held at position p of a 16-bit encoding tile (forward: store_pieces of the pe_h fragments), or -1.
@@ -497,6 +498,13 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(JobTable table, const flo
 // Bound: HBM (1 KiB per sample and 256x256 layer, against 32 MFMA cycles per wave and piece pair).
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// 8-bit variant: per 16-lane group the lanes' 8-byte chunks form an 8-row x 16-column block of bytes (row r = the chunks of lanes
+// 2r, 2r+1) and lane j receives column j (tools/probes/ds_read_tr_b8.hip)
+__device__ __forceinline__ u32x2 lds_read_tr8(unsigned lds_byte_address, int byte_offset) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_address), "i"(byte_offset) : "memory");
+    return v;
+}
 __device__ __forceinline__ u32x2 lds_read_tr16(unsigned lds_byte_address, int byte_offset) {
     u32x2 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_address), "i"(byte_offset) : "memory");
@@ -524,7 +532,10 @@ constexpr int kWgrad16Buffers = 3;
 // The per-tile arithmetic and the chunking are unchanged, so the partial sums -- and the gradients -- are bit-identical.
 // BF (SNERF_PRECISION_BF16): X is saved as bf16 too, so both fragments go to v_mfma_f32_32x32x16_bf16 as they are -- no
 // widening, no region scale (bf16 has the range), and the reduction applies no factor (WgradJob::half = 0).
-template <int NO, int NI, bool PARTIAL = false, bool BF = false>
+// X8 (SNERF_PRECISION_F16S8; the large class only): a job with x8 set reads its X operand from fp8 tiles -- one KiB per
+// tile and block instead of two, one ds_read_b64_tr_b8 per fragment instead of two tr_b16, four v_cvt_scalef32_pk_f16_fp8 --
+// and stores its columns through the tile's byte order.
+template <int NO, int NI, bool PARTIAL = false, bool BF = false, bool X8 = false>
 __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const unsigned short* __restrict__ grads,
                                                          const unsigned short* __restrict__ acts, float* __restrict__ partial,
                                                          const float* __restrict__ zeros) {
@@ -560,9 +571,11 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
 
     // Staging: one LDS-DMA instruction per piece (lane-linear 1 KiB).  Every wave issues the same number of instructions
     // per block (surplus ones repeat the last piece) so that a counted vmcnt can leave later blocks in flight.
-    const int pieces_dy = job.out_tiles * 2, pieces = pieces_dy + job.in_tiles * 2;
+    const bool x8 = X8 && job.x8 != 0;
+    const int pieces_dy = job.out_tiles * 2, pieces = pieces_dy + (x8 ? job.in_tiles : job.in_tiles * 2);
     const int per_wave = (pieces + 3) >> 2;
-    const int dy_pieces_real = (job.dy_skip + job.out_rows + 15) >> 4, x_pieces_real = (job.in_rows + 15) >> 4;
+    const int dy_pieces_real = (job.dy_skip + job.out_rows + 15) >> 4;
+    const int x_pieces_real = x8 ? (job.in_rows + 31) >> 5 : (job.in_rows + 15) >> 4;
     const int buf_floats = (job.out_tiles + job.in_tiles) * (kPairBytes / 4);
     // Source base, LDS offset and per-block stride of each of this wave's (at most 8) pieces, worked out once: per block
     // the staging then costs one scalar 64-bit add and one DMA instruction per piece.  (Recomputing the addresses from
@@ -588,7 +601,8 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
 #endif
             }
         } else if (q - pieces_dy < x_pieces_real) {
-            src = reinterpret_cast<const char*>(acts + ((b0 * job.act_rows + job.x_row0) * 32 + (q - pieces_dy) * 512));
+            // (an 8-bit tile image sits where the tile's first 16-bit piece would be)
+            src = reinterpret_cast<const char*>(acts + ((b0 * job.act_rows + job.x_row0) * 32 + (q - pieces_dy) * (x8 ? 1024 : 512)));
             stride = (long long)job.act_rows * 64;
 #ifdef SNERF_PROBE_HALF_X      // traffic ablation (WRONG results): every second X piece of a wide operand comes from the zero page
             if (job.in_tiles >= 4 && ((q - pieces_dy) & 1)) { src = reinterpret_cast<const char*>(zeros + 192); stride = 0; }
@@ -596,7 +610,7 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
         }
         piece_src[k] = src;
         piece_stride[k] = stride;
-        piece_dst[k] = (q >> 1) * kPairBytes + (q & 1) * kPieceGap;
+        piece_dst[k] = (x8 && q >= pieces_dy) ? (job.out_tiles + (q - pieces_dy)) * kPairBytes : (q >> 1) * kPairBytes + (q & 1) * kPieceGap;
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds;
     // requests the NEXT block in line (blocks are staged strictly in order) into ring slot `slot`
@@ -616,6 +630,9 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     const int grp = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
     const unsigned lane_off = (grp & 1) * kPieceGap + 32 * (8 * (grp >> 1) + q4) + 16 * (p4 & 1) + 8 * (p4 >> 1);
     const float gk = BF ? 1.0f : wgrad_scale(region_max(zeros, job.dy_row0 / 32));
+    // 8-bit X: lane (group g = lane >> 4, j = lane & 15) points at byte chunk j & 1 of slot 2 * (8 * (g >> 1) + (j >> 1)) + (g & 1),
+    // i.e. sample 8 * (g >> 1) + (j >> 1) of the k-step, lane half g & 1, and receives byte j of its group's eight samples
+    const unsigned lane_off8 = 16 * (2 * (8 * (grp >> 1) + ((lane & 15) >> 1)) + (grp & 1)) + 8 * (lane & 1);
 
     // Software pipeline over the 16-sample k-steps (two per block): the transposed reads of step t+1 are issued before the
     // MFMAs of step t, into the other fragment set, so the LDS latency and the bf16->fp16 conversion of the next step run
@@ -636,6 +653,12 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
             if (PARTIAL && oo >= no_eff) continue;      // (a tile outside the job would be read from the next buffer's bytes)
             f.a[oo].d[0] = lds_read_tr16(a_kk, oo * kPairBytes);
             f.a[oo].d[1] = lds_read_tr16(a_kk, oo * kPairBytes + 128);
+        }
+        if (x8) {
+            const unsigned b8 = buf - lane_off + lane_off8 + b_off;
+#pragma unroll
+            for (int ii = 0; ii < NI; ++ii) f.bx[ii].d[0] = lds_read_tr8(b8, ii * kPairBytes);
+            return;
         }
 #pragma unroll
         for (int ii = 0; ii < NI; ++ii) {
@@ -665,6 +688,16 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
                 }
             }
             if constexpr (BF) ah[oo] = f.a[oo].h;     // the bf16 fragment as read
+        }
+        if (x8) {       // eight fp8 bytes (samples 0..7 of this lane's k half) -> the fp16 operand
+            const float sc = 1.0f;
+#pragma unroll
+            for (int ii = 0; ii < NI; ++ii) {
+                const unsigned w0 = f.bx[ii].d[0][0], w1 = f.bx[ii].d[0][1];
+                const f16x2 e01 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, sc, false), e23 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, sc, true);
+                const f16x2 e45 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, sc, false), e67 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, sc, true);
+                f.bx[ii].h = f16x8{e01[0], e01[1], e23[0], e23[1], e45[0], e45[1], e67[0], e67[1]};
+            }
         }
     };
     auto products = [&](const FragSet& f, const f16x8 (&ah)[NO]) {
@@ -712,6 +745,9 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     if (NO == 2 && NI == 8) SNERF_STAMP_END(wgrad16);      // (the large class)
     if (!active) return;
     const int in_cols = job.in_tiles * 32;
+    // 8-bit X: accumulator column n = (lane half hh = n >> 4, byte b = n & 15 of the slot) is feature 16 (b >> 3) + 8 ((b >> 2) & 1) + 4 hh + (b & 3)
+    const int n31 = lane & 31;
+    const int column = x8 ? 16 * ((n31 & 15) >> 3) + 8 * ((n31 >> 2) & 1) + 4 * (n31 >> 4) + (n31 & 3) : n31;
     float* out = partial + job.partial_off + (long long)chunk * rows_dy * in_cols;
     float* bout = partial + job.bias_off + (long long)chunk * rows_dy;
 #pragma unroll
@@ -725,7 +761,7 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                out[(long long)(o * 32 + row) * in_cols + i * 32 + (lane & 31)] = acc[oo][ii][r];
+                out[(long long)(o * 32 + row) * in_cols + i * 32 + column] = acc[oo][ii][r];
             }
         }
         if (wi == 0) {
@@ -830,7 +866,8 @@ struct Workspace {
 };
 
 // `f16`: SNERF_PRECISION_F16 -- dY and X are 16-bit operand pieces (same row numbers; encoding tiles in register order)
-Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool f16 = false) {
+// `s8`: SNERF_PRECISION_F16S8 -- the trunk activations h_1 .. h_D-1 are 8-bit tile images (jobs of trunk layers 1 .. D-1)
+Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool f16 = false, bool s8 = false) {
     Workspace w;
     // wave blocks the chain writes and the weight-gradient jobs contract over: whole workgroups of the chain kernel (eight
     // waves in the 16-bit mode, mlp_backward_f16.hip chain_waves; snerf_mlp_saved_floats sizes the saved tiles the same way)
@@ -859,6 +896,7 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
         j.grad_rows = f16 ? p.grad16_rows() : p.grad_rows(); j.act_rows = f16 ? p.act16_rows() : p.act_rows();
         j.chunks = 1; j.blocks = blocks; j.partial_off = 0; j.bias_off = 0;
         j.w_param = w_param; j.w_ld = w_ld; j.w_col = w_col; j.b_param = b_param; j.half = f16 ? 1 : 0;
+        j.x8 = (s8 && x_kind == snerf::SEG_ACC && x_row0 >= p.act_h(1) && x_row0 < p.act_h(p.depth)) ? 1 : 0;
         w.jobs.push_back(j);
     };
     const int d = p.depth, wd = p.width;
@@ -956,12 +994,12 @@ int launch_wgrad(const JobTable& table, const float* grads, const float* acts, f
 
 }  // namespace
 
-template <int NO, int NI, bool PARTIAL = false, bool BF = false>
+template <int NO, int NI, bool PARTIAL = false, bool BF = false, bool X8 = false>
 int launch_wgrad16(const JobTable& table, const float* grads, const float* acts, float* partial, hipStream_t stream) {
     int max_tiles = 0;
     for (int j = 0; j < table.count; ++j) max_tiles = std::max(max_tiles, table.jobs[j].out_tiles + table.jobs[j].in_tiles);
     const size_t lds_bytes = (size_t)kWgrad16Buffers * max_tiles * kPairBytes;
-    auto kernel = wgrad16_kernel<NO, NI, PARTIAL, BF>;
+    auto kernel = wgrad16_kernel<NO, NI, PARTIAL, BF, X8>;
     static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
     const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), kWgrad16Buffers * 16 * kPairBytes, "mlp_backward");
     if (attr != SNERF_OK) return attr;
@@ -1006,10 +1044,11 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     for (int i = 0; i < num_params; ++i) SNERF_REQUIRE(param_grads[i], "mlp_backward: gradient tensor %d is NULL", i);
     SNERF_REQUIRE(num_rays >= 1 && num_samples >= 1, "mlp_backward: bad sizes n=%lld S=%d", num_rays, num_samples);
     if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3 && precision != SNERF_PRECISION_F16 &&
-        precision != SNERF_PRECISION_BF16)
+        precision != SNERF_PRECISION_BF16 && precision != SNERF_PRECISION_F16S8)
         return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: precision %d not built", precision);
     const bool bf16 = precision == SNERF_PRECISION_BF16;
-    const bool f16 = precision == SNERF_PRECISION_F16 || bf16;   // the 16-bit tile layouts; saved_acts must come from forward_train at the same precision
+    const bool s8 = precision == SNERF_PRECISION_F16S8;       // fp16 products, trunk activations saved as fp8
+    const bool f16 = precision == SNERF_PRECISION_F16 || bf16 || s8;   // the 16-bit tile layouts; saved_acts must come from forward_train at the same precision
     if (precision != SNERF_PRECISION_FP32 && !bf16) {   // the forward that saved these activations may have left the fp16 range
         const int range = snerf::report_range("mlp_backward");
         if (range != SNERF_OK) return range;
@@ -1017,7 +1056,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     const long long total = num_rays * num_samples;
     if ((total + 127) / 128 > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many samples");
     hipStream_t s = (hipStream_t)stream;
-    const Workspace ws = plan_workspace(plan, total, f16);
+    const Workspace ws = plan_workspace(plan, total, f16, s8);
     // every limit is checked BEFORE anything is enqueued: the chain kernel publishes one maximum per 32-row dY region
     // into a kRegionWords-word slot, and the reduction's job table holds kMaxJobs entries
     if ((int)ws.jobs.size() > kMaxJobs) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many weight-gradient jobs");
@@ -1142,7 +1181,8 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
             else rc = launch_wgrad16<1, 1, false, true>(sub, grads, saved_acts, partial, s);
         }
         else if (f16) {
-            if (cls[0] == 2 && cls[1] == 8) rc = launch_wgrad16<2, 8>(sub, grads, saved_acts, partial, s);
+            if (cls[0] == 2 && cls[1] == 8) rc = s8 ? launch_wgrad16<2, 8, false, false, true>(sub, grads, saved_acts, partial, s)
+                                                    : launch_wgrad16<2, 8>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 2 && cls[1] == 2) rc = launch_wgrad16<2, 2>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 2 && cls[1] == 1) rc = launch_wgrad16<2, 1>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 1 && cls[1] == 8) rc = launch_wgrad16<1, 8>(sub, grads, saved_acts, partial, s);

@@ -535,6 +535,41 @@ __device__ __forceinline__ void store_pieces(const f16x8 (&frag)[NB], _Float16* 
     }
 }
 
+// 8-bit saved tiles (SNERF_PRECISION_F16S8): the trunk activations h_1 .. h_D-1 are read back ONLY by the weight-gradient
+// kernel, as the X operand of a contraction over ~10^6 samples -- a per-element rounding error of 2^-4 averages out there (it is
+// never seen by the forward or the backward chain) -- so they are kept as plain fp8 e4m3: half the bytes of the fp16 pieces on
+// the way out and on the way back in (measured bound of the saving: profiles/r04_train_f16_traffic_ablation.txt).  e4m3 spans
+// 2^-9 .. 448 with four significant bits from 2^-6 up; post-ReLU activations above 448 are CLAMPED there (in this operand of the
+// weight gradients only: v_cvt_scalef32_pk_fp8_f16 returns NaN above the range, tools/probes/cvt_fp8_scale.hip), values
+// below 2^-10 contribute nothing -- as they would not to the sum.  A tile (two k-steps) becomes one KiB: slot = 2 * sample +
+// lane half holds 16 bytes, k-step 2u's eight elements then k-step 2u+1's, stored where the tile's FIRST 16-bit piece would be
+// (the second piece's KiB stays unused: same row numbers for every format).  The weight-gradient kernel reads it back
+// transposed with ds_read_b64_tr_b8 and widens with v_cvt_scalef32_pk_f16_fp8 (mlp_backward.hip).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// `frag`: NKS post-ReLU (non-negative) fp16 fragments of this wave block
+template <int NKS, int NB>
+__device__ __forceinline__ void store_pieces8(const f16x8 (&frag)[NB], _Float16* __restrict__ rows, int lane) {
+    static_assert(NB >= NKS && NKS % 2 == 0, "whole tiles");
+    const int slot = 2 * (lane & 31) + (lane >> 5);
+    const f16x2 top = {(_Float16)448.0f, (_Float16)448.0f};
+#pragma unroll
+    for (int u = 0; u < NKS / 2; ++u) {
+        u32x4 w;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const f16x8& f = frag[2 * u + k];
+                s16x2 p = {0, 0};
+                p = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p, __builtin_elementwise_min(f16x2{f[4 * d], f[4 * d + 1]}, top), 1.0f, false);
+                p = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p, __builtin_elementwise_min(f16x2{f[4 * d + 2], f[4 * d + 3]}, top), 1.0f, true);
+                w[2 * k + d] = __builtin_bit_cast(unsigned, p);
+            }
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(rows + (2 * u) * 512 + slot * 8));
+    }
+}
+
 // One finished accumulator tile -> rows 32u .. 32u+31 of a [feature][32-sample] fp32 tile (training: saved activations).
 template <bool RELU>
 __device__ __forceinline__ void store_tile_rows(const f32x16& acc, float* __restrict__ rows, int lane) {

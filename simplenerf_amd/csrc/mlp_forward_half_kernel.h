@@ -59,9 +59,12 @@ struct HalfArgs {
 // the point where a request's pieces run out -- folds to constants.  With the generic (DEPTH = 0) loop that bookkeeping
 // is ~250 scalar instructions, compare-and-branch trees included, around the 16 MFMAs of a 256-wide unit: at one or two
 // waves per SIMD every one of them is an issue slot, and the matrix pipe waited on the scalar unit (r02).
-template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P, int DEPTH, bool BF = false>
+// S8 (SNERF_PRECISION_F16S8, training forward of the fp16 single-product format): the trunk activations h_1 .. h_D-1 are saved
+// as fp8 e4m3 tiles (store_pieces8, mlp_device_f16.h); everything else as with P = 1.
+template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P, int DEPTH, bool BF = false, bool S8 = false>
 __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(HalfArgs args) {
     static_assert(!BF || P == 1, "bf16 operands: single-product kernels only");
+    static_assert(!S8 || (P == 1 && !BF && STORE), "8-bit saved activations: the fp16 single-product training forward");
     constexpr int NW = P == 1 ? 8 : 4;   // waves per workgroup (see UnitStreamT)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const MlpArgs& a = args.m;
@@ -178,7 +181,10 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         if constexpr (P == 1) convert_tile<true, BF>(acc[u], xh[2 * u], xh[2 * u + 1]);
         else split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
     }
-    if (STORE16) { store_pieces<HK>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK); }
+    if (STORE16) {
+        if (S8 && depth > 1) { store_pieces8<HK>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK / 2); }   // h_1
+        else { store_pieces<HK>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK); }
+    }
 
     // ---- trunk layers 1 .. depth-1 --------------------------------------------------------------------------------
     auto trunk_layer = [&](int l) __attribute__((always_inline)) {
@@ -210,7 +216,11 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
                 for (int i = 0; i < HK; ++i) watch.see(xh[i]);
             }
         }
-        if (STORE16) { store_pieces<HK>(xh, tile16 + (a.act_h1 + l * a.width) * 32, lane); st.note_vmem(HK); }
+        if (STORE16) {
+            // (h_D, the last trunk tensor, stays fp16: it also feeds the small head products)
+            if (S8 && !last) { store_pieces8<HK>(xh, tile16 + (a.act_h1 + l * a.width) * 32, lane); st.note_vmem(HK / 2); }
+            else { store_pieces<HK>(xh, tile16 + (a.act_h1 + l * a.width) * 32, lane); st.note_vmem(HK); }
+        }
     };
     if constexpr (DEPTH > 0) {
         static_for<1, DEPTH>([&](auto layer) __attribute__((always_inline)) { trunk_layer(decltype(layer)::value); });
@@ -283,13 +293,13 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
     }
 }
 
-template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P, int DEPTH = 0, bool BF = false>
+template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P, int DEPTH = 0, bool BF = false, bool S8 = false>
 int launch_half(const HalfArgs& args, hipStream_t stream) {
     constexpr int NW = P == 1 ? 8 : 4;
     const long long blocks = (args.m.total + NW * 32 - 1) / (NW * 32);
     if (blocks > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: too many samples in one call");
     const size_t lds_bytes = sizeof(float) * (kUnitBuffers * (size_t)args.slot_floats + NW * 256 + (size_t)args.const_floats);
-    auto kernel = mlp_forward_f16x3_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE, P, DEPTH, BF>;
+    auto kernel = mlp_forward_f16x3_kernel<WT, VT, VIEWDEP, SIGMA_PE, STORE, P, DEPTH, BF, S8>;
     static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
     const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 2048 + 5120)), "mlp_forward");
     if (attr != SNERF_OK) return attr;
@@ -298,20 +308,28 @@ int launch_half(const HalfArgs& args, hipStream_t stream) {
 }
 
 // FORMAT: 3 = split precision (SNERF_PRECISION_F16X3), 1 = single fp16 product (SNERF_PRECISION_F16), 2 = single bf16 product
-// (SNERF_PRECISION_BF16).  One translation unit instantiates the formats it serves (mlp_forward_f16.hip: 3 and 1;
-// mlp_forward_bf16.hip: 2), so that the two compile side by side.
+// (SNERF_PRECISION_BF16), 4 = the training forward of SNERF_PRECISION_F16S8 (fp16 products, trunk activations saved as fp8).
+// One translation unit instantiates the format it serves (mlp_forward_f16x3.hip: 3; mlp_forward_f16.hip: 1;
+// mlp_forward_bf16.hip: 2; mlp_forward_s8.hip: 4), so that they compile side by side.
 template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, int FORMAT>
 int launch_variant(const HalfArgs& args, bool train, hipStream_t stream) {
     constexpr int P = FORMAT == 3 ? 3 : 1;
     constexpr bool BF = FORMAT == 2;
-    if constexpr (WT == 8 && VIEWDEP) {   // the shipped 8 x 256 trunk: compile-time unit schedule (the view-independent
-                                          // layout spills ~300 registers when unrolled: it keeps the loop)
-        if (args.m.depth == 8)
-            return train ? launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, P, 8, BF>(args, stream)
-                         : launch_half<WT, VT, VIEWDEP, SIGMA_PE, false, P, 8, BF>(args, stream);
+    if constexpr (FORMAT == 4) {        // training only (rendering in this mode IS the fp16 mode)
+        if constexpr (WT == 8 && VIEWDEP) {
+            if (args.m.depth == 8) return launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, 1, 8, false, true>(args, stream);
+        }
+        return launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, 1, 0, false, true>(args, stream);
+    } else {
+        if constexpr (WT == 8 && VIEWDEP) {   // the shipped 8 x 256 trunk: compile-time unit schedule (the view-independent
+                                              // layout spills ~300 registers when unrolled: it keeps the loop)
+            if (args.m.depth == 8)
+                return train ? launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, P, 8, BF>(args, stream)
+                             : launch_half<WT, VT, VIEWDEP, SIGMA_PE, false, P, 8, BF>(args, stream);
+        }
+        return train ? launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, P, 0, BF>(args, stream)
+                     : launch_half<WT, VT, VIEWDEP, SIGMA_PE, false, P, 0, BF>(args, stream);
     }
-    return train ? launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, P, 0, BF>(args, stream)
-                 : launch_half<WT, VT, VIEWDEP, SIGMA_PE, false, P, 0, BF>(args, stream);
 }
 
 // Argument block + layout dispatch shared by the entry points (argument checks were done by snerf_mlp_forward).  `stages` /
