@@ -20,6 +20,7 @@
 // rate: under the HBM roofline, overlapped with the matrix work.
 #include "mlp_generic.h"
 #include <algorithm>
+#include <type_traits>
 
 #include "clock_stamp.h"
 #include "mlp_device_f16.h"
@@ -518,12 +519,25 @@ union Frag16 {
     u32x2 d[2];
     f16x8 h;
 };
+// f(integral_constant<I>), ..., f(integral_constant<N-1>): one inlined copy of the body per index
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 SNERF_STAMP_DEFINE(wgrad16)
 
 constexpr int kPairBytes = 2304;   // LDS image of one 32-row tile: piece 0 at +0, piece 1 at +1152 (bank phase +32 dwords:
 constexpr int kPieceGap = 1152;    // the two 16-lane groups of a half-wave read different pieces of the same tile)
 constexpr int kWgrad16Buffers = 3;
+#ifdef SNERF_PROBE_RING4        // ablation: a fourth slot for the 8-bit instance (measured: +0.23 ms per config-5 iteration)
+constexpr int wgrad16_ring(bool x8) { return x8 ? 4 : kWgrad16Buffers; }
+#else
+constexpr int wgrad16_ring(bool) { return kWgrad16Buffers; }
+#endif
 
 // PARTIAL: the small head / encoding jobs -- (8 x 2), (1 x 8), (4 x 1) and (1 x 4) tiles for the main MLP -- share ONE launch
 // of the <2, 2> instance: a wave's register tile may then be only partly covered by the job (wave-uniform guards around its
@@ -601,8 +615,8 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
 #endif
             }
         } else if (q - pieces_dy < x_pieces_real) {
-            // (an 8-bit tile image sits where the tile's first 16-bit piece would be)
-            src = reinterpret_cast<const char*>(acts + ((b0 * job.act_rows + job.x_row0) * 32 + (q - pieces_dy) * (x8 ? 1024 : 512)));
+            // (8-bit tile images are one KiB each, packed: WgradJob::x_row0 already counts them so)
+            src = reinterpret_cast<const char*>(acts + ((b0 * job.act_rows + job.x_row0) * 32 + (q - pieces_dy) * 512));
             stride = (long long)job.act_rows * 64;
 #ifdef SNERF_PROBE_HALF_X      // traffic ablation (WRONG results): every second X piece of a wide operand comes from the zero page
             if (job.in_tiles >= 4 && ((q - pieces_dy) & 1)) { src = reinterpret_cast<const char*>(zeros + 192); stride = 0; }
@@ -713,32 +727,168 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     const int nblocks = (int)(b1 - b0);
     SNERF_STAMP_BEGIN();
     FragSet even, odd;
-    f16x8 ah[NO];
     int stage_slot = 0, read_slot = 0;                       // ring positions of the next block to request / to read
-    auto advance = [](int& slot) { slot = slot == kWgrad16Buffers - 1 ? 0 : slot + 1; };
-    if (nblocks > 0) {
-        stage_next(stage_slot); advance(stage_slot);
-        if (nblocks > 1) { stage_next(stage_slot); advance(stage_slot); }
-        wait_vmcnt(nblocks > 1 ? per_wave : 0);
+    // RING slots, AHEAD blocks requested before the first is used.  What the large class is bound by (config 5, round 4):
+    // with the MFMAs and LDS reads compiled out (SNERF_PROBE_WGRAD_NOMATH) the block stream alone takes 257 us (16-bit X) /
+    // 233 us (8-bit X) of the 260 / 237 us the kernels take -- ONE block per CU is in flight at a time (the ring's other
+    // two slots hold the block being read and the block that has landed for the next half-block), and a block's round trip
+    // under load is ~1.2 us whether it is 32 or 24 KiB.  More in flight did NOT help once the arithmetic is there: a fourth
+    // slot (SNERF_PROBE_RING4: 209 us without the arithmetic, 256-260 us with it) and the same three slots refilled one
+    // barrier earlier (SNERF_PROBE_DEEP: 255 us for 16-bit X, 243 us for 8-bit X) -- cause not found.
+    constexpr int RING = wgrad16_ring(X8);
+    constexpr bool OVERLAP = !PARTIAL && NO * NI >= 8;       // (the schedule below)
+    // The serial schedule reads block n's second k-step after the mid-block barrier, so block n's slot cannot be refilled
+    // there: AHEAD = RING - 1.  In the overlapped schedule every read of block n has LANDED before that barrier (they are
+    // waited for inside the first k-step), so the barrier would free block n's own slot: the probe requests one block more.
+#ifdef SNERF_PROBE_DEEP
+    constexpr int AHEAD = OVERLAP ? RING : RING - 1;
+#else
+    constexpr int AHEAD = RING - 1;
+#endif
+    auto advance = [](int& slot) { slot = slot == RING - 1 ? 0 : slot + 1; };
+    auto first_block = [&]() {
+        const int ahead = nblocks < AHEAD ? nblocks : AHEAD;
+        for (int k = 0; k < ahead; ++k) { stage_next(stage_slot); advance(stage_slot); }
+        wait_vmcnt((ahead - 1) * per_wave);
         __builtin_amdgcn_s_barrier();                       // block 0 is in for every wave
-        if (active) issue_reads(even, read_slot, 0);
-    }
-    for (int n = 0; n < nblocks; ++n) {
-        if (active) {
-            wait_reads(even, ah);
-            issue_reads(odd, read_slot, 1);
-            products(even, ah);
+    };
+    // block n+1 (requested half a block ago or earlier) is in for every wave, everyone is done with block n-1 (serial
+    // schedule) / block n (overlapped): its slot is requested for block n + AHEAD
+    auto next_block = [&](int n) {
+        if (AHEAD == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else { const int behind = nblocks - (n + 2) < AHEAD - 2 ? nblocks - (n + 2) : AHEAD - 2; wait_vmcnt(behind * per_wave); }
+        __builtin_amdgcn_s_barrier();
+        if (n + AHEAD < nblocks) { stage_next(stage_slot); advance(stage_slot); }
+    };
+
+    // The large register tiles (one wave per SIMD, 16 or 8 MFMAs per k-step) run the conversions of k-step t+1 in the
+    // SHADOW of k-step t's MFMAs: issued one after the other -- convert, then 16 MFMAs back to back -- the wave sat
+    // issue-stalled behind the matrix pipe for a third of the time and issued VALU work with the pipe idle for another
+    // 40 % (PMC, r04_pmc_train_f16.json): ~3200 cycles per block for 1024 cycles of MFMAs, and the 8-bit X operand --
+    // fewer bytes, 64 more conversions per block -- came out SLOWER than the 16-bit one.  Order per k-step: the first
+    // quarter of the MFMAs (the next step's transposed reads, issued at the end of the previous step, land meanwhile),
+    // the LDS wait, then the remaining MFMAs with the next step's conversion tasks dealt out between them.  Same
+    // arithmetic in the same order per accumulator and bias sum: results are bit-identical to the serial schedule.
+    if constexpr (OVERLAP) {
+        auto pipeline = [&](auto x8_job) __attribute__((always_inline)) {
+            constexpr bool X8J = decltype(x8_job)::value;
+            f16x8 ah_even[NO], ah_odd[NO];
+            auto request = [&](FragSet& f, int slot, int kk) {
+                const unsigned buf = lds0 + (unsigned)slot * (unsigned)(buf_floats * 4) + kk * 512;
+                const unsigned a_kk = buf + a_off, b_kk = buf + b_off;
+#pragma unroll
+                for (int oo = 0; oo < NO; ++oo) {
+                    f.a[oo].d[0] = lds_read_tr16(a_kk, oo * kPairBytes);
+                    f.a[oo].d[1] = lds_read_tr16(a_kk, oo * kPairBytes + 128);
+                }
+                if constexpr (X8J) {
+                    const unsigned b8 = buf - lane_off + lane_off8 + b_off;
+#pragma unroll
+                    for (int ii = 0; ii < NI; ++ii) f.bx[ii].d[0] = lds_read_tr8(b8, ii * kPairBytes);
+                } else {
+#pragma unroll
+                    for (int ii = 0; ii < NI; ++ii) {
+                        f.bx[ii].d[0] = lds_read_tr16(b_kk, ii * kPairBytes);
+                        f.bx[ii].d[1] = lds_read_tr16(b_kk, ii * kPairBytes + 128);
+                    }
+                }
+            };
+            auto landed = [&](FragSet& f) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int oo = 0; oo < NO; ++oo) { after_lds_wait(f.a[oo].d[0]); after_lds_wait(f.a[oo].d[1]); }
+#pragma unroll
+                for (int ii = 0; ii < NI; ++ii) { after_lds_wait(f.bx[ii].d[0]); if (!X8J) after_lds_wait(f.bx[ii].d[1]); }
+            };
+            constexpr int TASKS = NO * 4 + (X8J ? NI : 0);
+            // task t < 4 NO: word t & 3 of dY tile t >> 2 (bf16 pair -> fp32 (exact), bias sum in true units, x region scale
+            // -> fp16); then, 8-bit X: tile t - 4 NO (eight fp8 bytes -> the fp16 operand)
+            auto convert = [&](FragSet& f, f16x8 (&ah)[NO], auto task) __attribute__((always_inline)) {
+                constexpr int t = decltype(task)::value;
+                if constexpr (t < NO * 4) {
+                    constexpr int oo = t >> 2, w = t & 3;
+                    const unsigned word = f.a[oo].d[w >> 1][w & 1];
+                    const f32x2 v = {__uint_as_float(word << 16), __uint_as_float(word & 0xffff0000u)};
+                    bsum[oo] += v[0] + v[1];
+                    if constexpr (!BF) {
+                        const f16x2 hcv = __builtin_convertvector(v * gk, f16x2);
+                        ah[oo][2 * w] = hcv[0]; ah[oo][2 * w + 1] = hcv[1];
+                    } else if constexpr (w == 3) {
+                        ah[oo] = f.a[oo].h;     // the bf16 fragment as read
+                    }
+                } else {
+                    constexpr int ii = t - NO * 4;
+                    const unsigned w0 = f.bx[ii].d[0][0], w1 = f.bx[ii].d[0][1];
+                    const f16x2 e01 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, false), e23 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, true);
+                    const f16x2 e45 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, false), e67 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, true);
+                    f.bx[ii].h = f16x8{e01[0], e01[1], e23[0], e23[1], e45[0], e45[1], e67[0], e67[1]};
+                }
+            };
+            auto convert_all = [&](FragSet& f, f16x8 (&ah)[NO]) {
+                static_for<0, TASKS>([&](auto task) __attribute__((always_inline)) { convert(f, ah, task); });
+            };
+            // MFMAs of one k-step (f, ah); `with_next`: the next step's fragments g become operands (gh) meanwhile
+            auto step = [&](const FragSet& f, const f16x8 (&ah)[NO], FragSet& g, f16x8 (&gh)[NO], auto with_next) __attribute__((always_inline)) {
+                constexpr bool NEXT = decltype(with_next)::value;
+                constexpr int M = NO * NI, LEAD = M / 4, SLOTS = M - LEAD + 1;
+                static_for<0, M>([&](auto index) __attribute__((always_inline)) {
+                    constexpr int m = decltype(index)::value, ii = m / NO, oo = m % NO;
+                    acc[oo][ii] = mfma_32x32x16<BF>(ah[oo], f.bx[ii].h, acc[oo][ii]);
+                    if constexpr (NEXT && m >= LEAD - 1) {
+                        if constexpr (m == LEAD - 1) landed(g);
+                        constexpr int t0 = (m - (LEAD - 1)) * TASKS / SLOTS, t1 = (m + 1 - (LEAD - 1)) * TASKS / SLOTS;
+                        static_for<t0, t1>([&](auto task) __attribute__((always_inline)) { convert(g, gh, task); });
+                    }
+                });
+            };
+            if (nblocks > 0) {
+                first_block();
+                if (active) {
+                    request(even, read_slot, 0);
+                    landed(even);
+                    convert_all(even, ah_even);
+                    request(odd, read_slot, 1);
+                }
+            }
+#ifdef SNERF_PROBE_WGRAD_NOMATH      // ablation (WRONG results): the block stream alone -- requests, waits and barriers, no LDS reads, no MFMAs
+            for (int n = 0; n + 1 < nblocks; ++n) { advance(read_slot); next_block(n); }
+            return;
+#endif
+            for (int n = 0; n + 1 < nblocks; ++n) {
+                if (active) step(even, ah_even, odd, ah_odd, std::true_type{});
+                advance(read_slot);
+                next_block(n);
+                if (active) {
+                    request(even, read_slot, 0);
+                    step(odd, ah_odd, even, ah_even, std::true_type{});
+                    request(odd, read_slot, 1);
+                }
+            }
+            if (nblocks > 0 && active) {                     // the last block: nothing behind its second k-step
+                step(even, ah_even, odd, ah_odd, std::true_type{});
+                step(odd, ah_odd, even, ah_even, std::false_type{});
+            }
+        };
+        if (X8 && x8) pipeline(std::bool_constant<X8>{}); else pipeline(std::false_type{});
+    } else {
+        f16x8 ah[NO];
+        if (nblocks > 0) {
+            first_block();
+            if (active) issue_reads(even, read_slot, 0);
         }
-        advance(read_slot);
-        if (n + 1 < nblocks) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // block n+1 (requested half a block ago or earlier)
-            __builtin_amdgcn_s_barrier();
-            if (n + 2 < nblocks) { stage_next(stage_slot); advance(stage_slot); }
-        }
-        if (active) {
-            wait_reads(odd, ah);
-            if (n + 1 < nblocks) issue_reads(even, read_slot, 0);
-            products(odd, ah);
+        for (int n = 0; n < nblocks; ++n) {
+            if (active) {
+                wait_reads(even, ah);
+                issue_reads(odd, read_slot, 1);
+                products(even, ah);
+            }
+            advance(read_slot);
+            if (n + 1 < nblocks) next_block(n);
+            if (active) {
+                wait_reads(odd, ah);
+                if (n + 1 < nblocks) issue_reads(even, read_slot, 0);
+                products(odd, ah);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -896,7 +1046,10 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
         j.grad_rows = f16 ? p.grad16_rows() : p.grad_rows(); j.act_rows = f16 ? p.act16_rows() : p.act_rows();
         j.chunks = 1; j.blocks = blocks; j.partial_off = 0; j.bias_off = 0;
         j.w_param = w_param; j.w_ld = w_ld; j.w_col = w_col; j.b_param = b_param; j.half = f16 ? 1 : 0;
-        j.x8 = (s8 && x_kind == snerf::SEG_ACC && x_row0 >= p.act_h(1) && x_row0 < p.act_h(p.depth)) ? 1 : 0;
+        // (256-wide trunks only: their products form the large class; mlp_forward_half_kernel.h stores fp8 under the same condition)
+        j.x8 = (s8 && p.wt == 8 && x_kind == snerf::SEG_ACC && x_row0 >= p.act_h(1) && x_row0 < p.act_h(p.depth)) ? 1 : 0;
+        // ... packed: layer l's eight KiB tiles follow layer l-1's, from where h_1's 16-bit rows would begin (64-byte rows)
+        if (j.x8) j.x_row0 = p.act_h(1) + (x_row0 - p.act_h(1)) / 2;
         w.jobs.push_back(j);
     };
     const int d = p.depth, wd = p.width;
@@ -998,10 +1151,10 @@ template <int NO, int NI, bool PARTIAL = false, bool BF = false, bool X8 = false
 int launch_wgrad16(const JobTable& table, const float* grads, const float* acts, float* partial, hipStream_t stream) {
     int max_tiles = 0;
     for (int j = 0; j < table.count; ++j) max_tiles = std::max(max_tiles, table.jobs[j].out_tiles + table.jobs[j].in_tiles);
-    const size_t lds_bytes = (size_t)kWgrad16Buffers * max_tiles * kPairBytes;
+    const size_t lds_bytes = (size_t)wgrad16_ring(X8) * max_tiles * kPairBytes;
     auto kernel = wgrad16_kernel<NO, NI, PARTIAL, BF, X8>;
     static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
-    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), kWgrad16Buffers * 16 * kPairBytes, "mlp_backward");
+    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), wgrad16_ring(X8) * 16 * kPairBytes, "mlp_backward");
     if (attr != SNERF_OK) return attr;
     hipLaunchKernelGGL(kernel, dim3((unsigned)table.wg_start[table.count]), dim3(256), lds_bytes, stream, table,
                        reinterpret_cast<const unsigned short*>(grads), reinterpret_cast<const unsigned short*>(acts), partial,

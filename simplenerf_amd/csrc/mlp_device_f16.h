@@ -542,8 +542,9 @@ __device__ __forceinline__ void store_pieces(const f16x8 (&frag)[NB], _Float16* 
 // 2^-9 .. 448 with four significant bits from 2^-6 up; post-ReLU activations above 448 are CLAMPED there (in this operand of the
 // weight gradients only: v_cvt_scalef32_pk_fp8_f16 returns NaN above the range, tools/probes/cvt_fp8_scale.hip), values
 // below 2^-10 contribute nothing -- as they would not to the sum.  A tile (two k-steps) becomes one KiB: slot = 2 * sample +
-// lane half holds 16 bytes, k-step 2u's eight elements then k-step 2u+1's, stored where the tile's FIRST 16-bit piece would be
-// (the second piece's KiB stays unused: same row numbers for every format).  The weight-gradient kernel reads it back
+// lane half holds 16 bytes, k-step 2u's eight elements then k-step 2u+1's; tile after tile and layer after layer PACKED from
+// where h_1's 16-bit rows would begin (one-KiB images with one-KiB holes between them, i.e. the 16-bit row numbers, read back
+// SLOWER than the 16-bit pieces: half of every two KiB never requested).  The weight-gradient kernel reads it back
 // transposed with ds_read_b64_tr_b8 and widens with v_cvt_scalef32_pk_f16_fp8 (mlp_backward.hip).
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -566,7 +567,7 @@ __device__ __forceinline__ void store_pieces8(const f16x8 (&frag)[NB], _Float16*
                 p = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p, __builtin_elementwise_min(f16x2{f[4 * d + 2], f[4 * d + 3]}, top), 1.0f, true);
                 w[2 * k + d] = __builtin_bit_cast(unsigned, p);
             }
-        __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(rows + (2 * u) * 512 + slot * 8));
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(rows + u * 512 + slot * 8));
     }
 }
 

@@ -65,6 +65,9 @@ template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P, int DE
 __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(HalfArgs args) {
     static_assert(!BF || P == 1, "bf16 operands: single-product kernels only");
     static_assert(!S8 || (P == 1 && !BF && STORE), "8-bit saved activations: the fp16 single-product training forward");
+    // (only the 256-wide trunk: its weight-gradient products are the large register-tile class, the one built to read fp8 tiles;
+    // a 128-wide MLP's are folded into the small-job launch and keep fp16 activations -- for it this mode IS the fp16 mode)
+    constexpr bool SAVE8 = S8 && WT == 8;
     constexpr int NW = P == 1 ? 8 : 4;   // waves per workgroup (see UnitStreamT)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const MlpArgs& a = args.m;
@@ -182,7 +185,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         else split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
     }
     if (STORE16) {
-        if (S8 && depth > 1) { store_pieces8<HK>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK / 2); }   // h_1
+        if (SAVE8 && depth > 1) { store_pieces8<HK>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK / 2); }   // h_1
         else { store_pieces<HK>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK); }
     }
 
@@ -218,7 +221,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         }
         if (STORE16) {
             // (h_D, the last trunk tensor, stays fp16: it also feeds the small head products)
-            if (S8 && !last) { store_pieces8<HK>(xh, tile16 + (a.act_h1 + l * a.width) * 32, lane); st.note_vmem(HK / 2); }
+            if (SAVE8 && !last) { store_pieces8<HK>(xh, tile16 + a.act_h1 * 32 + l * (WT * 512), lane); st.note_vmem(HK / 2); }
             else { store_pieces<HK>(xh, tile16 + (a.act_h1 + l * a.width) * 32, lane); st.note_vmem(HK); }
         }
     };
