@@ -533,10 +533,12 @@ SNERF_STAMP_DEFINE(wgrad16)
 constexpr int kPairBytes = 2304;   // LDS image of one 32-row tile: piece 0 at +0, piece 1 at +1152 (bank phase +32 dwords:
 constexpr int kPieceGap = 1152;    // the two 16-lane groups of a half-wave read different pieces of the same tile)
 constexpr int kWgrad16Buffers = 3;
-#ifdef SNERF_PROBE_RING4        // ablation: a fourth slot for the 8-bit instance (measured: +0.23 ms per config-5 iteration)
-constexpr int wgrad16_ring(bool x8) { return x8 ? 4 : kWgrad16Buffers; }
+#if defined(SNERF_PROBE_RING4)  // ablation: a fourth slot for the 8-bit instance (measured: +0.23 ms per config-5 iteration)
+constexpr int wgrad16_ring(bool x8, bool) { return x8 ? 4 : kWgrad16Buffers; }
+#elif defined(SNERF_PROBE_SMALL_RING)   // ablation: that many slots for the small-job launch (4: 107 -> 138 us, 5: 140 us)
+constexpr int wgrad16_ring(bool, bool partial) { return partial ? SNERF_PROBE_SMALL_RING : kWgrad16Buffers; }
 #else
-constexpr int wgrad16_ring(bool) { return kWgrad16Buffers; }
+constexpr int wgrad16_ring(bool, bool) { return kWgrad16Buffers; }
 #endif
 
 // PARTIAL: the small head / encoding jobs -- (8 x 2), (1 x 8), (4 x 1) and (1 x 4) tiles for the main MLP -- share ONE launch
@@ -734,8 +736,10 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     // two slots hold the block being read and the block that has landed for the next half-block), and a block's round trip
     // under load is ~1.2 us whether it is 32 or 24 KiB.  More in flight did NOT help once the arithmetic is there: a fourth
     // slot (SNERF_PROBE_RING4: 209 us without the arithmetic, 256-260 us with it) and the same three slots refilled one
-    // barrier earlier (SNERF_PROBE_DEEP: 255 us for 16-bit X, 243 us for 8-bit X) -- cause not found.
-    constexpr int RING = wgrad16_ring(X8);
+    // barrier earlier (SNERF_PROBE_DEEP: 255 us for 16-bit X, 243 us for 8-bit X); the small-job launch loses 30 % with a
+    // fourth or fifth slot (SNERF_PROBE_SMALL_RING).  Cause not found: more LDS-DMA in flight per wave is faster alone and
+    // slower as soon as the same waves read LDS and multiply.
+    constexpr int RING = wgrad16_ring(X8, PARTIAL);
     constexpr bool OVERLAP = !PARTIAL && NO * NI >= 8;       // (the schedule below)
     // The serial schedule reads block n's second k-step after the mid-block barrier, so block n's slot cannot be refilled
     // there: AHEAD = RING - 1.  In the overlapped schedule every read of block n has LANDED before that barrier (they are
@@ -1151,10 +1155,10 @@ template <int NO, int NI, bool PARTIAL = false, bool BF = false, bool X8 = false
 int launch_wgrad16(const JobTable& table, const float* grads, const float* acts, float* partial, hipStream_t stream) {
     int max_tiles = 0;
     for (int j = 0; j < table.count; ++j) max_tiles = std::max(max_tiles, table.jobs[j].out_tiles + table.jobs[j].in_tiles);
-    const size_t lds_bytes = (size_t)wgrad16_ring(X8) * max_tiles * kPairBytes;
+    const size_t lds_bytes = (size_t)wgrad16_ring(X8, PARTIAL) * max_tiles * kPairBytes;
     auto kernel = wgrad16_kernel<NO, NI, PARTIAL, BF, X8>;
     static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
-    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), wgrad16_ring(X8) * 16 * kPairBytes, "mlp_backward");
+    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), wgrad16_ring(X8, PARTIAL) * (PARTIAL ? 10 : 16) * kPairBytes, "mlp_backward");
     if (attr != SNERF_OK) return attr;
     hipLaunchKernelGGL(kernel, dim3((unsigned)table.wg_start[table.count]), dim3(256), lds_bytes, stream, table,
                        reinterpret_cast<const unsigned short*>(grads), reinterpret_cast<const unsigned short*>(acts), partial,

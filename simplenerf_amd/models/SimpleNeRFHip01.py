@@ -16,7 +16,12 @@ One extra, optional config key: ``configs['model']['hip_precision']`` = ``'fp32'
 ``'f16x3'`` (fp16 hi/lo split, three MFMAs per product, fp32 accumulate: fp32-grade results ~2.5x faster; covers the
 forward, the activation-keeping training forward, the backward dgrad chain and the large weight-gradient products), or
 ``'f16'`` (16-bit mode: one fp16 MFMA per product, 16-bit saved activations / layer gradients, fp32 master weights and
-accumulation; ~4x faster training than fp32 at ~1e-3 agreement -- outside the fp32 parity bar, tests/test_gpu_f16.py).
+accumulation; ~4x faster training than fp32 at ~1e-3 agreement -- outside the fp32 parity bar, tests/test_gpu_f16.py),
+``'bf16'`` (the 16-bit mode on bf16 operands: no range limit, three significand bits fewer, tests/test_gpu_bf16.py) or
+``'f16s8'`` (the fp16 16-bit mode with the saved trunk activations of 256-wide MLPs kept as fp8 e4m3 for the weight
+gradients: rendering and the forward are ``'f16'``'s bit for bit, the training iteration moves 15 % fewer HBM bytes).
+``configs['model']['hip_fused_render']`` = ``True``: eval-mode renders of a plain coarse + fine fp32 model as one launch
+(csrc/render_fused.hip; bit-identical, off by default).
 
 Differences from the reference that a caller can observe:
   * ``model.chunk`` / ``model.netchunk`` are accepted and ignored -- the kernels tile the work themselves and the
