@@ -173,6 +173,12 @@ struct WgradJob {
                                         // pe_index(p) and only indices in [feat_lo, feat_hi) belong to this job
     int feat_lo, feat_hi;
     int x8;                             // SNERF_PRECISION_F16S8: X is an 8-bit (fp8 e4m3) tile image (mlp_device_f16.h store_pieces8)
+    // 16-bit modes: a skinny product over the SAME dY rows rides in this job as extra X tiles -- the last x2_tiles of in_tiles
+    // come from rows x2_row0 (a whole encoding tile) -- instead of streaming dY a second time from a job of its own ...
+    int x2_row0, x2_tiles;
+    // ... and that product's own entry stays in the table for the reduction only (launched = 0), as a VIEW of this job's
+    // partial sums: partial_ld floats per row (0: in_tiles * 32), its columns from partial_col0
+    int launched, partial_ld, partial_col0;
 };
 
 // Encoding index held at position p of a 16-bit encoding tile (forward: store_pieces of the pe_h fragments), or -1.
@@ -616,6 +622,11 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
                 if (job.out_tiles >= 4 && (q & 1)) { src = reinterpret_cast<const char*>(zeros + 192); stride = 0; }
 #endif
             }
+        } else if (!x8 && job.x2_tiles > 0 && q - pieces_dy >= 2 * (job.in_tiles - job.x2_tiles)) {
+            // the rider's X tiles (WgradJob::x2_row0): whole encoding tiles
+            src = reinterpret_cast<const char*>(acts + ((b0 * job.act_rows + job.x2_row0) * 32 +
+                                                        (q - pieces_dy - 2 * (job.in_tiles - job.x2_tiles)) * 512));
+            stride = (long long)job.act_rows * 64;
         } else if (q - pieces_dy < x_pieces_real) {
             // (8-bit tile images are one KiB each, packed: WgradJob::x_row0 already counts them so)
             src = reinterpret_cast<const char*>(acts + ((b0 * job.act_rows + job.x_row0) * 32 + (q - pieces_dy) * 512));
@@ -942,7 +953,7 @@ __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float
         job.half ? 1.0f / wgrad_scale(region_max(partial, job.dy_row0 / 32)) : 1.0f;
     float* __restrict__ grad_w = ptrs.p[job.w_param];
     float* __restrict__ grad_b = job.b_param >= 0 ? ptrs.p[job.b_param] : nullptr;
-    const int in_cols = job.in_tiles * 32, rows_dy = job.out_tiles * 32;
+    const int in_cols = job.partial_ld ? job.partial_ld : job.in_tiles * 32, rows_dy = job.out_tiles * 32;
     const long long nw = (long long)job.out_rows * job.in_rows;
     const long long total = nw + (grad_b ? job.out_rows : 0);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -957,7 +968,7 @@ __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float
             if (idx < nw) {
                 o = (int)(idx / job.in_rows);
                 i = (int)(idx - (long long)o * job.in_rows);
-                p = partial + job.partial_off + (long long)(o + job.dy_skip) * in_cols + i;
+                p = partial + job.partial_off + (long long)(o + job.dy_skip) * in_cols + job.partial_col0 + i;
                 stride = (long long)rows_dy * in_cols;
             } else {
                 o = (int)(idx - nw);
@@ -1054,6 +1065,7 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
         j.x8 = (s8 && p.wt == 8 && x_kind == snerf::SEG_ACC && x_row0 >= p.act_h(1) && x_row0 < p.act_h(p.depth)) ? 1 : 0;
         // ... packed: layer l's eight KiB tiles follow layer l-1's, from where h_1's 16-bit rows would begin (64-byte rows)
         if (j.x8) j.x_row0 = p.act_h(1) + (x_row0 - p.act_h(1)) / 2;
+        j.x2_row0 = 0; j.x2_tiles = 0; j.launched = 1; j.partial_ld = 0; j.partial_col0 = 0;
         w.jobs.push_back(j);
     };
     const int d = p.depth, wd = p.width;
@@ -1077,6 +1089,24 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
         add(p.grad_head() + 1, 3, p.act_hv(), p.views_width, 2 * d + 6, p.views_width, 0, 2 * d + 7);  // views_output_linear
     } else {
         add(p.grad_head(), 4, p.act_h(d), wd, 2 * d, wd, 0, 2 * d + 1);                      // pts_output_linear (4 rows)
+    }
+    // 16-bit modes: views_linears.0 | view-direction encoding (4 x 1 tiles: 8 KiB of dY and 2 KiB of X per block, in the
+    // small-job launch) becomes a ninth X tile of views_linears.0 | feature, which streams the same dY.
+    // (Measured and NOT kept: the density head (1 x 8 tiles over h_D) as a VALU side sum inside feature_linear's workgroups --
+    // ~100 VALU per k-step there made the large launch 67 us slower for 17 us less in the small one.)
+    if (f16) {
+        for (WgradJob& host : w.jobs) {
+            if (host.x_kind != snerf::SEG_ACC || host.out_tiles != 4 || host.in_tiles != 8 || host.dy_skip != 0) continue;
+            for (WgradJob& rider : w.jobs) {
+                if (rider.x_kind != snerf::SEG_VIEWS_PE || rider.dy_row0 != host.dy_row0 || rider.out_rows != host.out_rows ||
+                    rider.dy_skip != 0 || rider.in_tiles != 1 || rider.launched == 0 || host.x2_tiles != 0)
+                    continue;
+                host.x2_row0 = rider.x_row0; host.x2_tiles = rider.in_tiles;
+                rider.launched = 0; rider.partial_col0 = host.in_tiles * 32;
+                host.in_tiles += rider.in_tiles;
+                rider.partial_ld = host.in_tiles * 32;
+            }
+        }
     }
     // heaviest products first, so the tail of the single launch is made of the small head/encoding jobs
     std::stable_sort(w.jobs.begin(), w.jobs.end(), [](const WgradJob& a, const WgradJob& b) {
@@ -1109,10 +1139,18 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
         if (chunks > cap) chunks = cap;
         if (chunks < 1) chunks = 1;
         j.chunks = (int)chunks;
+        if (!j.launched) continue;        // (a view of its host's partial sums: below)
         j.partial_off = off;
         off += chunks * j.out_tiles * 32 * j.in_tiles * 32;
         j.bias_off = off;
         off += chunks * j.out_tiles * 32;
+    }
+    for (WgradJob& rider : w.jobs) {
+        if (rider.launched) continue;
+        for (const WgradJob& host : w.jobs)
+            if (host.launched && host.x2_tiles > 0 && host.dy_row0 == rider.dy_row0 && host.x2_row0 == rider.x_row0) {
+                rider.chunks = host.chunks; rider.partial_off = host.partial_off; rider.bias_off = host.bias_off;
+            }
     }
     w.partial_floats = off;
     w.total_floats = w.grads_floats + w.partial_floats;
@@ -1281,7 +1319,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
         const long long work = (long long)jobs[j].out_rows * jobs[j].in_rows + jobs[j].out_rows;
         if (work > max_work) max_work = work;
     }
-    static const int classes[][2] = {{2, 8}, {2, 2}, {2, 1}, {1, 8}, {1, 4}, {1, 2}, {1, 1}};
+    static const int classes[][2] = {{2, 8}, {2, 2}, {2, 1}, {1, 9}, {1, 8}, {1, 4}, {1, 2}, {1, 1}};   // ({1, 9}: 16-bit modes only)
     // 16-bit mode: every small job (fewer than 32 tile products: heads, encodings) rides in ONE launch of the <2, 2> instance
     // with partial register tiles (wgrad16_kernel PARTIAL) instead of one launch per register-tile class
 #ifdef SNERF_PROBE_NO_SMALL_FOLD     // A/B probe builds: one launch per register-tile class, as before round 3
@@ -1303,7 +1341,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
         sub.count = 0;
         sub.wg_start[0] = 0;
         for (const WgradJob& job : jobs) {
-            if (!small16(job)) continue;
+            if (!small16(job) || !job.launched) continue;
             sub.jobs[sub.count] = job;
             sub.wg_start[sub.count + 1] = sub.wg_start[sub.count] + job.chunks;
             ++sub.count;
@@ -1321,7 +1359,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
         for (const WgradJob& job : jobs) {
             int no, ni;
             wave_tile(job, &no, &ni);
-            if (no != cls[0] || ni != cls[1] || small16(job)) continue;
+            if (no != cls[0] || ni != cls[1] || small16(job) || !job.launched) continue;
             sub.jobs[sub.count] = job;
             sub.wg_start[sub.count + 1] = sub.wg_start[sub.count] + job.chunks;
             ++sub.count;
@@ -1332,6 +1370,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
             if (cls[0] == 2 && cls[1] == 8) rc = launch_wgrad16<2, 8, false, true>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 2 && cls[1] == 2) rc = launch_wgrad16<2, 2, false, true>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 2 && cls[1] == 1) rc = launch_wgrad16<2, 1, false, true>(sub, grads, saved_acts, partial, s);
+            else if (cls[0] == 1 && cls[1] == 9) rc = launch_wgrad16<1, 9, false, true>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 1 && cls[1] == 8) rc = launch_wgrad16<1, 8, false, true>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 1 && cls[1] == 4) rc = launch_wgrad16<1, 4, false, true>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 1 && cls[1] == 2) rc = launch_wgrad16<1, 2, false, true>(sub, grads, saved_acts, partial, s);
@@ -1342,6 +1381,7 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
                                                     : launch_wgrad16<2, 8>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 2 && cls[1] == 2) rc = launch_wgrad16<2, 2>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 2 && cls[1] == 1) rc = launch_wgrad16<2, 1>(sub, grads, saved_acts, partial, s);
+            else if (cls[0] == 1 && cls[1] == 9) rc = launch_wgrad16<1, 9>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 1 && cls[1] == 8) rc = launch_wgrad16<1, 8>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 1 && cls[1] == 4) rc = launch_wgrad16<1, 4>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 1 && cls[1] == 2) rc = launch_wgrad16<1, 2>(sub, grads, saved_acts, partial, s);
