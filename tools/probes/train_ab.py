@@ -30,6 +30,7 @@ precision = sys.argv[2] if len(sys.argv) > 2 else 'f16'
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(dev)
-ms, fwd, bwd, rows = bench.time_training(precision, dev, steps, 3)
+with bench.BoardSampler(0) as sampler:       # board power and shader clock during the run (sysfs, every 20 ms)
+    ms, fwd, bwd, rows = bench.time_training(precision, dev, steps, 3)
 print(json.dumps({'lib': os.path.basename(sys.argv[1]), 'precision': precision, 'ms_per_iteration': ms, 'mlp_forward_ms': fwd,
-                  'mlp_backward_ms': bwd, 'step_ms_p50': bench.time_training.timing['step_ms']['p50']}))
+                  'mlp_backward_ms': bwd, 'step_ms_p50': bench.time_training.timing['step_ms']['p50'], 'board': sampler.summary()}))
