@@ -741,15 +741,13 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
     SNERF_STAMP_BEGIN();
     FragSet even, odd;
     int stage_slot = 0, read_slot = 0;                       // ring positions of the next block to request / to read
-    // RING slots, AHEAD blocks requested before the first is used.  What the large class is bound by (config 5, round 4):
-    // with the MFMAs and LDS reads compiled out (SNERF_PROBE_WGRAD_NOMATH) the block stream alone takes 257 us (16-bit X) /
-    // 233 us (8-bit X) of the 260 / 237 us the kernels take -- ONE block per CU is in flight at a time (the ring's other
-    // two slots hold the block being read and the block that has landed for the next half-block), and a block's round trip
-    // under load is ~1.2 us whether it is 32 or 24 KiB.  More in flight did NOT help once the arithmetic is there: a fourth
-    // slot (SNERF_PROBE_RING4: 209 us without the arithmetic, 256-260 us with it) and the same three slots refilled one
-    // barrier earlier (SNERF_PROBE_DEEP: 255 us for 16-bit X, 243 us for 8-bit X); the small-job launch loses 30 % with a
-    // fourth or fifth slot (SNERF_PROBE_SMALL_RING).  Cause not found: more LDS-DMA in flight per wave is faster alone and
-    // slower as soon as the same waves read LDS and multiply.
+    // RING slots, AHEAD blocks requested before the first is used.  What the large class is bound by (config 5, round 4;
+    // tools/probes/lds_dma_depth.hip is this kernel's skeleton): 16-bit X, 32-KiB blocks -- the stream itself, 6.6 TB/s with
+    // this addressing (244 us + the launch's fixed costs: ramp, 64 MiB of partial sums at the end = the measured 260); 8-bit X,
+    // 24-KiB blocks -- one wave's chain of LDS-read latency and 32 MFMAs per block, ~1.1 us (215 us + fixed costs = 237), not
+    // its bytes (181 us).  More blocks in flight are neutral in the skeleton and LOSE in this kernel: a fourth slot
+    // (SNERF_PROBE_RING4) 256-260 us, the same three slots refilled one barrier earlier (SNERF_PROBE_DEEP) 243 us (255 for
+    // 16-bit X), the small-job launch 107 -> 138 us with a fourth or fifth slot (SNERF_PROBE_SMALL_RING).  Not explained.
     constexpr int RING = wgrad16_ring(X8, PARTIAL);
     constexpr bool OVERLAP = !PARTIAL && NO * NI >= 8;       // (the schedule below)
     // The serial schedule reads block n's second k-step after the mid-block barrier, so block n's slot cannot be refilled

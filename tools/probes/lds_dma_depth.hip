@@ -1,0 +1,177 @@
+// the 16-bit weight-gradient kernels stream one block per CU and round trip, and got SLOWER with more
+// blocks in flight as soon as the same waves read LDS and multiply.  This probe is that kernel's skeleton with every part
+// switchable: one 256-thread workgroup per CU (a ring of RING slots in LDS fills the CU), each wave requests P one-KiB pieces
+// per block by LDS-DMA (global_load_lds_dwordx4), AHEAD blocks are requested before the first is used; per half block a wave
+// issues READS transposed LDS reads (ds_read_b64_tr_b16) of the block that has landed and MFMAS v_mfma_f32_32x32x16_f16.
+// Prints microseconds per block and the HBM rate for AHEAD = 2, 3, 4 x {stream only, + reads, + MFMAs, + both}.
+//   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/lds_dma_depth tools/probes/lds_dma_depth.hip && gpurun_out/lds_dma_depth
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void lds_dma(const void* uniform_base, unsigned lane_byte_offset, unsigned lds_byte_address) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds_byte_address), "v"(lane_byte_offset),
+                 "s"(uniform_base)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ u32x2 read_tr16(unsigned addr, int off) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(off) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void wait_vm() {
+#define W(K) if (N == K) asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory");
+    W(0) W(6) W(8) W(12) W(16) W(18) W(24)
+#undef W
+}
+
+// LAYOUT 0: block n of workgroup w is one contiguous 4 P KiB run, the workgroups' runs adjacent (the ideal stream).
+// LAYOUT 1: as the weight-gradient jobs address their operands -- 8 jobs x 32 chunks; a block holds every layer's tiles
+//   ([block][layer][tile]: 144 KiB of gradients, 176 KiB of activations per block); job j reads 16 KiB of dY and (P = 6: 8 KiB of
+//   fp8 / P = 8: 16 KiB of fp16) X out of each of its chunk's consecutive blocks.
+// LAYOUT 2: the same bytes layer-major ([layer][block][tile]): a job's consecutive blocks are adjacent in memory.
+template <int P, int AHEAD, bool READS, bool MFMAS, int LAYOUT = 0>
+__global__ void __launch_bounds__(256, 1) stream_kernel(const char* __restrict__ src, float* out, int nblocks, long long block_stride) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int RING = AHEAD + 1, SLOT = 4 * P * 1024;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds;
+    const char* mine = src + (long long)blockIdx.x * 4 * P * 1024 + (long long)wave * P * 1024;   // block n of this workgroup: + n * block_stride
+    // LAYOUT 1 / 2: piece q = wave + 4 k of a block: q < 16 -> dY piece q, else X piece q - 16
+    constexpr long long kGradBlock = 144 * 1024, kActBlock = 176 * 1024, kBlocks = 32 * 192, kActs0 = kGradBlock * kBlocks;
+    const int job = blockIdx.x >> 5, chunk = blockIdx.x & 31;
+    const long long x_tile_bytes = (4 * P - 16) * 1024;      // X bytes of one block and job
+    const char* piece[P];
+    long long piece_stride[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const int q = wave + 4 * k;
+        const long long b0 = (long long)chunk * nblocks;
+        if (LAYOUT == 1) {
+            piece[k] = q < 16 ? src + b0 * kGradBlock + job * 16384 + q * 1024
+                              : src + kActs0 + b0 * kActBlock + 6144 + job * x_tile_bytes + (q - 16) * 1024;
+            piece_stride[k] = q < 16 ? kGradBlock : kActBlock;
+        } else {
+            piece[k] = q < 16 ? src + (job * kBlocks + b0) * 16384 + q * 1024
+                              : src + kActs0 + (job * kBlocks + b0) * x_tile_bytes + (q - 16) * 1024;
+            piece_stride[k] = q < 16 ? 16384 : x_tile_bytes;
+        }
+    }
+    int stage_slot = 0, read_slot = 0;
+    auto stage = [&]() {
+        if (LAYOUT == 0) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) lds_dma(mine + k * 1024, lane * 16, lds_base + stage_slot * SLOT + (wave * P + k) * 1024);
+            mine += block_stride;
+        } else {
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                lds_dma(piece[k], lane * 16, lds_base + stage_slot * SLOT + (wave * P + k) * 1024);
+                piece[k] += piece_stride[k];
+            }
+        }
+        stage_slot = stage_slot == RING - 1 ? 0 : stage_slot + 1;
+    };
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    f16x8 a = {1, 2, 3, 4, 5, 6, 7, 8}, b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = a;
+    unsigned sink = 0;
+    const unsigned lane_off = lane * 8;
+    auto half_block = [&](int slot, int kk) {
+        if (READS) {
+            const unsigned base = lds_base + slot * SLOT + kk * 512 + lane_off;
+            u32x2 v[20];
+#pragma unroll
+            for (int i = 0; i < 20; ++i) v[i] = read_tr16(base, (i % (4 * P)) * 1024);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 20; ++i) { asm volatile("" : "+v"(v[i])); sink ^= v[i][0] ^ v[i][1]; }
+            if (MFMAS) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) b[i][0] = (_Float16)(float)(v[i][0] & 1);
+            }
+        }
+        if (MFMAS) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[i & 7], acc[i & 7], 0, 0, 0);
+        }
+    };
+    for (int k = 0; k < AHEAD && k < nblocks; ++k) stage();
+    wait_vm<(AHEAD - 1) * P>();
+    __builtin_amdgcn_s_barrier();
+    for (int n = 0; n < nblocks; ++n) {
+        half_block(read_slot, 0);
+        if (n + 1 < nblocks) {
+            // block n+1 is in for every wave; the AHEAD - 2 blocks behind it stay in flight (the tail waits for everything)
+            if (n + AHEAD <= nblocks) wait_vm<(AHEAD - 2) * P>(); else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            if (n + AHEAD < nblocks) stage();
+        }
+        half_block(read_slot, 1);
+        read_slot = read_slot == RING - 1 ? 0 : read_slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = (float)sink;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0];
+    if (s == 1234.5f) out[0] = s;
+}
+
+template <int P, int AHEAD, bool READS, bool MFMAS, int LAYOUT = 0>
+void run(const char* src, float* out, size_t bytes) {
+    const int wgs = 256, nblocks = 192;
+    const long long block_stride = (long long)wgs * 4 * P * 1024;
+    if ((size_t)block_stride * nblocks > bytes) { printf("buffer too small\n"); return; }
+    auto k = stream_kernel<P, AHEAD, READS, MFMAS, LAYOUT>;
+    const int lds_bytes = (AHEAD + 1) * 4 * P * 1024;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        printf("P = %d, ring %d: %d KiB of LDS refused\n", P, AHEAD + 1, lds_bytes / 1024);
+        return;
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, dim3(wgs), dim3(256), lds_bytes, 0, src, out, nblocks, block_stride);
+    hipDeviceSynchronize();
+    const int reps = 8;
+    hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k, dim3(wgs), dim3(256), lds_bytes, 0, src, out, nblocks, block_stride);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / reps, tb = (double)block_stride * nblocks / (us * 1e-6) * 1e-12;
+    printf("layout %d, P = %d (%2d KiB blocks), %d in flight behind the awaited block, ring %d (%3d KiB LDS)%s%s: %7.1f us per launch, %.3f us per block, %.2f TB/s\n",
+           LAYOUT, P, 4 * P, AHEAD - 1, AHEAD + 1, lds_bytes / 1024, READS ? " + 40 tr16 reads" : "", MFMAS ? " + 32 MFMAs" : "", us, us / nblocks, tb);
+}
+
+template <int P>
+void sweep(const char* src, float* out, size_t bytes) {
+    run<P, 2, false, false>(src, out, bytes); run<P, 2, true, false>(src, out, bytes); run<P, 2, false, true>(src, out, bytes); run<P, 2, true, true>(src, out, bytes);
+    run<P, 3, false, false>(src, out, bytes); run<P, 3, true, false>(src, out, bytes); run<P, 3, false, true>(src, out, bytes); run<P, 3, true, true>(src, out, bytes);
+    run<P, 4, false, false>(src, out, bytes); run<P, 4, true, false>(src, out, bytes); run<P, 4, false, true>(src, out, bytes); run<P, 4, true, true>(src, out, bytes);
+}
+
+int main() {
+    const size_t bytes = (size_t)(144 + 176) * 1024 * 32 * 192;      // 1.9 GiB: the gradient and the activation tensors of LAYOUT 1
+    char* src; float* out;
+    if (hipMalloc(&src, bytes) != hipSuccess || hipMalloc(&out, 4) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+    hipMemset(src, 0, bytes);
+    run<8, 2, false, false>(src, out, bytes);   // warm-up
+    sweep<8>(src, out, bytes);
+    sweep<6>(src, out, bytes);
+    // the weight-gradient jobs' addressing against the same bytes layer-major, stream alone and with the arithmetic
+    run<8, 2, false, false, 1>(src, out, bytes); run<8, 2, true, true, 1>(src, out, bytes);
+    run<8, 2, false, false, 2>(src, out, bytes); run<8, 2, true, true, 2>(src, out, bytes);
+    run<6, 2, false, false, 1>(src, out, bytes); run<6, 2, true, true, 1>(src, out, bytes);
+    run<6, 2, false, false, 2>(src, out, bytes); run<6, 2, true, true, 2>(src, out, bytes);
+    run<8, 3, false, false, 1>(src, out, bytes); run<8, 3, true, true, 1>(src, out, bytes);
+    run<6, 3, false, false, 1>(src, out, bytes); run<6, 3, true, true, 1>(src, out, bytes);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
