@@ -4,9 +4,11 @@
 // of their own that no kernel reads and no output depends on them; in the shipped build every macro below is empty.
 #pragma once
 #ifdef SNERF_CLOCK_STAMP
+// (a kernel header included by several translation units defines its stamps in each of them: the buffer is per unit and the
+// accessor weak -- it reads the unit the linker kept, which is the kernel's own when only one unit holds the stamped kernel)
 #define SNERF_STAMP_DEFINE(name)                                                                                          \
-    __device__ unsigned long long name##_stamps[2 * 8192];                                                                \
-    extern "C" int snerf_debug_clock_stamps_##name(unsigned long long* host, int pairs) {                                 \
+    static __device__ unsigned long long name##_stamps[2 * 8192];                                                         \
+    extern "C" __attribute__((weak)) int snerf_debug_clock_stamps_##name(unsigned long long* host, int pairs) {           \
         return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(name##_stamps), sizeof(unsigned long long) * 2 * (pairs < 8192 ? pairs : 8192)); \
     }
 #define SNERF_STAMP_BEGIN() \

@@ -557,6 +557,10 @@ constexpr int wgrad16_ring(bool, bool) { return kWgrad16Buffers; }
 // X8 (SNERF_PRECISION_F16S8; the large class only): a job with x8 set reads its X operand from fp8 tiles -- one KiB per
 // tile and block instead of two, one ds_read_b64_tr_b8 per fragment instead of two tr_b16, four v_cvt_scalef32_pk_f16_fp8 --
 // and stores its columns through the tile's byte order.
+// (Two waves per SIMD for the 8-bit-X instance -- <2, 4> register tiles on a 4 x 2 wave grid, 128 accumulators, so that one
+// wave's LDS-read latency and conversions run under the other's MFMAs -- take a 24-KiB block from 1.12 to 0.96 us in the kernel's
+// skeleton, tools/probes/lds_dma_depth.hip, and measured the SAME as this instance in the kernel: 101 / 102 us per workgroup
+// of one launch.  Not kept.)
 template <int NO, int NI, bool PARTIAL = false, bool BF = false, bool X8 = false>
 __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const unsigned short* __restrict__ grads,
                                                          const unsigned short* __restrict__ acts, float* __restrict__ partial,
@@ -1122,13 +1126,19 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
         wave_tile(j, &no, &ni);
         long long chunks, cap;
         if (j.out_tiles * j.in_tiles >= 32) {
-            int peers = 0;
+            // ... shared among the jobs of the launch in proportion to the bytes a block of theirs streams (an 8-bit X
+            // operand makes a block 24 KiB instead of 32): the launch ends with its slowest job, and with equal shares that
+            // was feature_linear, whose X (h_D) stays 16-bit, 260 us, however fast the seven fp8 jobs ran
+            long long peers_weight = 0;
+            // (measured with in-kernel stamps, config 5, two boxes: a block of 24 KiB costs its workgroup 0.76 / 0.87 of what
+            // one of 32 KiB does -- tools/probes/wgrad_wg_times.py; 0.80 here)
+            auto weight = [](const WgradJob& k) { return 20 * k.out_tiles + (k.x8 ? 12 : 20) * k.in_tiles; };
             for (const WgradJob& k : w.jobs) {
                 int ko, ki;
                 wave_tile(k, &ko, &ki);
-                peers += (ko == no && ki == ni && k.out_tiles * k.in_tiles >= 32);
+                if (ko == no && ki == ni && k.out_tiles * k.in_tiles >= 32 && k.launched) peers_weight += weight(k);
             }
-            chunks = 256 / peers;   // rounded DOWN: 7 jobs x 37 chunks = 259 workgroups ran as 256 + a second round of 3
+            chunks = 256 * weight(j) / peers_weight;   // rounded DOWN: 7 jobs x 37 chunks = 259 workgroups ran as 256 + a second round of 3
             cap = blocks / 8;
         } else {
             chunks = kSmallJobChunks;
@@ -1137,11 +1147,34 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
         if (chunks > cap) chunks = cap;
         if (chunks < 1) chunks = 1;
         j.chunks = (int)chunks;
+    }
+    // what the rounding left of the 256 goes, one workgroup each, to the large class's lightest jobs (first in the table
+    // among equals): 7 fp8 jobs x 30 + 38 = 248 becomes 7 x 31 + 38 + 1
+    {
+        int used = 0, members = 0;
+        for (const WgradJob& j : w.jobs) {
+            int no, ni;
+            wave_tile(j, &no, &ni);
+            if (no == 2 && ni == 8 && j.launched && j.out_tiles * j.in_tiles >= 32) { used += j.chunks; ++members; }
+        }
+        for (int spare = 256 - used; members > 1 && spare > 0;) {
+            bool given = false;
+            for (int light = 1; light >= 0 && spare > 0; --light)
+                for (WgradJob& j : w.jobs) {
+                    int no, ni;
+                    wave_tile(j, &no, &ni);
+                    if (no != 2 || ni != 8 || !j.launched || j.out_tiles * j.in_tiles < 32 || (j.x8 != 0) != (light != 0)) continue;
+                    if (spare > 0 && j.chunks < blocks / 8) { ++j.chunks; --spare; given = true; }
+                }
+            if (!given) break;
+        }
+    }
+    for (WgradJob& j : w.jobs) {
         if (!j.launched) continue;        // (a view of its host's partial sums: below)
         j.partial_off = off;
-        off += chunks * j.out_tiles * 32 * j.in_tiles * 32;
+        off += (long long)j.chunks * j.out_tiles * 32 * j.in_tiles * 32;
         j.bias_off = off;
-        off += chunks * j.out_tiles * 32;
+        off += (long long)j.chunks * j.out_tiles * 32;
     }
     for (WgradJob& rider : w.jobs) {
         if (rider.launched) continue;

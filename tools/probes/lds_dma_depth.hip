@@ -24,7 +24,7 @@ __device__ __forceinline__ u32x2 read_tr16(unsigned addr, int off) {
 }
 template <int N> __device__ __forceinline__ void wait_vm() {
 #define W(K) if (N == K) asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory");
-    W(0) W(6) W(8) W(12) W(16) W(18) W(24)
+    W(0) W(3) W(4) W(6) W(8) W(9) W(12) W(16) W(18) W(24)
 #undef W
 }
 
@@ -33,23 +33,24 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 //   ([block][layer][tile]: 144 KiB of gradients, 176 KiB of activations per block); job j reads 16 KiB of dY and (P = 6: 8 KiB of
 //   fp8 / P = 8: 16 KiB of fp16) X out of each of its chunk's consecutive blocks.
 // LAYOUT 2: the same bytes layer-major ([layer][block][tile]): a job's consecutive blocks are adjacent in memory.
-template <int P, int AHEAD, bool READS, bool MFMAS, int LAYOUT = 0>
-__global__ void __launch_bounds__(256, 1) stream_kernel(const char* __restrict__ src, float* out, int nblocks, long long block_stride) {
+// NW = 8: the same block handled by eight waves (two per SIMD), half the pieces, reads and MFMAs each.
+template <int P, int AHEAD, bool READS, bool MFMAS, int LAYOUT = 0, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, 1) stream_kernel(const char* __restrict__ src, float* out, int nblocks, long long block_stride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int RING = AHEAD + 1, SLOT = 4 * P * 1024;
+    constexpr int RING = AHEAD + 1, SLOT = 4 * P * 1024, PW = P * 4 / NW;   // PW pieces per wave
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds;
-    const char* mine = src + (long long)blockIdx.x * 4 * P * 1024 + (long long)wave * P * 1024;   // block n of this workgroup: + n * block_stride
+    const char* mine = src + (long long)blockIdx.x * 4 * P * 1024 + (long long)wave * PW * 1024;   // block n of this workgroup: + n * block_stride
     // LAYOUT 1 / 2: piece q = wave + 4 k of a block: q < 16 -> dY piece q, else X piece q - 16
     constexpr long long kGradBlock = 144 * 1024, kActBlock = 176 * 1024, kBlocks = 32 * 192, kActs0 = kGradBlock * kBlocks;
     const int job = blockIdx.x >> 5, chunk = blockIdx.x & 31;
     const long long x_tile_bytes = (4 * P - 16) * 1024;      // X bytes of one block and job
-    const char* piece[P];
-    long long piece_stride[P];
+    const char* piece[PW];
+    long long piece_stride[PW];
 #pragma unroll
-    for (int k = 0; k < P; ++k) {
-        const int q = wave + 4 * k;
+    for (int k = 0; k < PW; ++k) {
+        const int q = wave + NW * k;
         const long long b0 = (long long)chunk * nblocks;
         if (LAYOUT == 1) {
             piece[k] = q < 16 ? src + b0 * kGradBlock + job * 16384 + q * 1024
@@ -65,12 +66,12 @@ __global__ void __launch_bounds__(256, 1) stream_kernel(const char* __restrict__
     auto stage = [&]() {
         if (LAYOUT == 0) {
 #pragma unroll
-            for (int k = 0; k < P; ++k) lds_dma(mine + k * 1024, lane * 16, lds_base + stage_slot * SLOT + (wave * P + k) * 1024);
+            for (int k = 0; k < PW; ++k) lds_dma(mine + k * 1024, lane * 16, lds_base + stage_slot * SLOT + (wave * PW + k) * 1024);
             mine += block_stride;
         } else {
 #pragma unroll
-            for (int k = 0; k < P; ++k) {
-                lds_dma(piece[k], lane * 16, lds_base + stage_slot * SLOT + (wave * P + k) * 1024);
+            for (int k = 0; k < PW; ++k) {
+                lds_dma(piece[k], lane * 16, lds_base + stage_slot * SLOT + (wave * PW + k) * 1024);
                 piece[k] += piece_stride[k];
             }
         }
@@ -89,12 +90,13 @@ __global__ void __launch_bounds__(256, 1) stream_kernel(const char* __restrict__
     auto half_block = [&](int slot, int kk) {
         if (READS) {
             const unsigned base = lds_base + slot * SLOT + kk * 512 + lane_off;
-            u32x2 v[20];
+            constexpr int NR = 80 / NW;
+            u32x2 v[NR];
 #pragma unroll
-            for (int i = 0; i < 20; ++i) v[i] = read_tr16(base, (i % (4 * P)) * 1024);
+            for (int i = 0; i < NR; ++i) v[i] = read_tr16(base, (i % (4 * P)) * 1024);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 20; ++i) { asm volatile("" : "+v"(v[i])); sink ^= v[i][0] ^ v[i][1]; }
+            for (int i = 0; i < NR; ++i) { asm volatile("" : "+v"(v[i])); sink ^= v[i][0] ^ v[i][1]; }
             if (MFMAS) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) b[i][0] = (_Float16)(float)(v[i][0] & 1);
@@ -102,17 +104,17 @@ __global__ void __launch_bounds__(256, 1) stream_kernel(const char* __restrict__
         }
         if (MFMAS) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[i & 7], acc[i & 7], 0, 0, 0);
+            for (int i = 0; i < 64 / NW; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[i & 7], acc[i & 7], 0, 0, 0);
         }
     };
     for (int k = 0; k < AHEAD && k < nblocks; ++k) stage();
-    wait_vm<(AHEAD - 1) * P>();
+    wait_vm<(AHEAD - 1) * PW>();
     __builtin_amdgcn_s_barrier();
     for (int n = 0; n < nblocks; ++n) {
         half_block(read_slot, 0);
         if (n + 1 < nblocks) {
             // block n+1 is in for every wave; the AHEAD - 2 blocks behind it stay in flight (the tail waits for everything)
-            if (n + AHEAD <= nblocks) wait_vm<(AHEAD - 2) * P>(); else wait_vm<0>();
+            if (n + AHEAD <= nblocks) wait_vm<(AHEAD - 2) * PW>(); else wait_vm<0>();
             __builtin_amdgcn_s_barrier();
             if (n + AHEAD < nblocks) stage();
         }
@@ -126,12 +128,12 @@ __global__ void __launch_bounds__(256, 1) stream_kernel(const char* __restrict__
     if (s == 1234.5f) out[0] = s;
 }
 
-template <int P, int AHEAD, bool READS, bool MFMAS, int LAYOUT = 0>
+template <int P, int AHEAD, bool READS, bool MFMAS, int LAYOUT = 0, int NW = 4>
 void run(const char* src, float* out, size_t bytes) {
     const int wgs = 256, nblocks = 192;
     const long long block_stride = (long long)wgs * 4 * P * 1024;
     if ((size_t)block_stride * nblocks > bytes) { printf("buffer too small\n"); return; }
-    auto k = stream_kernel<P, AHEAD, READS, MFMAS, LAYOUT>;
+    auto k = stream_kernel<P, AHEAD, READS, MFMAS, LAYOUT, NW>;
     const int lds_bytes = (AHEAD + 1) * 4 * P * 1024;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -139,16 +141,16 @@ void run(const char* src, float* out, size_t bytes) {
         return;
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k, dim3(wgs), dim3(256), lds_bytes, 0, src, out, nblocks, block_stride);
+    hipLaunchKernelGGL(k, dim3(wgs), dim3(NW * 64), lds_bytes, 0, src, out, nblocks, block_stride);
     hipDeviceSynchronize();
     const int reps = 8;
     hipEventRecord(e0);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k, dim3(wgs), dim3(256), lds_bytes, 0, src, out, nblocks, block_stride);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k, dim3(wgs), dim3(NW * 64), lds_bytes, 0, src, out, nblocks, block_stride);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / reps, tb = (double)block_stride * nblocks / (us * 1e-6) * 1e-12;
-    printf("layout %d, P = %d (%2d KiB blocks), %d in flight behind the awaited block, ring %d (%3d KiB LDS)%s%s: %7.1f us per launch, %.3f us per block, %.2f TB/s\n",
-           LAYOUT, P, 4 * P, AHEAD - 1, AHEAD + 1, lds_bytes / 1024, READS ? " + 40 tr16 reads" : "", MFMAS ? " + 32 MFMAs" : "", us, us / nblocks, tb);
+    printf("layout %d, %d waves, P = %d (%2d KiB blocks), %d in flight behind the awaited block, ring %d (%3d KiB LDS)%s%s: %7.1f us per launch, %.3f us per block, %.2f TB/s\n",
+           LAYOUT, NW, P, 4 * P, AHEAD - 1, AHEAD + 1, lds_bytes / 1024, READS ? " + 40 tr16 reads" : "", MFMAS ? " + 32 MFMAs" : "", us, us / nblocks, tb);
 }
 
 template <int P>
@@ -173,5 +175,10 @@ int main() {
     run<6, 2, false, false, 2>(src, out, bytes); run<6, 2, true, true, 2>(src, out, bytes);
     run<8, 3, false, false, 1>(src, out, bytes); run<8, 3, true, true, 1>(src, out, bytes);
     run<6, 3, false, false, 1>(src, out, bytes); run<6, 3, true, true, 1>(src, out, bytes);
+    // two waves per SIMD
+    run<6, 2, false, false, 1, 8>(src, out, bytes); run<6, 2, true, true, 1, 8>(src, out, bytes);
+    run<6, 3, true, true, 1, 8>(src, out, bytes);
+    run<8, 2, false, false, 1, 8>(src, out, bytes); run<8, 2, true, true, 1, 8>(src, out, bytes);
+    run<8, 3, true, true, 1, 8>(src, out, bytes);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
