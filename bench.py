@@ -618,10 +618,11 @@ def training_record(device, steps=10, warmup=3):
     # (harness.train_one_iter single_pass: same objective, the reference sub-batches only for device memory), and the
     # whole sub-batched iteration -- batch assembly, draws, pass, Adam -- replayed from ONE HIP graph
     # (harness.GraphedIteration: parameters bit-identical to the eager iterations')
-    for name, kwargs in (('f16_single_pass', {'single_pass': True}), ('f16_graphed', {'graphed': True})):
-        ms, fwd_ms, bwd_ms, rows = time_training('f16', device, steps, warmup, **kwargs)
+    for name, precision, kwargs in (('f16_single_pass', 'f16', {'single_pass': True}), ('f16_graphed', 'f16', {'graphed': True}),
+                                    ('f16s8_single_pass', 'f16s8', {'single_pass': True})):
+        ms, fwd_ms, bwd_ms, rows = time_training(precision, device, steps, warmup, **kwargs)
         tflops = rows * TRAIN_FLOP_PER_RAY / (ms * 1e-3) / 1e12
-        out['modes'][name] = {'dtype': TRAIN_DTYPE['f16'], 'ms_per_step': ms, 'value': rows / (ms * 1e-3), 'unit': 'rays/s',
+        out['modes'][name] = {'dtype': TRAIN_DTYPE[precision], 'ms_per_step': ms, 'value': rows / (ms * 1e-3), 'unit': 'rays/s',
                               'algorithmic_tflops': tflops, 'peak_tflops': PEAK_FP16_MFMA_TFLOPS, 'frac_of_peak': tflops / PEAK_FP16_MFMA_TFLOPS,
                               'host_enqueue_ms_p50': time_training.timing['enqueue_ms']['p50']}
     return out
