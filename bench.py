@@ -289,8 +289,8 @@ def pmc_traffic(precision):
 
 def pmc_train_traffic(precision):
     """HBM bytes per training iteration (config 5) from a separate rocprofv3 --pmc run of `bench.py --train` (profiles/
-    pmc_traffic_train_<precision>.json: tools/pmc_passes.sh + tools/collect_pmc_kernels.py --iterations N) -- the training
-    step is HBM-bound in the 16-bit modes, so this, not the MFMA fraction, is its limiter.  -> dict or None"""
+    pmc_traffic_train_<precision>.json: tools/pmc_passes.sh + tools/collect_pmc_kernels.py --iterations N) -- in the
+    16-bit modes the weight gradients stream at the HBM rate and this figure / 6.3 TB/s is the floor under the iteration.  -> dict or None"""
     name = f'pmc_traffic_train_{precision}.json'
     path = os.path.join(REPO, 'profiles', name)
     if not os.path.exists(path):
@@ -592,8 +592,8 @@ def training_record(device, steps=10, warmup=3):
     against its own MFMA ceiling."""
     dominant = {'fp32': 'wgrad_kernel<2,8,false> (weight gradients); forward mlp_forward_kernel<8,4,true,false,true>',
                 'f16x3': 'wgrad_kernel<2,8,true> (weight gradients); chain mlp_backward_chain_f16x3_kernel<8,4,true,3,8>',
-                'f16': 'chain mlp_backward_chain_f16x3_kernel<8,4,true,1,8>; wgrad16_kernel<2,8> (weight gradients, HBM-bound, '
-                       '6.4 TB/s); forward mlp_forward_f16x3_kernel<8,4,true,false,true,1,8>',
+                'f16': 'chain mlp_backward_chain_f16x3_kernel<8,4,true,1,8>; wgrad16_kernel<2,8> (weight gradients, stream-bound, '
+                       '6.3 TB/s); forward mlp_forward_f16x3_kernel<8,4,true,false,true,1,8>',
                 'bf16': 'the f16 kernels instantiated for bf16 operands (<..., true>): v_mfma_f32_32x32x16_bf16',
                 'f16s8': 'the f16 kernels; the storing forward writes h_1..h_7 as fp8 tiles (<..., S8>), wgrad16_kernel<2,8,false,false,true> '
                          'reads them back with ds_read_b64_tr_b8'}
@@ -663,8 +663,9 @@ def train_bench(args, rank, world, device, dist):
                             'peak': {'fp32': PEAK_FP32_MFMA_TFLOPS, 'f16x3': PEAK_FP16_MFMA_TFLOPS / 3}.get(args.precision, PEAK_FP16_MFMA_TFLOPS),
                             'unit': 'TFLOP/s', 'traffic': None if traffic is None else traffic['hbm_gb_per_iteration'] * 1e9,
                             'traffic_source': None if traffic is None else traffic['source'],
-                            'note': 'whole-iteration wall time against the MFMA peak of the mode; in the 16-bit modes the iteration is '
-                                    'HBM-bound: `traffic` (bytes per iteration, all kernels) / 6.3 TB/s is its floor'}
+                            'note': 'whole-iteration wall time against the MFMA peak of the mode; `traffic` = HBM bytes per iteration, '
+                                    'all kernels: / 6.3 TB/s it is the HBM floor (5.0-5.9 ms in the 16-bit modes; DESIGN.md 10.5 '
+                                    'says what bounds each kernel above it)'}
         line['roofline']['frac'] = line['roofline']['achieved'] / line['roofline']['peak']
         if dist is not None:
             line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(), 'bytes': 2265488 * 4,
