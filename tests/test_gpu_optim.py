@@ -186,7 +186,7 @@ def test_graphed_sub_batched_iteration_equals_the_eager_trainer_iteration(precis
         assert torch.equal(a, b), name
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'f16'])
+@pytest.mark.parametrize('precision', ['fp32', 'f16', 'f16s8'])
 def test_graphed_whole_iteration_equals_the_eager_trainer_iteration(precision):
     """harness.GraphedIteration: batch assembly, draws, the sub-batched pass AND the Adam update replayed from ONE HIP graph,
     the per-iteration scalars (epoch positions, iteration number, Adam's factors with the decayed learning rate) read from a
