@@ -1014,8 +1014,15 @@ __global__ void __launch_bounds__(256) reduce_kernel(JobTable table, const float
 // Workgroups (= partial sums the reduction folds afterwards) of a small head / encoding job.  Every chunk ends with a partial
 // of out_tiles x in_tiles x 4 KiB that is written once and read once, so the count trades staging parallelism against
 // partial-sum traffic (the two 8x2-tile encoding jobs of the main MLP: 64 KB per chunk).  -DSNERF_SMALL_CHUNKS=n for A/B builds.
+// 512 dated from one launch per register-tile class (one job per launch); with the four or five small jobs of an MLP in ONE launch
+// it left a workgroup 8 blocks of a 64-samples-per-ray pass to stream and a 64 KB partial to write: config-5 backward per
+// iteration 5.05 ms (384), 4.85 (256), 4.85 (128), 4.94 (64) against 5.25-5.49 at 512, same box; blocks / 32 clamped to
+// 64 .. 384 measured the same as a fixed 192.
 #ifndef SNERF_SMALL_CHUNKS
-#define SNERF_SMALL_CHUNKS 512
+#define SNERF_SMALL_CHUNKS 192
+#endif
+#ifndef SNERF_MID_BLOCKS
+#define SNERF_MID_BLOCKS 32
 #endif
 constexpr int kSmallJobChunks = SNERF_SMALL_CHUNKS;
 
@@ -1139,9 +1146,13 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
                 if (ko == no && ki == ni && k.out_tiles * k.in_tiles >= 32 && k.launched) peers_weight += weight(k);
             }
             chunks = 256 * weight(j) / peers_weight;   // rounded DOWN: 7 jobs x 37 chunks = 259 workgroups ran as 256 + a second round of 3
+            // (a lone job of fewer than 64 tile products -- the views layer's 4 x 9 -- ends every workgroup with a 144 KB
+            // partial: at least SNERF_MID_BLOCKS blocks of operands per workgroup; config 5: 128 instead of 256 workgroups
+            // for a 64-samples-per-ray pass is worth 0.04 ms per iteration, 64 costs 0.25)
+            if (j.out_tiles * j.in_tiles < 64 && chunks > blocks / SNERF_MID_BLOCKS) chunks = std::max<long long>(blocks / SNERF_MID_BLOCKS, 1);
             cap = blocks / 8;
         } else {
-            chunks = kSmallJobChunks;
+            chunks = f16 ? kSmallJobChunks : 512;     // (fp32 / f16x3: one launch per register-tile class, one or two jobs each)
             cap = blocks / 8;
         }
         if (chunks > cap) chunks = cap;
