@@ -1152,7 +1152,10 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
             if (j.out_tiles * j.in_tiles < 64 && chunks > blocks / SNERF_MID_BLOCKS) chunks = std::max<long long>(blocks / SNERF_MID_BLOCKS, 1);
             cap = blocks / 8;
         } else {
-            chunks = f16 ? kSmallJobChunks : 512;     // (fp32 / f16x3: one launch per register-tile class, one or two jobs each)
+#ifndef SNERF_SMALL_CHUNKS_FP32
+#define SNERF_SMALL_CHUNKS_FP32 256      // (512 -> 256: config-5 backward 29.06 -> 28.88 ms in fp32, 13.10 -> 13.02 in f16x3)
+#endif
+            chunks = f16 ? kSmallJobChunks : SNERF_SMALL_CHUNKS_FP32;     // (fp32 / f16x3: one launch per register-tile class, one or two jobs each)
             cap = blocks / 8;
         }
         if (chunks > cap) chunks = cap;
