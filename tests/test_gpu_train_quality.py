@@ -2,7 +2,8 @@
 DISTRIBUTIONS over seeds, not about one trajectory.  The long record -- 8 seeds x {fp32, f16x3, f16, bf16} x 5000 iterations
 -- is profiles/r04_train_seeds.json (tools/train_seeds.py): final PSNR 40.3 +- 1.4 dB (fp32), 39.7 +- 1.4 (f16x3), 39.4 +- 1.2
 (f16), 39.2 +- 1.4 (bf16); every mean inside fp32's own min..max, every difference under two standard errors; f16s8 (fp8 saved
-activations; profiles/r04_train_seeds_f16s8.json, same seeds): 39.8 +- 1.9.  Here: the same runs, shorter (3 seeds x 1200
+activations; profiles/r04_train_seeds_f16s8.json, same seeds): 39.8 +- 1.9.  The same seeds on the round's final code
+(r04_train_seeds_final_code.json): 40.3 / 40.7 / 40.3 / 39.6 / 40.1 -- the ordering of the first record was trajectory.  Here: the same runs, shorter (3 seeds x 1200
 iterations), as a gate on the means with the pooled seed spread as the yardstick."""
 import os
 import statistics
