@@ -204,7 +204,8 @@ def host_cores():
         return max(1, os.cpu_count() or 1)
 
 
-CPU_LEG_TIMEOUT_S = 45.0
+CPU_LEG_TIMEOUT_S = 45.0           # the os.cpu_count() leg: hopeless where the job owns fewer cores, so it is cut short
+CPU_LEG_TIMEOUT_16_S = 100.0       # the 16-thread leg (~15 s on an idle host; one GPU box took > 45 s for it)
 
 
 def cpu_leg(kind, first_ray, threads, budget_seconds=9.0, max_runs=9):
@@ -228,6 +229,9 @@ def cpu_leg(kind, first_ray, threads, budget_seconds=9.0, max_runs=9):
             t0 = time.perf_counter()
             nerf_oracle.render(params, configs, batch, training=False)
             times.append(time.perf_counter() - t0)
+            # (one line per finished pass: a parent that runs out of patience keeps what there is)
+            print(json.dumps({'threads': threads, 'value': RAYS_PER_GPU / min(times), 'unit': 'rays/s', 'runs': len(times),
+                              'best_s': min(times), 'mean_s': sum(times) / len(times)}), flush=True)
     return {'threads': threads, 'value': RAYS_PER_GPU / min(times), 'unit': 'rays/s', 'runs': len(times),
             'best_s': min(times), 'mean_s': sum(times) / len(times)}
 
@@ -251,15 +255,20 @@ def cpu_baseline(kind, first_ray):
         env.update(OMP_NUM_THREADS=str(n), MKL_NUM_THREADS=str(n))
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=CPU_LEG_TIMEOUT_S, env=env)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=CPU_LEG_TIMEOUT_S if n > 16 else CPU_LEG_TIMEOUT_16_S, env=env)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
             if r.returncode == 0 and lines:
                 legs.append(json.loads(lines[-1]))
             else:
                 legs.append({'threads': n, 'failed': (r.stderr or r.stdout)[-300:]})
-        except subprocess.TimeoutExpired:
-            legs.append({'threads': n, 'timed_out_after_s': round(time.perf_counter() - t0, 1),
-                         'note': 'more threads than the cores this job may use: not a usable baseline on this host'})
+        except subprocess.TimeoutExpired as late:
+            so_far = late.stdout.decode() if isinstance(late.stdout, bytes) else (late.stdout or '')
+            lines = [ln for ln in so_far.splitlines() if ln.startswith('{') and ln.rstrip().endswith('}')]
+            leg = json.loads(lines[-1]) if lines else {'threads': n}     # the passes it did finish, if any
+            leg['timed_out_after_s'] = round(time.perf_counter() - t0, 1)
+            leg['note'] = ('cut short: the figure is from the passes that finished' if lines else
+                           'no pass finished in time' + (': more threads than the cores this job may use' if n > 16 else ''))
+            legs.append(leg)
     done = [r for r in legs if 'value' in r]
     if not done:
         return {'value': None, 'unit': 'rays/s', 'cores': None, 'kind': 'port', 'legs': legs,
