@@ -535,7 +535,8 @@ def training_step(precision, rank, world, device, single_pass=False, graphed=Fal
     if graphed:      # the WHOLE iteration -- batch assembly, draws, pass, Adam -- replayed from ONE HIP graph (GraphedIteration)
         if world > 1:
             raise SystemExit('the graphed training iteration is a single-GPU measurement')
-        graph = harness.GraphedIteration(model, losses, opt, batcher, decayer, sub_batch_size=cfg['sub_batch_size'])
+        # (with single_pass: ONE model pass, i.e. the reference's loop with sub_batch_size = batch size -- Trainer01.py:82)
+        graph = harness.GraphedIteration(model, losses, opt, batcher, decayer, sub_batch_size=None if single_pass else cfg['sub_batch_size'])
 
     def step():
         it = state['iter']
@@ -628,7 +629,8 @@ def training_record(device, steps=10, warmup=3):
     # whole sub-batched iteration -- batch assembly, draws, pass, Adam -- replayed from ONE HIP graph
     # (harness.GraphedIteration: parameters bit-identical to the eager iterations')
     for name, precision, kwargs in (('f16_single_pass', 'f16', {'single_pass': True}), ('f16_graphed', 'f16', {'graphed': True}),
-                                    ('f16s8_single_pass', 'f16s8', {'single_pass': True})):
+                                    ('f16s8_single_pass', 'f16s8', {'single_pass': True}),
+                                    ('f16s8_one_pass_graphed', 'f16s8', {'single_pass': True, 'graphed': True})):
         ms, fwd_ms, bwd_ms, rows = time_training(precision, device, steps, warmup, **kwargs)
         tflops = rows * TRAIN_FLOP_PER_RAY / (ms * 1e-3) / 1e12
         out['modes'][name] = {'dtype': TRAIN_DTYPE[precision], 'ms_per_step': ms, 'value': rows / (ms * 1e-3), 'unit': 'rays/s',
