@@ -32,7 +32,7 @@ enum snerf_status {
 
 /* ABI version of this header; bumped on any signature change (new enum values such as SNERF_PRECISION_F16 extend a
  * version without changing it: older callers never pass them). */
-#define SNERF_ABI_VERSION 8
+#define SNERF_ABI_VERSION 9
 int snerf_abi_version(void);
 const char* snerf_last_error(void);
 
@@ -94,6 +94,15 @@ size_t snerf_mlp_packed_floats(const snerf_mlp_desc* desc);
  * parameter update; the stream is what snerf_mlp_forward consumes. */
 int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* params, int num_params, float* packed,
                    snerf_stream_t stream);
+
+/* snerf_mlp_pack writes EVERY operand format of the weights (fp32 segments, the fp16 hi/lo streams for training and for
+ * rendering, their bf16 counterparts): a trainer that re-packs after every optimiser step pays for six of them and reads
+ * two.  This variant writes what calls at ONE precision (enum snerf_precision, below) in ONE mode will read -- training != 0:
+ * snerf_mlp_forward_train / snerf_mlp_backward / the render ops with saved activations; training == 0: additionally the
+ * rendering layout -- and zeroes the rest: the caller re-packs when it changes precision or mode (the Python model keys its
+ * packed streams by both).  No counterpart in the reference (its modules read their parameters directly). */
+int snerf_mlp_pack_for(const snerf_mlp_desc* desc, const float* const* params, int num_params, float* packed, int precision,
+                       int training, snerf_stream_t stream);
 
 enum snerf_precision {
     SNERF_PRECISION_FP32 = 0, /* fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 FMA chains */

@@ -12,7 +12,7 @@ from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_s
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsimplenerf_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 ITERATION_WORDS = 8      # struct snerf_iteration as 64-bit words (include/simplenerf_train.h)
@@ -95,6 +95,7 @@ SIGNATURES = {
     'snerf_mlp_num_params': (c_int, [POINTER(MlpDesc)]),
     'snerf_mlp_packed_floats': (c_size_t, [POINTER(MlpDesc)]),
     'snerf_mlp_pack': (c_int, [POINTER(MlpDesc), POINTER(c_void_p), c_int, _FP, c_void_p]),
+    'snerf_mlp_pack_for': (c_int, [POINTER(MlpDesc), POINTER(c_void_p), c_int, _FP, c_int, c_int, c_void_p]),
     'snerf_mlp_forward': (c_int, [POINTER(MlpDesc), _FP, _FP, _FP, _FP, _FP, c_longlong, c_int, _FP, _FP, _FP, c_int,
                                   c_void_p]),
     'snerf_mlp_saved_floats': (c_size_t, [POINTER(MlpDesc), c_longlong, c_int]),

@@ -174,8 +174,12 @@ extern "C" size_t snerf_mlp_packed_floats(const snerf_mlp_desc* desc) {
     return (size_t)plan.total_floats;
 }
 
-extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* params, int num_params, float* packed,
-                              snerf_stream_t stream) {
+namespace {
+// which 16-bit copies of the weights a pack writes besides the fp32 segments, biases and heads (everything else is zeroed)
+constexpr unsigned kPackF16 = 1u, kPackF16Eval = 2u, kPackBf16 = 4u, kPackBf16Eval = 8u, kPackAll = 15u;
+
+int pack_impl(const snerf_mlp_desc* desc, const float* const* params, int num_params, float* packed, snerf_stream_t stream,
+              unsigned formats) {
     snerf::MlpPlan plan;
     const int st = snerf::build_plan(desc, &plan);
     snerf::GenericPlan layered;
@@ -229,6 +233,10 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
         };
         for (const std::vector<snerf::MlpPlan::HalfStage>* list : {&plan.half_stages, &plan.half_dgrad_stages, &plan.m16_stages,
                                                                    &plan.bf_stages, &plan.bf_dgrad_stages, &plan.bf_m16_stages}) {
+            const unsigned bit = (list == &plan.half_stages || list == &plan.half_dgrad_stages) ? kPackF16
+                                 : list == &plan.m16_stages ? kPackF16Eval
+                                 : list == &plan.bf_m16_stages ? kPackBf16Eval : kPackBf16;
+            if (!(formats & bit)) continue;
             for (const snerf::MlpPlan::HalfStage& st : *list) {
                 for (int k = 0; k < 3; ++k) table.w[n][k] = params[st.seg[k < st.nseg ? k : 0].param];
                 table.stage[n] = st;
@@ -261,4 +269,24 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
     hipLaunchKernelGGL(copy_rows_kernel, dim3(4, ncopies), dim3(256), 0, s, copies, packed);
     if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_pack: copy: %s", hipGetErrorString(e));
     return snerf::check_launch("mlp_pack");
+}
+}  // namespace
+
+extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* params, int num_params, float* packed,
+                              snerf_stream_t stream) {
+    return pack_impl(desc, params, num_params, packed, stream, kPackAll);
+}
+
+extern "C" int snerf_mlp_pack_for(const snerf_mlp_desc* desc, const float* const* params, int num_params, float* packed,
+                                  int precision, int training, snerf_stream_t stream) {
+    unsigned formats = 0;
+    switch (precision) {
+        case SNERF_PRECISION_FP32: break;
+        case SNERF_PRECISION_F16X3: case SNERF_PRECISION_F16: case SNERF_PRECISION_F16S8:
+            formats = kPackF16 | (training ? 0u : kPackF16Eval);
+            break;
+        case SNERF_PRECISION_BF16: formats = kPackBf16 | (training ? 0u : kPackBf16Eval); break;
+        default: return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_pack_for: unknown precision %d", precision);
+    }
+    return pack_impl(desc, params, num_params, packed, stream, formats);
 }

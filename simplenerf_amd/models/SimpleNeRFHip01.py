@@ -326,17 +326,21 @@ class SimpleNeRFHip(torch.nn.Module):
             cols.append(poses[other][:, :3, 3])
         return torch.stack(cols, dim=1).contiguous()
 
-    def _packed_mlp(self, name: str) -> ops.PackedMlp:
+    def _packed_mlp(self, name: str, keeps_activations: bool) -> ops.PackedMlp:
         module: MlpParameters = getattr(self, name)
         params = module.abi_params()
         # staleness stamp: every parameter's in-place version counter (optimiser steps, load_state_dict, manual edits)
         # plus the storage address of the first one (a .to(device) / re-materialisation moves them all)
-        stamp = (params[0].data_ptr(),) + tuple(p._version for p in params)
+        # ... and what the stream was packed FOR: the optimiser step of every training iteration re-packs, and writing only
+        # the operand formats this precision reads in this mode (snerf_mlp_pack_for) leaves 9 of 25 pack launches
+        # (``keeps_activations``: this call saves activations for a backward -- the storing forward and the backward read the
+        # training layout, a plain render reads the rendering layout as well)
+        stamp = (params[0].data_ptr(), self.precision, bool(keeps_activations)) + tuple(p._version for p in params)
         entry = self._packed.get(name)
         if entry is None or entry[0] != stamp or entry[1].buffer.device != params[0].device:
             packed = entry[1] if entry is not None and entry[1].buffer.device == params[0].device \
                 else ops.PackedMlp(module.mlp_configs, params[0].device)
-            packed.pack(params)
+            packed.pack(params, self.precision, bool(keeps_activations))
             self._packed[name] = (stamp, packed)
         return self._packed[name][1]
 
@@ -479,7 +483,7 @@ class SimpleNeRFHip(torch.nn.Module):
                 if present[level]:
                     draws[('noise', level)] = draw(_NOISE_KEYS[level], (n, s_c + s_f, 1), True)
 
-        packed = [self._packed_mlp(name) if name else None for name in present]
+        packed = [self._packed_mlp(name, with_grad) if name else None for name in present]
         per_sample = ('alpha', 'visibility', 'weights') if retraw else ('alpha',)
         predicts = [name is not None and getattr(self, name).predict_visibility for name in present]
         if any(predicts):

@@ -166,16 +166,22 @@ class PackedMlp:
         self.buffer = torch.zeros(floats, dtype=torch.float32, device=device)
         self.use_view_dirs = bool(self.desc.view_dependent_rgb)
 
-    def pack(self, params: List[Tensor]) -> None:
+    def pack(self, params: List[Tensor], precision: Optional[int] = None, training: bool = False) -> None:
         """params in C-ABI order: pts_linears.{i}.weight/.bias ..., pts_output_linear.*, [feature_linear.*,
-        views_linears.0.*, views_output_linear.*]."""
+        views_linears.0.*, views_output_linear.*].  ``precision`` None: every operand format (snerf_mlp_pack); a PRECISION_*
+        value: only what calls at that precision in that mode read (snerf_mlp_pack_for) -- re-pack before using the stream
+        at another precision or mode."""
         lib = _lib.load()
         if len(params) != self.num_params:
             raise RuntimeError(f'expected {self.num_params} parameter tensors, got {len(params)}')
         held = [_dev(p, f'param[{i}]') for i, p in enumerate(params)]
         arr = (ctypes.c_void_p * len(held))(*[p.data_ptr() for p in held])
         with torch.cuda.device(self.buffer.device):
-            st = lib.snerf_mlp_pack(ctypes.byref(self.desc), arr, len(held), _ptr(self.buffer), _stream())
+            if precision is None:
+                st = lib.snerf_mlp_pack(ctypes.byref(self.desc), arr, len(held), _ptr(self.buffer), _stream())
+            else:
+                st = lib.snerf_mlp_pack_for(ctypes.byref(self.desc), arr, len(held), _ptr(self.buffer), int(precision),
+                                            1 if training else 0, _stream())
         _lib.check(st, 'snerf_mlp_pack')
 
     def forward(self, origins: Tensor, dirs: Tensor, view_dirs: Optional[Tensor], depths: Tensor,

@@ -468,3 +468,53 @@ def test_f16s8_training_batch_close_to_fp32():
     worst16 = max(rel_l2(got_grads[k], f16_grads[k]) for k in ref_grads)
     util.observe('f16s8/training_batch', f'parameter gradients vs fp32: worst rel L2 {worst32:.4f} [0.05]; vs the fp16 mode: {worst16:.4f} [0.02]')
     assert worst32 <= 0.05 and worst16 <= 0.02
+
+
+# ---------------------------------------------------------------- snerf_mlp_pack_for: only the operand formats one precision reads
+@pytest.mark.parametrize('precision', ['fp32', 'f16x3', 'f16', 'bf16', 'f16s8'])
+def test_selective_pack_gives_the_same_bits_as_the_full_pack(precision):
+    """snerf_mlp_pack writes every operand format of the weights, snerf_mlp_pack_for(precision, training) only what that
+    precision reads in that mode: rendering (training = 0) and the storing forward + backward (training = 1) from the selective
+    streams are bit-identical to the same calls on the full stream."""
+    prec = ops.PRECISIONS[precision]
+    cfg, sd, inputs, (g_sigma, g_rgb) = mlp_case('main', (8, 256, 128))
+    plist = abi_param_list({k: torch.from_numpy(v_).to(DEV) for k, v_ in sd.items()})
+    shapes = [tuple(p.shape) for p in plist]
+    dev = [t.to(DEV) for t in inputs]
+    full = ops.PackedMlp(cfg, DEV)
+    full.pack(plist)
+    ref_eval = full.forward(*dev, prec)
+    sigma, rgb, saved = full.forward_train(*dev, prec)
+    ref_grads = full.backward(saved, sigma, rgb, g_sigma.to(DEV), g_rgb.to(DEV), shapes, prec)
+
+    lean = ops.PackedMlp(cfg, DEV)
+    lean.pack(plist, prec, training=False)
+    got_eval = lean.forward(*dev, prec)
+    assert all(torch.equal(a, b) for a, b in zip(got_eval, ref_eval))
+    lean.pack(plist, prec, training=True)
+    sigma2, rgb2, saved2 = lean.forward_train(*dev, prec)
+    assert torch.equal(sigma2, sigma) and torch.equal(rgb2, rgb)
+    got_grads = lean.backward(saved2, sigma2, rgb2, g_sigma.to(DEV), g_rgb.to(DEV), shapes, prec)
+    assert all(torch.equal(a, b) for a, b in zip(got_grads, ref_grads))
+    torch.cuda.synchronize()
+    assert ops.range_status(clear=True) == 0
+
+
+def test_model_repacks_when_a_render_follows_training_steps():
+    """The model keys its packed streams by (precision, keeps activations): an evaluation render between training iterations
+    reads the rendering layout, which the training pack does not write -- it must trigger a re-pack, not read zeros."""
+    cfg = synth.training_configs('f16', num_rays=192, num_sparse=64)
+    cfg['losses'] = synth.loss_configs(iter_weighted=False)
+    model = synthetic_model(cfg, 'f16').train()
+    scene = synth.training_scene(0, 3, 48, 64, sparse_fraction=0.05)
+    batcher = BatchAssembler(cfg, scene, DEV)
+    losses = LossComputer(cfg)
+    batch = batcher.get_next_batch(0)
+    with torch.no_grad():
+        before = {k: v.clone() for k, v in model(batch).items() if isinstance(v, torch.Tensor)}
+    terms = losses.compute_losses(batch, model(batch))          # a training pass: packs the training layout only
+    terms['TotalLoss'].backward()
+    with torch.no_grad():
+        after = {k: v for k, v in model(batch).items() if isinstance(v, torch.Tensor)}
+    assert before and all(torch.equal(before[k], after[k]) for k in before), 'a render after a training pass changed'
+    assert any(float(v.abs().max()) > 0 for v in after.values())
