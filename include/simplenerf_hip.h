@@ -96,8 +96,8 @@ int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* params, int n
                    snerf_stream_t stream);
 
 /* snerf_mlp_pack writes EVERY operand format of the weights (fp32 segments, the fp16 hi/lo streams for training and for
- * rendering, their bf16 counterparts): a trainer that re-packs after every optimiser step pays for six of them and reads
- * two.  This variant writes what calls at ONE precision (enum snerf_precision, below) in ONE mode will read -- training != 0:
+ * rendering, their bf16 counterparts): a trainer that re-packs after every optimiser step pays for seven of them and reads
+ * two (the fp32 precision: the fp32 segments alone).  This variant writes what calls at ONE precision (enum snerf_precision, below) in ONE mode will read -- training != 0:
  * snerf_mlp_forward_train / snerf_mlp_backward / the render ops with saved activations; training == 0: additionally the
  * rendering layout -- and zeroes the rest: the caller re-packs when it changes precision or mode (the Python model keys its
  * packed streams by both).  No counterpart in the reference (its modules read their parameters directly). */

@@ -176,7 +176,7 @@ extern "C" size_t snerf_mlp_packed_floats(const snerf_mlp_desc* desc) {
 
 namespace {
 // which 16-bit copies of the weights a pack writes besides the fp32 segments, biases and heads (everything else is zeroed)
-constexpr unsigned kPackF16 = 1u, kPackF16Eval = 2u, kPackBf16 = 4u, kPackBf16Eval = 8u, kPackAll = 15u;
+constexpr unsigned kPackF16 = 1u, kPackF16Eval = 2u, kPackBf16 = 4u, kPackBf16Eval = 8u, kPackFp32 = 16u, kPackAll = 31u;
 
 int pack_impl(const snerf_mlp_desc* desc, const float* const* params, int num_params, float* packed, snerf_stream_t stream,
               unsigned formats) {
@@ -211,6 +211,7 @@ int pack_impl(const snerf_mlp_desc* desc, const float* const* params, int num_pa
             most = 0;
         };
         for (const std::vector<snerf::Segment>* list : {&plan.segments, &plan.dgrad_segments}) {
+            if (!(formats & kPackFp32)) continue;          // (the fp32 K-segment slabs: read by the fp32 kernels only)
             for (const snerf::Segment& seg : *list) {
                 table.w[n] = params[seg.param];
                 table.seg[n] = seg;
@@ -281,7 +282,7 @@ extern "C" int snerf_mlp_pack_for(const snerf_mlp_desc* desc, const float* const
                                   int precision, int training, snerf_stream_t stream) {
     unsigned formats = 0;
     switch (precision) {
-        case SNERF_PRECISION_FP32: break;
+        case SNERF_PRECISION_FP32: formats = kPackFp32; break;
         case SNERF_PRECISION_F16X3: case SNERF_PRECISION_F16: case SNERF_PRECISION_F16S8:
             formats = kPackF16 | (training ? 0u : kPackF16Eval);
             break;

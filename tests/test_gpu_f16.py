@@ -471,13 +471,15 @@ def test_f16s8_training_batch_close_to_fp32():
 
 
 # ---------------------------------------------------------------- snerf_mlp_pack_for: only the operand formats one precision reads
+@pytest.mark.parametrize('layout', ['main', 'ptsaug', 'viewsaug'])
+@pytest.mark.parametrize('size', [(8, 256, 128), (4, 128, 64)])
 @pytest.mark.parametrize('precision', ['fp32', 'f16x3', 'f16', 'bf16', 'f16s8'])
-def test_selective_pack_gives_the_same_bits_as_the_full_pack(precision):
+def test_selective_pack_gives_the_same_bits_as_the_full_pack(precision, size, layout):
     """snerf_mlp_pack writes every operand format of the weights, snerf_mlp_pack_for(precision, training) only what that
     precision reads in that mode: rendering (training = 0) and the storing forward + backward (training = 1) from the selective
     streams are bit-identical to the same calls on the full stream."""
     prec = ops.PRECISIONS[precision]
-    cfg, sd, inputs, (g_sigma, g_rgb) = mlp_case('main', (8, 256, 128))
+    cfg, sd, inputs, (g_sigma, g_rgb) = mlp_case(layout, size)
     plist = abi_param_list({k: torch.from_numpy(v_).to(DEV) for k, v_ in sd.items()})
     shapes = [tuple(p.shape) for p in plist]
     dev = [t.to(DEV) for t in inputs]
