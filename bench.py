@@ -91,6 +91,8 @@ PRECISION_INFO = {
     'bf16': (PEAK_FP16_MFMA_TFLOPS, 'bf16 (bf16 MFMA, fp32 accumulate)', 'mlp_forward_m16_kernel<1,8,true>',
              'one bf16 MFMA pass per product (BASELINE config 5\'s literal dtype; no range limit); NOT within the fp32 parity bar '
              '(sigma ~1e-2 relative, tests/test_gpu_bf16.py)'),
+    'bf16s8': (PEAK_FP16_MFMA_TFLOPS, 'bf16 (bf16 MFMA, fp32 accumulate; training keeps the trunk activations as fp8)', 'mlp_forward_m16_kernel<1,8,true>',
+               "rendering in this mode IS the bf16 mode; only what the training forward saves differs"),
 }
 
 # whole-frame workloads (BASELINE configs 2 and 4; SURVEY 8d resolves the resolutions): name -> (scene, camera kwargs, text)
@@ -559,7 +561,8 @@ def training_step(precision, rank, world, device, single_pass=False, graphed=Fal
 TRAIN_WORKLOAD = ('config 5: 2048 pixel + 2048 sparse-depth rows per GPU in two sub-batches, main coarse+fine + points-aug + '
                   'views-aug MLPs (64 + 192 samples), nine shipped losses, Adam, NeRF LR decay')
 TRAIN_DTYPE = {'fp32': 'f32', 'f16x3': 'f16x3', 'f16': 'f16 (bf16 layer gradients)', 'bf16': 'bf16',
-               'f16s8': 'f16 (bf16 layer gradients, fp8 e4m3 saved trunk activations)'}
+               'f16s8': 'f16 (bf16 layer gradients, fp8 e4m3 saved trunk activations)',
+               'bf16s8': 'bf16 (fp8 e4m3 saved trunk activations)'}
 
 
 def time_training(precision, device, steps, warmup, single_pass=False, board_seconds=0.0, graphed=False):
@@ -606,11 +609,12 @@ def training_record(device, steps=10, warmup=3):
                        '6.3 TB/s); forward mlp_forward_f16x3_kernel<8,4,true,false,true,1,8>',
                 'bf16': 'the f16 kernels instantiated for bf16 operands (<..., true>): v_mfma_f32_32x32x16_bf16',
                 'f16s8': 'the f16 kernels; the storing forward writes h_1..h_7 as fp8 tiles (<..., S8>), wgrad16_kernel<2,8,false,false,true> '
-                         'reads them back with ds_read_b64_tr_b8'}
+                         'reads them back with ds_read_b64_tr_b8',
+                'bf16s8': 'the bf16 kernels with fp8 saved trunk activations (<..., true, S8>, wgrad16_kernel<2,8,false,true,true>)'}
     out = {'workload': TRAIN_WORKLOAD, 'rows_per_gpu': 4096, 'steps': steps, 'warmup': warmup, 'modes': {}}
     # (f16x3 issues three fp16 MFMA passes per algorithmic product: its ceiling is a third of the fp16 peak)
     for precision, peak in (('fp32', PEAK_FP32_MFMA_TFLOPS), ('f16x3', PEAK_FP16_MFMA_TFLOPS / 3), ('f16', PEAK_FP16_MFMA_TFLOPS),
-                            ('bf16', PEAK_FP16_MFMA_TFLOPS), ('f16s8', PEAK_FP16_MFMA_TFLOPS)):
+                            ('bf16', PEAK_FP16_MFMA_TFLOPS), ('f16s8', PEAK_FP16_MFMA_TFLOPS), ('bf16s8', PEAK_FP16_MFMA_TFLOPS)):
         ms, fwd_ms, bwd_ms, rows = time_training(precision, device, steps, warmup, board_seconds=1.0)
         tflops = rows * TRAIN_FLOP_PER_RAY / (ms * 1e-3) / 1e12
         out['modes'][precision] = {
@@ -669,7 +673,7 @@ def train_bench(args, rank, world, device, dist):
             'timing': step_summary(elapsed, device_ms, enqueue_ms, None)}
         line['timing']['short_batches'] = step.short_batches   # timed iterations with fewer than rows_per_gpu rows (epoch ends)
         traffic = pmc_train_traffic(args.precision)
-        line['roofline'] = {'bound': 'hbm' if args.precision in ('f16', 'bf16') else 'mfma',
+        line['roofline'] = {'bound': 'mfma',      # (what `achieved` / `peak` are; the HBM side of the iteration is `traffic`)
                             'achieved': line['algorithmic_tflops'] / world,
                             'peak': {'fp32': PEAK_FP32_MFMA_TFLOPS, 'f16x3': PEAK_FP16_MFMA_TFLOPS / 3}.get(args.precision, PEAK_FP16_MFMA_TFLOPS),
                             'unit': 'TFLOP/s', 'traffic': None if traffic is None else traffic['hbm_gb_per_iteration'] * 1e9,
@@ -946,7 +950,7 @@ def main(argv=None, renderer_cls=None, backend='nccl', share_devices=False, scri
                     help='run the N > 1 protocol -- process group, barriers, the per-step gather (or gradient all-reduce), the '
                          'max-over-ranks reduction -- with whatever N is, including 1: every RCCL call of the multi-GPU line on a '
                          'one-GPU box')
-    ap.add_argument('--precision', choices=('fp32', 'f16x3', 'f16', 'bf16', 'f16s8'), default='fp32',
+    ap.add_argument('--precision', choices=('fp32', 'f16x3', 'f16', 'bf16', 'f16s8', 'bf16s8'), default='fp32',
                     help="arithmetic of the fused MLP kernel: fp32 MFMA; fp16 hi/lo split with 3 MFMAs per product "
                          "(fp32-grade results, same parity tests); or f16 = one fp16 MFMA per product with 16-bit saved "
                          "tensors (BASELINE config 5's 16-bit training mode, own tolerances: tests/test_gpu_f16.py)")

@@ -836,9 +836,17 @@ __global__ void __launch_bounds__(256, 1) wgrad16_kernel(JobTable table, const u
                 } else {
                     constexpr int ii = t - NO * 4;
                     const unsigned w0 = f.bx[ii].d[0][0], w1 = f.bx[ii].d[0][1];
-                    const f16x2 e01 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, false), e23 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, true);
-                    const f16x2 e45 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, false), e67 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, true);
-                    f.bx[ii].h = f16x8{e01[0], e01[1], e23[0], e23[1], e45[0], e45[1], e67[0], e67[1]};
+                    if constexpr (BF) {       // (SNERF_PRECISION_BF16S8: the bf16 operand of the bf16 MFMA)
+                        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                        const bf16x2_t e01 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w0, 1.0f, false), e23 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w0, 1.0f, true);
+                        const bf16x2_t e45 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w1, 1.0f, false), e67 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w1, 1.0f, true);
+                        f.bx[ii].d[0] = u32x2{__builtin_bit_cast(unsigned, e01), __builtin_bit_cast(unsigned, e23)};
+                        f.bx[ii].d[1] = u32x2{__builtin_bit_cast(unsigned, e45), __builtin_bit_cast(unsigned, e67)};
+                    } else {
+                        const f16x2 e01 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, false), e23 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, true);
+                        const f16x2 e45 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, false), e67 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, true);
+                        f.bx[ii].h = f16x8{e01[0], e01[1], e23[0], e23[1], e45[0], e45[1], e67[0], e67[1]};
+                    }
                 }
             };
             auto convert_all = [&](FragSet& f, f16x8 (&ah)[NO]) {
@@ -1284,10 +1292,10 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     for (int i = 0; i < num_params; ++i) SNERF_REQUIRE(param_grads[i], "mlp_backward: gradient tensor %d is NULL", i);
     SNERF_REQUIRE(num_rays >= 1 && num_samples >= 1, "mlp_backward: bad sizes n=%lld S=%d", num_rays, num_samples);
     if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3 && precision != SNERF_PRECISION_F16 &&
-        precision != SNERF_PRECISION_BF16 && precision != SNERF_PRECISION_F16S8)
+        precision != SNERF_PRECISION_BF16 && precision != SNERF_PRECISION_F16S8 && precision != SNERF_PRECISION_BF16S8)
         return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: precision %d not built", precision);
-    const bool bf16 = precision == SNERF_PRECISION_BF16;
-    const bool s8 = precision == SNERF_PRECISION_F16S8;       // fp16 products, trunk activations saved as fp8
+    const bool bf16 = precision == SNERF_PRECISION_BF16 || precision == SNERF_PRECISION_BF16S8;
+    const bool s8 = precision == SNERF_PRECISION_F16S8 || precision == SNERF_PRECISION_BF16S8;   // trunk activations saved as fp8
     const bool f16 = precision == SNERF_PRECISION_F16 || bf16 || s8;   // the 16-bit tile layouts; saved_acts must come from forward_train at the same precision
     if (precision != SNERF_PRECISION_FP32 && !bf16) {   // the forward that saved these activations may have left the fp16 range
         const int range = snerf::report_range("mlp_backward");
@@ -1412,7 +1420,8 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
         if (sub.count == 0) continue;
         const bool x3 = precision == SNERF_PRECISION_F16X3;
         if (bf16) {
-            if (cls[0] == 2 && cls[1] == 8) rc = launch_wgrad16<2, 8, false, true>(sub, grads, saved_acts, partial, s);
+            if (cls[0] == 2 && cls[1] == 8) rc = s8 ? launch_wgrad16<2, 8, false, true, true>(sub, grads, saved_acts, partial, s)
+                                                    : launch_wgrad16<2, 8, false, true>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 2 && cls[1] == 2) rc = launch_wgrad16<2, 2, false, true>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 2 && cls[1] == 1) rc = launch_wgrad16<2, 1, false, true>(sub, grads, saved_acts, partial, s);
             else if (cls[0] == 1 && cls[1] == 9) rc = launch_wgrad16<1, 9, false, true>(sub, grads, saved_acts, partial, s);

@@ -548,12 +548,16 @@ __device__ __forceinline__ void store_pieces(const f16x8 (&frag)[NB], _Float16* 
 // transposed with ds_read_b64_tr_b8 and widens with v_cvt_scalef32_pk_f16_fp8 (mlp_backward.hip).
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// `frag`: NKS post-ReLU (non-negative) fp16 fragments of this wave block
-template <int NKS, int NB>
+// `frag`: NKS post-ReLU (non-negative) fp16 fragments of this wave block -- BF (SNERF_PRECISION_BF16S8): bf16 bits in the same
+// registers; bf16 has no packed minimum, but non-negative values order like their bit patterns, so the clamp is an UNSIGNED
+// 16-bit minimum against 448's (v_cvt_scalef32_pk_fp8_bf16 returns NaN above it too: tools/probes/cvt_fp8_bf16.hip)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+template <int NKS, bool BF = false, int NB>
 __device__ __forceinline__ void store_pieces8(const f16x8 (&frag)[NB], _Float16* __restrict__ rows, int lane) {
     static_assert(NB >= NKS && NKS % 2 == 0, "whole tiles");
     const int slot = 2 * (lane & 31) + (lane >> 5);
     const f16x2 top = {(_Float16)448.0f, (_Float16)448.0f};
+    const u16x2 top_bits = {0x43E0, 0x43E0};            // 448.0 as bf16
 #pragma unroll
     for (int u = 0; u < NKS / 2; ++u) {
         u32x4 w;
@@ -563,8 +567,15 @@ __device__ __forceinline__ void store_pieces8(const f16x8 (&frag)[NB], _Float16*
             for (int d = 0; d < 2; ++d) {
                 const f16x8& f = frag[2 * u + k];
                 s16x2 p = {0, 0};
-                p = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p, __builtin_elementwise_min(f16x2{f[4 * d], f[4 * d + 1]}, top), 1.0f, false);
-                p = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p, __builtin_elementwise_min(f16x2{f[4 * d + 2], f[4 * d + 3]}, top), 1.0f, true);
+                if constexpr (BF) {
+                    const u16x2 lo = __builtin_elementwise_min(__builtin_bit_cast(u16x2, f16x2{f[4 * d], f[4 * d + 1]}), top_bits);
+                    const u16x2 hi = __builtin_elementwise_min(__builtin_bit_cast(u16x2, f16x2{f[4 * d + 2], f[4 * d + 3]}), top_bits);
+                    p = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(p, __builtin_bit_cast(bf16x2, lo), 1.0f, false);
+                    p = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(p, __builtin_bit_cast(bf16x2, hi), 1.0f, true);
+                } else {
+                    p = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p, __builtin_elementwise_min(f16x2{f[4 * d], f[4 * d + 1]}, top), 1.0f, false);
+                    p = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(p, __builtin_elementwise_min(f16x2{f[4 * d + 2], f[4 * d + 3]}, top), 1.0f, true);
+                }
                 w[2 * k + d] = __builtin_bit_cast(unsigned, p);
             }
         __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(rows + u * 512 + slot * 8));

@@ -35,6 +35,7 @@ inline int mlp_forward_f16x3(const MlpPlan& plan, const MlpArgs& m, bool train, 
 int mlp_forward_m16(const MlpPlan& plan, const MlpArgs& m, int products, hipStream_t stream, bool bf16);  // mlp_forward_m16.hip; -1 = layout not built there
 int mlp_forward_bf16(const MlpPlan& plan, const MlpArgs& m, bool train, hipStream_t stream);              // mlp_forward_bf16.hip
 int mlp_forward_s8_train(const MlpPlan& plan, const MlpArgs& m, hipStream_t stream);                      // mlp_forward_s8.hip
+int mlp_forward_bs8_train(const MlpPlan& plan, const MlpArgs& m, hipStream_t stream);                     // mlp_forward_bs8.hip
 }
 
 namespace {
@@ -93,11 +94,12 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     SNERF_REQUIRE(num_rays >= 0 && num_samples >= 1, "mlp_forward: bad sizes n=%lld S=%d", num_rays, num_samples);
     SNERF_REQUIRE(!train || saved_acts, "mlp_forward_train: saved_acts is NULL");
     if (precision != SNERF_PRECISION_FP32 && precision != SNERF_PRECISION_F16X3 && precision != SNERF_PRECISION_F16 &&
-        precision != SNERF_PRECISION_BF16 && precision != SNERF_PRECISION_F16S8)
+        precision != SNERF_PRECISION_BF16 && precision != SNERF_PRECISION_F16S8 && precision != SNERF_PRECISION_BF16S8)
         return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: precision %d not built", precision);
-    const bool bf16 = precision == SNERF_PRECISION_BF16;
-    const bool s8 = precision == SNERF_PRECISION_F16S8;
-    if (s8 && (!train || plan.depth < 2)) precision = SNERF_PRECISION_F16;     // only what the training forward SAVES differs
+    // (the fp8 modes: only what the training forward SAVES differs from their 16-bit mode)
+    if (precision == SNERF_PRECISION_F16S8 && (!train || plan.depth < 2)) precision = SNERF_PRECISION_F16;
+    if (precision == SNERF_PRECISION_BF16S8 && (!train || plan.depth < 2)) precision = SNERF_PRECISION_BF16;
+    const bool bf16 = precision == SNERF_PRECISION_BF16 || precision == SNERF_PRECISION_BF16S8;
     if (vis.wanted()) {
         SNERF_REQUIRE(desc->predict_visibility, "mlp_forward_visibility: the descriptor has predict_visibility = 0");
         SNERF_REQUIRE(vis.num_other >= 0 && vis.num_other <= 64, "mlp_forward_visibility: %d secondary views", vis.num_other);
@@ -143,6 +145,7 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
     if (precision == SNERF_PRECISION_F16 || bf16 || precision == SNERF_PRECISION_F16S8) {
         a.act_rows = plan.act16_rows();  // 16-bit pieces: same row numbers, rows of 64 bytes (mlp_plan.h)
         if (precision == SNERF_PRECISION_F16S8) return snerf::mlp_forward_s8_train(plan, a, s);
+        if (precision == SNERF_PRECISION_BF16S8) return snerf::mlp_forward_bs8_train(plan, a, s);
         return bf16 ? snerf::mlp_forward_bf16(plan, a, train, s) : snerf::mlp_forward_f16x3(plan, a, train, 1, s);
     }
     const int key = plan.wt * 100 + plan.vt * 10 + (plan.sigma_pe ? 1 : 0);

@@ -64,7 +64,7 @@ struct HalfArgs {
 template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, bool STORE, int P, int DEPTH, bool BF = false, bool S8 = false>
 __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forward_f16x3_kernel(HalfArgs args) {
     static_assert(!BF || P == 1, "bf16 operands: single-product kernels only");
-    static_assert(!S8 || (P == 1 && !BF && STORE), "8-bit saved activations: the fp16 single-product training forward");
+    static_assert(!S8 || (P == 1 && STORE), "8-bit saved activations: the single-product training forwards");
     // (only the 256-wide trunk: its weight-gradient products are the large register-tile class, the one built to read fp8 tiles;
     // a 128-wide MLP's are folded into the small-job launch and keep fp16 activations -- for it this mode IS the fp16 mode)
     constexpr bool SAVE8 = S8 && WT == 8;
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         else split_tile<true>(acc[u], xh[2 * u], xl[2 * u], xh[2 * u + 1], xl[2 * u + 1]);
     }
     if (STORE16) {
-        if (SAVE8 && depth > 1) { store_pieces8<HK>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK / 2); }   // h_1
+        if (SAVE8 && depth > 1) { store_pieces8<HK, BF>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK / 2); }   // h_1
         else { store_pieces<HK>(xh, tile16 + a.act_h1 * 32, lane); st.note_vmem(HK); }
     }
 
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         }
         if (STORE16) {
             // (h_D, the last trunk tensor, stays fp16: it also feeds the small head products)
-            if (SAVE8 && !last) { store_pieces8<HK>(xh, tile16 + a.act_h1 * 32 + l * (WT * 512), lane); st.note_vmem(HK / 2); }
+            if (SAVE8 && !last) { store_pieces8<HK, BF>(xh, tile16 + a.act_h1 * 32 + l * (WT * 512), lane); st.note_vmem(HK / 2); }
             else { store_pieces<HK>(xh, tile16 + (a.act_h1 + l * a.width) * 32, lane); st.note_vmem(HK); }
         }
     };
@@ -311,18 +311,18 @@ int launch_half(const HalfArgs& args, hipStream_t stream) {
 }
 
 // FORMAT: 3 = split precision (SNERF_PRECISION_F16X3), 1 = single fp16 product (SNERF_PRECISION_F16), 2 = single bf16 product
-// (SNERF_PRECISION_BF16), 4 = the training forward of SNERF_PRECISION_F16S8 (fp16 products, trunk activations saved as fp8).
-// One translation unit instantiates the format it serves (mlp_forward_f16x3.hip: 3; mlp_forward_f16.hip: 1;
-// mlp_forward_bf16.hip: 2; mlp_forward_s8.hip: 4), so that they compile side by side.
+// (SNERF_PRECISION_BF16), 4 / 5 = the training forward of SNERF_PRECISION_F16S8 / _BF16S8 (fp16 / bf16 products, trunk
+// activations saved as fp8).  One translation unit instantiates the format it serves (mlp_forward_f16x3.hip: 3;
+// mlp_forward_f16.hip: 1; mlp_forward_bf16.hip: 2; mlp_forward_s8.hip: 4; mlp_forward_bs8.hip: 5), so that they compile side by side.
 template <int WT, int VT, bool VIEWDEP, bool SIGMA_PE, int FORMAT>
 int launch_variant(const HalfArgs& args, bool train, hipStream_t stream) {
     constexpr int P = FORMAT == 3 ? 3 : 1;
-    constexpr bool BF = FORMAT == 2;
-    if constexpr (FORMAT == 4) {        // training only (rendering in this mode IS the fp16 mode)
+    constexpr bool BF = FORMAT == 2 || FORMAT == 5;
+    if constexpr (FORMAT == 4 || FORMAT == 5) {        // training only (rendering in these modes IS the fp16 / bf16 mode)
         if constexpr (WT == 8 && VIEWDEP) {
-            if (args.m.depth == 8) return launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, 1, 8, false, true>(args, stream);
+            if (args.m.depth == 8) return launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, 1, 8, BF, true>(args, stream);
         }
-        return launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, 1, 0, false, true>(args, stream);
+        return launch_half<WT, VT, VIEWDEP, SIGMA_PE, true, 1, 0, BF, true>(args, stream);
     } else {
         if constexpr (WT == 8 && VIEWDEP) {   // the shipped 8 x 256 trunk: compile-time unit schedule (the view-independent
                                               // layout spills ~300 registers when unrolled: it keeps the loop)

@@ -286,7 +286,7 @@ extern "C" int snerf_mlp_pack_for(const snerf_mlp_desc* desc, const float* const
         case SNERF_PRECISION_F16X3: case SNERF_PRECISION_F16: case SNERF_PRECISION_F16S8:
             formats = kPackF16 | (training ? 0u : kPackF16Eval);
             break;
-        case SNERF_PRECISION_BF16: formats = kPackBf16 | (training ? 0u : kPackBf16Eval); break;
+        case SNERF_PRECISION_BF16: case SNERF_PRECISION_BF16S8: formats = kPackBf16 | (training ? 0u : kPackBf16Eval); break;
         default: return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_pack_for: unknown precision %d", precision);
     }
     return pack_impl(desc, params, num_params, packed, stream, formats);

@@ -19,7 +19,8 @@ forward, the activation-keeping training forward, the backward dgrad chain and t
 accumulation; ~4x faster training than fp32 at ~1e-3 agreement -- outside the fp32 parity bar, tests/test_gpu_f16.py),
 ``'bf16'`` (the 16-bit mode on bf16 operands: no range limit, three significand bits fewer, tests/test_gpu_bf16.py) or
 ``'f16s8'`` (the fp16 16-bit mode with the saved trunk activations of 256-wide MLPs kept as fp8 e4m3 for the weight
-gradients: rendering and the forward are ``'f16'``'s bit for bit, the training iteration moves 15 % fewer HBM bytes).
+gradients: rendering and the forward are ``'f16'``'s bit for bit, the training iteration moves 15 % fewer HBM bytes;
+``'bf16s8'``: the same for the bf16 mode).
 ``configs['model']['hip_fused_render']`` = ``True``: eval-mode renders of a plain coarse + fine fp32 model as one launch
 (csrc/render_fused.hip; bit-identical, off by default).
 

@@ -17,7 +17,9 @@ PRECISION_F16X3 = 1  # fp16 hi/lo split, 3 MFMAs per product, fp32 accumulate: f
 PRECISION_F16 = 2    # 16-bit mode: one fp16 MFMA per product, fp32 accumulate / master weights; 16-bit saved tensors
 PRECISION_BF16 = 3   # the 16-bit mode on bf16 operands (BASELINE config 5's literal dtype): no range limit, 8 significand bits
 PRECISION_F16S8 = 4  # the 16-bit (fp16) mode with the saved trunk activations as fp8 e4m3: only the weight gradients differ from 'f16'
-PRECISIONS = {'fp32': PRECISION_FP32, 'f16x3': PRECISION_F16X3, 'f16': PRECISION_F16, 'bf16': PRECISION_BF16, 'f16s8': PRECISION_F16S8}
+PRECISION_BF16S8 = 5  # the bf16 mode with the saved trunk activations as fp8 e4m3: only the weight gradients differ from 'bf16'
+PRECISIONS = {'fp32': PRECISION_FP32, 'f16x3': PRECISION_F16X3, 'f16': PRECISION_F16, 'bf16': PRECISION_BF16, 'f16s8': PRECISION_F16S8,
+              'bf16s8': PRECISION_BF16S8}
 FP16_RANGE_PRECISIONS = (PRECISION_F16X3, PRECISION_F16, PRECISION_F16S8)     # the modes whose operands must stay below 65504 (Fp16RangeError)
 
 

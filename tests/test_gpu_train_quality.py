@@ -20,11 +20,11 @@ def test_sixteen_bit_training_lands_inside_the_fp32_seed_spread():
     import train_demo
     from tests import util
     seeds, iterations = (0, 1, 2), 1200
-    psnr = {p: [train_demo.run(iterations, p, False, s)['psnr_view0_after'] for s in seeds] for p in ('fp32', 'f16', 'bf16', 'f16s8')}
+    psnr = {p: [train_demo.run(iterations, p, False, s)['psnr_view0_after'] for s in seeds] for p in ('fp32', 'f16', 'bf16', 'f16s8', 'bf16s8')}
     mean = {p: statistics.fmean(v) for p, v in psnr.items()}
     # The yardstick is the seed-to-seed spread -- but not fp32's own from three runs: that estimate came out as 0.06, 0.34 and
     # 0.84 dB in three runs of this test (the trajectories change with every change of a summation order), while single runs of
-    # any precision range over 24.4 .. 29.4 dB.  Pooled over the precisions (twelve runs, eight degrees of freedom) it is stable;
+    # any precision range over 24.4 .. 29.4 dB.  Pooled over the precisions (fifteen runs, ten degrees of freedom) it is stable;
     # the gate is three standard errors of a difference of two three-seed means.
     pooled = statistics.fmean(statistics.variance(v) for v in psnr.values()) ** 0.5
     allowed = 3.0 * pooled * (2.0 / len(seeds)) ** 0.5
@@ -32,5 +32,5 @@ def test_sixteen_bit_training_lands_inside_the_fp32_seed_spread():
                  + f'; pooled seed stdev {pooled:.2f} dB [16-bit means within 3 standard errors = {allowed:.2f} dB of the fp32 mean]')
     assert mean['fp32'] > 20.0                      # the runs converge at all
     assert pooled < 2.0                             # ... and a seed does not decide by more than this
-    for p in ('f16', 'bf16', 'f16s8'):
+    for p in ('f16', 'bf16', 'f16s8', 'bf16s8'):
         assert abs(mean[p] - mean['fp32']) <= allowed, (p, mean, pooled)
