@@ -33,23 +33,23 @@ Timing protocol (every mode, every precision; ``timed_steps``):
             PE+MLP launches: device idle + the ~1 % of small kernels), so that a one-off stall is visible and attributable
             to the host or the device; ``step_trace_ms`` holds the raw per-step device times when K <= 64
 
-Printed JSON (rank 0, one line) also carries
-  roofline      fp32-MFMA roofline of the dominant kernel (fused PE+MLP forward): algorithmic FLOPs of its launches
-                inside the timed region / their HIP-event durations, against 157.3 TFLOP/s (MI355X_MICROARCH.md)
-  cpu_baseline  the oracle (torch CPU fp32 restatement of the reference path, reference chunking) timed on this
-                host on the same 1024-ray batch, best of 9 after one warm-up
-  collective    (N > 1) backend, number of ranks and bytes per rank and step torch.distributed moves, ``gather_ms`` (the
-                gather's own time per step, events around the call on the launch stream: p50 / max over the timed steps, per
-                rank) and ``per_rank`` (each rank's step_ms p50, its MLP-kernel ms per step and its elapsed seconds) so that
-                a sub-linear point is attributable to a rank, to the kernels or to the collective
-  also_measured*        the same step in the other two arithmetic modes (N = 1)
-  also_measured_frame   BASELINE configs 2 and 4 as whole frames: raygen -> render -> display conversion -> D2H of the five
-                        display outputs (Tester.predict_frame), wall time per frame.  N = 1: fern 1008x756 (reference-native),
-                        fern 504x378 (as BASELINE names it), RE10K camera at 1008x756, fp32 and f16x3.  N > 1: the RE10K frame
-                        strong-scaled over the N ranks incl. the gather (= ``--frame re10k``)
-  also_measured_train   BASELINE config 5 (the reference's training iteration, 4096 rows per GPU) in fp32 and in the
-                        16-bit mode: ms per iteration, algorithmic TFLOP/s, fraction of the matching MFMA peak
-  sustained     the headline step repeated for ~1 s of device time (the K timed steps alone are ~65 ms)
+Output contract (round 5).  stdout carries exactly ONE line of at most 2 KB, printed LAST, holding only
+  metric value unit n_gpus steps warmup ms_per_step higher_is_better scaling vs_baseline dtype data config
+  roofline      {bound, achieved, peak, unit, frac, traffic, traffic_algorithmic, traffic_source, kernel, launches,
+                avg_launch_ms}: the MFMA roofline of the dominant kernel (fused PE+MLP forward) -- algorithmic FLOPs of its
+                launches inside the timed region / their HIP-event durations on the launch stream, against the dense MFMA
+                peak of the arithmetic used (MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 matrix, 2 500 TFLOP/s fp16 / bf16)
+  cpu_baseline  {value, unit, cores, kind, sample}: the oracle (torch CPU fp32 restatement of the reference path, reference
+                chunking) timed on this host on the same 1024-ray batch, with as many threads as the job OWNS cores
+                (affinity mask capped by the cgroup CPU quota), bounded to ~10 s of CPU work
+  collective    (N > 1) {backend, ranks, bytes, gather_ms_p50}
+  also          (N = 1 default run) a handful of scalars: the same step in f16x3 / f16 / bf16 and the config-5 iteration in
+                the 16-bit modes, each with its fraction of the matching MFMA ceiling
+  extra         path of the side file (JSON) with EVERYTHING else: per-step timing, per-rank tables, the full records of the
+                secondary measurements.  ``--extras`` adds the long secondary set to it (sustained run, board power / clock,
+                whole frames of configs 2 and 4, config 5 in six precisions and three issue modes, rank share)
+Nothing is written to stderr unless ``--verbose`` (library chatter and Python warnings go to a log that is replayed on
+stderr only when the run fails), so the last non-empty line of stdout + stderr, however a caller merges them, is the result.
 """
 import argparse
 import json
@@ -156,21 +156,106 @@ def launch_ranks(num_ranks: int, script=None) -> int:
 
 
 _RESULT_FD = None
+_QUIET_LOG = None        # (file object, saved stderr descriptor) while stderr is held back
+VERBOSE = False
+EXTRA_FILE = None        # side file of the full record (set in main)
+
+LINE_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+             'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'collective', 'also', 'extra')
+ROOFLINE_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_algorithmic', 'traffic_source', 'kernel',
+                 'launches', 'avg_launch_ms')
+CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'sample')
+COLLECTIVE_KEYS = ('backend', 'ranks', 'bytes', 'gather_ms_p50')
+LINE_LIMIT = 2048
 
 
-def claim_stdout():
+def claim_stdout(quiet=True):
     """stdout carries exactly ONE line, the result: libraries write there too (RCCL prints a five-line version banner on
     stdout when the first communicator is created), so the rank keeps the real stdout for ``emit`` and points descriptor 1 --
-    whatever C or Python code prints from here on -- at stderr."""
-    global _RESULT_FD
+    whatever C or Python code prints from here on -- at stderr.  ``quiet`` (the default run): stderr itself is held back in a
+    log file that ``release_stderr(failed=True)`` replays, so that a successful run leaves nothing behind the result line
+    however the caller merges the two streams (round 4's driver record did not parse with progress lines after it)."""
+    global _RESULT_FD, _QUIET_LOG
     if _RESULT_FD is None:
         sys.stdout.flush()
+        sys.stderr.flush()
         _RESULT_FD = os.dup(1)
+        if quiet and _QUIET_LOG is None:
+            log = tempfile.TemporaryFile(mode='w+b')
+            _QUIET_LOG = (log, os.dup(2))
+            os.dup2(log.fileno(), 2)
         os.dup2(2, 1)
 
 
-def emit(line):
-    data = (json.dumps(line) + '\n').encode()
+def release_stderr(failed):
+    """give stderr back; replay what was held back if the run failed"""
+    global _QUIET_LOG
+    if _QUIET_LOG is None:
+        return
+    log, saved = _QUIET_LOG
+    _QUIET_LOG = None
+    sys.stderr.flush()
+    os.dup2(saved, 2)
+    os.close(saved)
+    if failed:
+        log.seek(0)
+        os.write(2, log.read()[-20000:])
+    log.close()
+
+
+def _short(value, digits=6):
+    """floats to ``digits`` significant digits (the line has a byte budget; the side file keeps full precision)"""
+    if isinstance(value, float):
+        return float(f'%.{digits}g' % value)
+    if isinstance(value, dict):
+        return {k: _short(v, digits) for k, v in value.items()}
+    if isinstance(value, (list, tuple)):
+        return [_short(v, digits) for v in value]
+    return value
+
+
+def compact_line(full, extra_path=None):
+    """The ONE stdout line out of the full record: the contract's keys only, sub-objects cut to theirs (module docstring)."""
+    line = {k: full[k] for k in LINE_KEYS if k in full}
+    if isinstance(line.get('roofline'), dict):
+        line['roofline'] = {k: line['roofline'][k] for k in ROOFLINE_KEYS if k in line['roofline']}
+    if isinstance(line.get('cpu_baseline'), dict):
+        line['cpu_baseline'] = {k: line['cpu_baseline'].get(k) for k in CPU_KEYS}
+    if isinstance(line.get('collective'), dict):
+        c = line['collective']
+        line['collective'] = {k: c[k] for k in COLLECTIVE_KEYS if k in c}
+        if isinstance(c.get('gather_ms'), dict):
+            line['collective']['gather_ms_p50'] = c['gather_ms'].get('p50')
+    if extra_path:
+        line['extra'] = extra_path
+    line = _short(line)
+    text = json.dumps(line, separators=(', ', ': '))
+    if len(text) > LINE_LIMIT:       # never happens with the fields above; rather lose the optional scalars than the parse
+        line.pop('also', None)
+        text = json.dumps(line, separators=(', ', ': '))
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
+
+def write_extra(full):
+    """The full record to the side file.  -> the path as the line names it (relative to the repo when inside it), or None."""
+    if not EXTRA_FILE:
+        return None
+    try:
+        os.makedirs(os.path.dirname(EXTRA_FILE) or '.', exist_ok=True)
+        with open(EXTRA_FILE, 'w') as f:
+            json.dump(full, f, indent=1)
+    except OSError:
+        return None
+    rel = os.path.relpath(EXTRA_FILE, REPO)
+    return EXTRA_FILE if rel.startswith('..') else rel
+
+
+def emit(full):
+    """Side file first, then the ONE line, last thing this process prints."""
+    text = compact_line(full, write_extra(full))
+    sys.stderr.flush()
+    data = (text + '\n').encode()
     if _RESULT_FD is None:
         sys.stdout.write(data.decode())
         sys.stdout.flush()
@@ -179,8 +264,9 @@ def emit(line):
 
 
 def progress(text):
-    """one line on stderr per phase (stdout carries the ONE JSON line): a long default run shows where it is"""
-    print(f'[bench {time.strftime("%H:%M:%S")}] {text}', file=sys.stderr, flush=True)
+    """--verbose: one line on stderr per phase (a long --extras run shows where it is).  Silent otherwise."""
+    if VERBOSE:
+        print(f'[bench {time.strftime("%H:%M:%S")}] {text}', file=sys.stderr, flush=True)
 
 
 def _pkg():
@@ -198,16 +284,53 @@ def synthetic_model(configs, seed, device, precision='fp32', fused=False):
     return model.to(device).eval()
 
 
-def host_cores():
-    """The cores this process may run on (its affinity mask; os.cpu_count() where the platform has none)."""
-    try:
-        return max(1, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        return max(1, os.cpu_count() or 1)
+def cgroup_cpu_quota():
+    """Cores the job's cgroup may use at once (cgroup v2 ``cpu.max``, v1 ``cpu.cfs_quota_us`` / ``cpu.cfs_period_us``), as a
+    float, or None when there is no quota.  The GPU boxes report 256 CPUs and a 256-wide affinity mask but schedule the job on
+    a 16-core share: this file is where that shows."""
+    def read(path):
+        try:
+            with open(path) as f:
+                return f.read().split()
+        except OSError:
+            return None
+    v2 = read('/sys/fs/cgroup/cpu.max')
+    if v2 and len(v2) == 2 and v2[0] != 'max':
+        try:
+            return float(v2[0]) / float(v2[1])
+        except (ValueError, ZeroDivisionError):
+            return None
+    quota, period = read('/sys/fs/cgroup/cpu/cpu.cfs_quota_us'), read('/sys/fs/cgroup/cpu/cpu.cfs_period_us')
+    if quota and period:
+        try:
+            q, p = float(quota[0]), float(period[0])
+            return q / p if q > 0 and p > 0 else None
+        except ValueError:
+            return None
+    return None
 
 
-CPU_LEG_TIMEOUT_S = 45.0           # the os.cpu_count() leg: hopeless where the job owns fewer cores, so it is cut short
-CPU_LEG_TIMEOUT_16_S = 100.0       # the 16-thread leg (~15 s on an idle host; one GPU box took > 45 s for it)
+CPU_LEG_MAX_THREADS = 16           # the pool's per-GPU CPU share; also the cap where no quota is visible
+
+
+def host_cores(affinity=None, quota='read', cap=CPU_LEG_MAX_THREADS):
+    """Threads for the CPU leg = the cores this job OWNS: its affinity mask (os.cpu_count() where the platform has none),
+    capped by the cgroup quota and by ``cap`` (a box that shows neither limit still schedules 16 cores per GPU; round 4's
+    256-thread leg never finished a pass there).  The arguments exist for the test."""
+    if affinity is None:
+        try:
+            affinity = len(os.sched_getaffinity(0))
+        except AttributeError:
+            affinity = os.cpu_count() or 1
+    if quota == 'read':
+        quota = cgroup_cpu_quota()
+    n = max(1, int(affinity))
+    if quota:
+        n = min(n, max(1, int(quota + 0.5)))
+    return min(n, cap) if cap else n
+
+
+CPU_LEG_TIMEOUT_S = 60.0           # hard limit of the one CPU leg (about 15 s on an idle 16-core share)
 
 
 def cpu_leg(kind, first_ray, threads, budget_seconds=9.0, max_runs=9):
@@ -238,63 +361,50 @@ def cpu_leg(kind, first_ray, threads, budget_seconds=9.0, max_runs=9):
             'best_s': min(times), 'mean_s': sum(times) / len(times)}
 
 
-def cpu_baseline(kind, first_ray):
-    """The oracle timed on this host's cores, on the same 1024-ray batch as the GPU step.  BASELINE.md section 3's protocol --
-    ``torch.set_num_threads(os.cpu_count())``, one warm-up, best of the following passes -- plus, beside it, the same at 16
-    threads (the GPU box's per-GPU CPU share).  Each leg runs in a child process with a hard time limit: where the box gives
-    this job fewer cores than ``os.cpu_count()`` reports, the first leg oversubscribes them and one pass can take minutes
-    (round 4's first attempt ran it in-process and the whole bench was killed as silent) -- such a leg is reported as timed
-    out, which is itself the reason the 16-thread figure is the baseline there.  `value` is the FASTEST leg (the baseline at
-    its best), `cores` its thread count."""
-    counts = []
-    for n in (os.cpu_count() or 1, 16):
-        if n not in counts:
-            counts.append(n)
-    legs = []
-    for n in counts:
-        cmd = [sys.executable, os.path.abspath(__file__), '--cpu-leg', str(n), '--cpu-leg-args', kind, str(first_ray)]
-        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-        env.update(OMP_NUM_THREADS=str(n), MKL_NUM_THREADS=str(n))
-        t0 = time.perf_counter()
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=CPU_LEG_TIMEOUT_S if n > 16 else CPU_LEG_TIMEOUT_16_S, env=env)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-            if r.returncode == 0 and lines:
-                legs.append(json.loads(lines[-1]))
-            else:
-                legs.append({'threads': n, 'failed': (r.stderr or r.stdout)[-300:]})
-        except subprocess.TimeoutExpired as late:
-            so_far = late.stdout.decode() if isinstance(late.stdout, bytes) else (late.stdout or '')
-            lines = [ln for ln in so_far.splitlines() if ln.startswith('{') and ln.rstrip().endswith('}')]
-            leg = json.loads(lines[-1]) if lines else {'threads': n}     # the passes it did finish, if any
-            leg['timed_out_after_s'] = round(time.perf_counter() - t0, 1)
-            leg['note'] = ('cut short: the figure is from the passes that finished' if lines else
-                           'no pass finished in time' + (': more threads than the cores this job may use' if n > 16 else ''))
-            legs.append(leg)
-    done = [r for r in legs if 'value' in r]
-    if not done:
-        return {'value': None, 'unit': 'rays/s', 'cores': None, 'kind': 'port', 'legs': legs,
-                'host': {'os_cpu_count': os.cpu_count(), 'usable_cores': host_cores()}}
-    best = max(done, key=lambda r: r['value'])
-    return {'value': best['value'], 'unit': 'rays/s', 'cores': best['threads'], 'kind': 'port',
-            'sample': f"{RAYS_PER_GPU} rays of the same workload, best of {best['runs']} after 1 warm-up ({best['best_s']:.3f} s best, "
-                      f"{best['mean_s']:.3f} s mean), torch {torch.__version__} CPU fp32, chunk 4096 / netchunk 16384",
-            'legs': legs, 'host': {'os_cpu_count': os.cpu_count(), 'usable_cores': host_cores()}}
+def cpu_baseline(kind, first_ray, threads=None):
+    """The oracle timed on this host, on the same 1024-ray batch as the GPU step: ONE bounded leg (a child process with a hard
+    time limit that reports after every finished pass, so a slow host still yields a figure) with ``host_cores()`` threads --
+    the cores the job owns, not the 256 the box advertises (BASELINE.md section 3 says os.cpu_count(); on this pool that leg
+    oversubscribes a 16-core share and does not finish one pass in 45 s: DESIGN.md section 6)."""
+    n = int(threads or host_cores())
+    host = {'os_cpu_count': os.cpu_count(), 'cgroup_quota_cores': cgroup_cpu_quota(), 'threads_used': n}
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-leg', str(n), '--cpu-leg-args', kind, str(first_ray)]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(OMP_NUM_THREADS=str(n), MKL_NUM_THREADS=str(n))
+    t0 = time.perf_counter()
+    leg = None
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=CPU_LEG_TIMEOUT_S, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode == 0 and lines:
+            leg = json.loads(lines[-1])
+        else:
+            host['failed'] = (r.stderr or r.stdout)[-300:]
+    except subprocess.TimeoutExpired as late:
+        so_far = late.stdout.decode() if isinstance(late.stdout, bytes) else (late.stdout or '')
+        lines = [ln for ln in so_far.splitlines() if ln.startswith('{') and ln.rstrip().endswith('}')]
+        leg = json.loads(lines[-1]) if lines else None       # the passes it did finish, if any
+        host['timed_out_after_s'] = round(time.perf_counter() - t0, 1)
+    if leg is None:
+        return {'value': None, 'unit': 'rays/s', 'cores': n, 'kind': 'port', 'sample': 'no pass finished', 'host': host}
+    return {'value': leg['value'], 'unit': 'rays/s', 'cores': n, 'kind': 'port',
+            'sample': f"{RAYS_PER_GPU} rays of the headline batch, best of {leg['runs']} passes after 1 warm-up ({leg['best_s']:.2f} s best), "
+                      f"torch CPU fp32, chunk 4096 / netchunk 16384",
+            'leg': leg, 'host': host}
 
 
 def pmc_traffic(precision):
     """HBM bytes per launch of the dominant kernel and where the figure comes from.  bench.py cannot read the memory
     counters of its own process (they need rocprofv3 around it): the figure is the one a separate ``rocprofv3 --pmc`` run of
-    this same command wrote to profiles/ (tools/pmc_passes.sh + tools/collect_pmc.py), named in ``traffic_source`` with the
-    commit it was collected at.  -> (bytes or None, source text or None)"""
+    this same command wrote to profiles/ (tools/pmc_passes.sh + tools/collect_pmc.py; FETCH_SIZE | WRITE_SIZE with the guide's
+    gfx950 corrections), named in ``traffic_source`` with the commit it was collected at.  -> (bytes or None, source or None)"""
     name = 'pmc_traffic.json' if precision == 'fp32' else f'pmc_traffic_{precision}.json'
     path = os.path.join(REPO, 'profiles', name)
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
         record = json.load(f)
-    source = (f"profiles/{name}: separate rocprofv3 --pmc passes of `bench.py --no-cpu-baseline --no-alt` (FETCH_SIZE | WRITE_SIZE), "
-              f"collected at commit {record.get('commit', 'unrecorded')} -- NOT measured in this run")
+    source = f"profiles/{name} @ {record.get('commit', 'unrecorded')} (separate rocprofv3 --pmc passes, not this run)"
     return record.get('mlp_forward_hbm_bytes_per_launch'), source
 
 
@@ -505,18 +615,24 @@ class HipRenderer:
 
 
 # ---------------------------------------------------------------------------------------------- config 5 (training)
-def training_step(precision, rank, world, device, single_pass=False, graphed=False, collective=False):
+def training_step(precision, rank, world, device, single_pass=False, graphed=False, collective=False, rows_per_gpu=4096):
     """BASELINE config 5: a callable running ONE iteration of the reference's training loop (Trainer.train_one_iter,
-    src/Trainer01.py:60-107) with every stage on the device: batch assembly (2048 pixel + 2048 sparse-depth rows per GPU,
-    each rank a slice of one global index stream), four MLPs forward, nine losses, backward, ONE all-reduce of the
-    flattened gradients (RCCL) for N > 1, Adam with the decayed rate.  Weak scaling: 4096 rows per GPU."""
+    src/Trainer01.py:60-107) with every stage on the device: batch assembly (pixel rows + as many sparse-depth rows, each rank
+    a slice of one global index stream), four MLPs forward, nine losses, backward, ONE all-reduce of the flattened gradients
+    (RCCL) for N > 1, Adam with the decayed rate.  ``rows_per_gpu`` = 4096: weak scaling, the reference's whole batch on every
+    GPU.  ``rows_per_gpu`` = 4096 / N: BASELINE config 5 as stated -- ONE 4096-row batch over the N ranks (8 ranks x
+    512 rows); the reference cuts its batch into two 2048-row sub-batches BEFORE DataParallel scatters each over the devices
+    (Trainer01.py:82-93), so a rank's share is processed as two sub-batches of rows_per_gpu / 2."""
     harness, _, synth, get_model = _pkg()
     from simplenerf_amd import optim
     from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
     from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
     from simplenerf_amd.lr_decayers.LearningRateDecayerFactory import get_lr_decayer
-    rows = 2048
+    if rows_per_gpu % 2 or rows_per_gpu <= 0:
+        raise SystemExit('--rows-per-gpu: an even number of rows (half pixel rows, half sparse-depth rows)')
+    rows = rows_per_gpu // 2
     cfg = synth.training_configs(precision, num_rays=rows * world, num_sparse=rows * world)
+    cfg['sub_batch_size'] = rows          # this rank's share of each of the reference's two sub-batches
     model = get_model(cfg, None)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
@@ -538,7 +654,8 @@ def training_step(precision, rank, world, device, single_pass=False, graphed=Fal
         if world > 1:
             raise SystemExit('the graphed training iteration is a single-GPU measurement')
         # (with single_pass: ONE model pass, i.e. the reference's loop with sub_batch_size = batch size -- Trainer01.py:82)
-        graph = harness.GraphedIteration(model, losses, opt, batcher, decayer, sub_batch_size=None if single_pass else cfg['sub_batch_size'])
+        graph = harness.GraphedIteration(model, losses, opt, batcher, decayer, sub_batch_size=None if single_pass else cfg['sub_batch_size'],
+                                         force_collective=collective)
 
     def step():
         it = state['iter']
@@ -555,21 +672,32 @@ def training_step(precision, rank, world, device, single_pass=False, graphed=Fal
                                       force_collective=collective)
 
     step.short_batches = 0
+    step.model = model
     return step, 2 * rows
 
 
 TRAIN_WORKLOAD = ('config 5: 2048 pixel + 2048 sparse-depth rows per GPU in two sub-batches, main coarse+fine + points-aug + '
                   'views-aug MLPs (64 + 192 samples), nine shipped losses, Adam, NeRF LR decay')
+
+
+def train_workload(rows_per_gpu, world, strong):
+    half = rows_per_gpu // 2
+    if strong:
+        return (f'config 5 as BASELINE states it: ONE {rows_per_gpu * world}-row batch over {world} rank(s) = {half} pixel + {half} '
+                'sparse-depth rows per GPU in two sub-batches, 4 MLPs (64 + 192 samples), nine losses, one gradient all-reduce, Adam')
+    return TRAIN_WORKLOAD.replace('2048 pixel + 2048', f'{half} pixel + {half}')
 TRAIN_DTYPE = {'fp32': 'f32', 'f16x3': 'f16x3', 'f16': 'f16 (bf16 layer gradients)', 'bf16': 'bf16',
                'f16s8': 'f16 (bf16 layer gradients, fp8 e4m3 saved trunk activations)',
                'bf16s8': 'bf16 (fp8 e4m3 saved trunk activations)'}
 
 
-def time_training(precision, device, steps, warmup, single_pass=False, board_seconds=0.0, graphed=False):
+def time_training(precision, device, steps, warmup, single_pass=False, board_seconds=0.0, graphed=False, rows_per_gpu=4096,
+                  collective=False):
     """Config 5 on one GPU: (ms per iteration, ms of MLP forward launches, ms of MLP backward calls, rows, timing summary)
-    from ``steps`` timed iterations after a settle phase and ``warmup`` iterations."""
+    from ``steps`` timed iterations after a settle phase and ``warmup`` iterations.  ``rows_per_gpu`` / ``collective``: one
+    rank's share of the 4096-row batch with the gradient all-reduce in the loop (a one-rank RCCL group)."""
     _, ops, _, _ = _pkg()
-    step, rows = training_step(precision, 0, 1, device, single_pass, graphed)
+    step, rows = training_step(precision, 0, 1, device, single_pass, graphed, collective, rows_per_gpu)
     settle(step, None, chunk=2)
     ops.profile_enable(64 * (steps + warmup))
     for _ in range(warmup):
@@ -643,9 +771,22 @@ def training_record(device, steps=10, warmup=3):
     return out
 
 
+def train_rows_per_gpu(args, world):
+    """rows of the training batch one GPU holds: --rows-per-gpu R, or --global-rows G (strong scaling: G / N), else 4096"""
+    if args.global_rows:
+        if args.global_rows % (2 * world):
+            raise SystemExit(f'--global-rows {args.global_rows}: not a multiple of 2 x {world} ranks')
+        return args.global_rows // world, True
+    return (args.rows_per_gpu or 4096), False
+
+
 def train_bench(args, rank, world, device, dist):
-    """--train: BASELINE config 5 instead of the headline metric (see training_step)."""
-    step, per_gpu = training_step(args.precision, rank, world, device, args.single_pass, collective=dist is not None)
+    """--train: BASELINE config 5 instead of the headline metric (see training_step).  Default: weak scaling, 4096 rows per
+    GPU.  ``--global-rows 4096``: the config as BASELINE states it -- ONE 4096-row batch over the N ranks (`scaling: strong`);
+    ``--rows-per-gpu 512 --force-collective`` on one GPU is what one rank of eight then does, all-reduce included."""
+    per_gpu, strong = train_rows_per_gpu(args, world)
+    step, per_gpu = training_step(args.precision, rank, world, device, args.single_pass, graphed=args.graphed,
+                                  collective=dist is not None, rows_per_gpu=per_gpu)
 
     def fence():
         if dist is not None:
@@ -665,28 +806,67 @@ def train_bench(args, rank, world, device, dist):
         line = {
             'metric': 'training rays/sec (config 5: forward + backward + optimiser, 4 MLPs, 9 losses)',
             'value': per_gpu * world * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': TRAIN_DTYPE[args.precision], 'data': 'synthetic',
-            'config': {'workload': TRAIN_WORKLOAD, 'rows_per_gpu': per_gpu, 'single_pass': bool(args.single_pass),
-                       'parallelism': f'row-shard x{world}' + (' + 1 gradient all-reduce/step' if world > 1 else '')},
+            'config': {'workload': train_workload(per_gpu, world, strong), 'rows_per_gpu': per_gpu, 'global_rows': per_gpu * world,
+                       'single_pass': bool(args.single_pass), 'graphed': bool(args.graphed),
+                       'parallelism': f'row-shard x{world}' + (' + 1 gradient all-reduce/step' if dist is not None else '')},
             'algorithmic_tflops': per_gpu * TRAIN_FLOP_PER_RAY * world * args.steps / elapsed / 1e12,
             'timing': step_summary(elapsed, device_ms, enqueue_ms, None)}
         line['timing']['short_batches'] = step.short_batches   # timed iterations with fewer than rows_per_gpu rows (epoch ends)
-        traffic = pmc_train_traffic(args.precision)
+        traffic = pmc_train_traffic(args.precision) if per_gpu == 4096 else None
         line['roofline'] = {'bound': 'mfma',      # (what `achieved` / `peak` are; the HBM side of the iteration is `traffic`)
                             'achieved': line['algorithmic_tflops'] / world,
                             'peak': {'fp32': PEAK_FP32_MFMA_TFLOPS, 'f16x3': PEAK_FP16_MFMA_TFLOPS / 3}.get(args.precision, PEAK_FP16_MFMA_TFLOPS),
                             'unit': 'TFLOP/s', 'traffic': None if traffic is None else traffic['hbm_gb_per_iteration'] * 1e9,
                             'traffic_source': None if traffic is None else traffic['source'],
+                            'kernel': 'whole iteration (all kernels)',
                             'note': 'whole-iteration wall time against the MFMA peak of the mode; `traffic` = HBM bytes per iteration, '
-                                    'all kernels: / 6.3 TB/s it is the HBM floor (5.0-5.9 ms in the 16-bit modes; DESIGN.md 10.5 '
-                                    'says what bounds each kernel above it)'}
+                                    'all kernels: / 6.3 TB/s it is the HBM floor (DESIGN.md says what bounds each kernel above it)'}
         line['roofline']['frac'] = line['roofline']['achieved'] / line['roofline']['peak']
         if dist is not None:
             line['collective'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(), 'bytes': 2265488 * 4,
                                   'pattern': 'one all-reduce of the flattened parameter gradients per iteration',
                                   'per_rank': [{'rank': i, 'step_ms_p50': r[0], 'elapsed_s': r[1]} for i, r in enumerate(ranks)]}
         emit(line)
+
+
+def one_rank_group(device):
+    """A one-rank RCCL process group for measurements that want the collective in the loop on a one-GPU box.  -> dist"""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
+    return dist
+
+
+def rank_share_record(device, steps=20, warmup=5, precisions=('f16', 'bf16s8')):
+    """What ONE rank of N does in BASELINE config 5 as stated (one 4096-row batch over N ranks): the iteration at 4096 / N rows
+    with the 9.06 MB gradient all-reduce issued (a one-rank RCCL group), against the 4096-row iteration / N -- the per-rank
+    fixed costs (partial-sum buffers and their reductions, re-pack, optimiser, launch count) are what separates the two.
+    `overhead` = t(rows) / (t(4096) / N); VERDICT r4 #3 asks for <= 1.3 at 512 rows."""
+    dist = one_rank_group(device)
+    out = {'what': 'one rank of N in the strong-scaled config-5 iteration: rows = 4096 / N, gradient all-reduce in the loop (one-rank RCCL group)',
+           'modes': {}}
+    try:
+        for precision in precisions:
+            entry = {}
+            for name, kwargs in (('eager', {}), ('graphed', {'graphed': True})):
+                full_ms, _, _, _ = time_training(precision, device, steps, warmup, collective=True, **kwargs)
+                rows_ms = {}
+                for rows in (2048, 1024, 512):
+                    ms, _, _, _ = time_training(precision, device, steps, warmup, rows_per_gpu=rows, collective=True, **kwargs)
+                    rows_ms[str(rows)] = {'ms_per_step': ms, 'ranks': 4096 // rows, 'overhead': ms / (full_ms * rows / 4096),
+                                          'job_rays_per_s_if_all_ranks_ran_at_this_rate': 4096 / (ms * 1e-3)}
+                entry[name] = {'ms_per_step_4096_rows': full_ms, 'rows': rows_ms}
+            out['modes'][precision] = entry
+    finally:
+        dist.destroy_process_group()
+    return out
 
 
 # ---------------------------------------------------------------------------------------------- whole frames (configs 2, 4)
@@ -848,76 +1028,118 @@ def render_bench(args, rank, world, device, dist, make_renderer, data):
     if rank != 0:
         return
     if not collective and alt and gpu:
-        harness, ops, synth, _ = _pkg()
+        result['also'] = quick_also(args, device, make_renderer, fence, result)
+        progress('secondary scalars done')
+        if args.extras:
+            long_extras(args, rank, world, device, make_renderer, fence, renderer, result)
+    if world == 1 and gpu and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline('headline', renderer.first, args.cpu_threads)
+        progress('cpu baseline done')
+    emit(result)
 
-        def board_state(r, achieved_tflops, nominal_peak, seconds=1.2):
-            """the same step back to back for ~1.2 s with the board's sensors sampled: power, cap, shader clock, and the
-            fraction of the peak AT THAT CLOCK (the nominal peaks are quoted at 2.4 GHz; the sysfs clock is the firmware's
-            average, in-kernel clock reads are lower -- tools/probes/gap_ab.py measures them on the diagnostic build)"""
-            sampler = BoardSampler(device.index or 0)
-            with torch.no_grad(), sampler:
-                t0 = time.perf_counter()
-                while time.perf_counter() - t0 < seconds:
-                    for _ in range(25):
-                        r.local()
-                    torch.cuda.synchronize()
-            state = sampler.summary()
-            if state['sclk_mhz']:
-                # sysfs freq1_input is the firmware's average: in the same runs the clock INSIDE the kernels
-                # (d s_memtime / d s_memrealtime of the -DSNERF_CLOCK_STAMP diagnostic build) read 8 % (16-bit) and 3 % (f16x3)
-                # lower, 0 % for fp32 -- profiles/r03_gap_ab_box*.jsonl; this fraction is therefore a LOWER bound of the one at
-                # the true clock
-                state['frac_of_peak_at_sysfs_clock'] = achieved_tflops / (nominal_peak * state['sclk_mhz'] / 2400.0)
-                state['sclk_source'] = 'sysfs hwmon freq1_input (reads 3-8 % above the in-kernel clock under fp16 load)'
-            return state
 
-        def tflops(meas):
-            return sum(meas['launch_samples']) * FLOP_PER_SAMPLE / (sum(meas['launch_ms']) * 1e-3) / 1e12
-
-        sustained_steps = 300       # ~1 s of device time
-        s = measure_headline(renderer, sustained_steps, args.warmup, fence, 1, do_settle=False)
-        s_tf = tflops(s)
-        result['sustained'] = {'steps': sustained_steps, 'value': RAYS_PER_GPU * sustained_steps / s['elapsed'], 'unit': 'rays/s',
-                               'ms_per_step': s['elapsed'] / sustained_steps * 1e3, 'achieved': s_tf,
-                               'frac': s_tf / PEAK_FP32_MFMA_TFLOPS, 'timed_region_s': s['elapsed'],
-                               'timing': step_summary(s['elapsed'], s['device_ms'], s['enqueue_ms'], sum(s['launch_ms'])),
-                               'board': board_state(renderer, s_tf, PEAK_FP32_MFMA_TFLOPS)}
-        progress('sustained leg done')
-        for key, precision, text in (
-                ('also_measured', 'f16x3', 'f16x3 (fp16 hi/lo split, 3 MFMA passes per product, fp32 accumulate; same parity tests)'),
-                ('also_measured_16bit', 'f16', 'f16 (one fp16 MFMA pass per product, fp32 accumulate; OUTSIDE the fp32 parity bar -- '
-                 'colour ~1e-4, depth ~6e-4 from the fp32 path, tests/test_gpu_f16.py; BASELINE config 5 names this mode for training)'),
-                ('also_measured_bf16', 'bf16', 'bf16 (one bf16 MFMA pass per product, fp32 accumulate; BASELINE config 5\'s literal dtype, no '
-                 'range limit; OUTSIDE the fp32 parity bar -- colour ~1e-3, tests/test_gpu_bf16.py)')):
+def quick_also(args, device, make_renderer, fence, result):
+    """The ``also`` object of the default N = 1 line: a handful of scalars measured with the SAME protocol (settle, warm-up,
+    fenced K steps) -- the headline step in the other arithmetic modes and BASELINE config 5's iteration in the 16-bit modes,
+    each with its fraction of the matching dense MFMA ceiling (f16x3: fp16 peak / 3, three MFMA passes per product).  The
+    full records go to the side file under ``also_full``.  A leg that fails is null here, with its error in the side file."""
+    also, full = {}, {}
+    for precision in ('f16x3', 'f16', 'bf16'):
+        try:
             r = make_renderer(precision, 'headline')
             a = measure_headline(r, args.steps, args.warmup, fence, 1)
             line = headline_line(1, args.steps, args.warmup, precision, a['elapsed'], a['device_ms'], a['enqueue_ms'],
                                  a['launch_ms'], a['launch_samples'], a['dropped'], a['settle_info'])
-            if precision == 'f16x3':
-                line['roofline']['frac_of_fp16_peak'] = line['roofline']['achieved'] / PEAK_FP16_MFMA_TFLOPS
-            result[key] = {'precision': text, 'value': line['value'], 'unit': 'rays/s', 'ms_per_step': line['ms_per_step'],
-                           'roofline': line['roofline'], 'timing': line['timing'],
-                           'board': board_state(r, line['roofline']['achieved'], PRECISION_INFO[precision][0])}
+            full[precision] = {k: line[k] for k in ('value', 'ms_per_step', 'dtype', 'roofline', 'timing')}
+            also[precision] = {'rays_s': line['value'], 'frac': line['roofline']['frac']}
             del r
-        # the same fp32 step with the whole render as ONE launch (the ray group's sample tile stays in LDS: render_fused.hip)
-        r = HipRenderer('fp32', device, rank, world, 'headline', collective=False, fused=True)
+        except Exception as err:            # noqa: BLE001 -- the headline must survive a failing secondary leg
+            also[precision], full[precision] = None, {'error': repr(err)[:500]}
+    for precision in ('f16', 'bf16s8'):
+        key = f'train_{precision}'
+        try:
+            ms, fwd_ms, bwd_ms, rows = time_training(precision, device, 10, 3)
+            tflops = rows * TRAIN_FLOP_PER_RAY / (ms * 1e-3) / 1e12
+            full[key] = {'workload': TRAIN_WORKLOAD, 'dtype': TRAIN_DTYPE[precision], 'ms_per_step': ms, 'rows': rows,
+                         'value': rows / (ms * 1e-3), 'algorithmic_tflops': tflops, 'peak_tflops': PEAK_FP16_MFMA_TFLOPS,
+                         'mlp_forward_ms_per_step': fwd_ms, 'mlp_backward_ms_per_step': bwd_ms, 'timing': time_training.timing}
+            also[key] = {'ms': ms, 'frac': tflops / PEAK_FP16_MFMA_TFLOPS}
+        except Exception as err:            # noqa: BLE001
+            also[key], full[key] = None, {'error': repr(err)[:500]}
+    result['also_full'] = full
+    return also
+
+
+def long_extras(args, rank, world, device, make_renderer, fence, renderer, result):
+    """--extras: the long secondary set, all of it into the side file (N = 1)."""
+    harness, ops, synth, _ = _pkg()
+
+    def board_state(r, achieved_tflops, nominal_peak, seconds=1.2):
+        """the same step back to back for ~1.2 s with the board's sensors sampled: power, cap, shader clock, and the
+        fraction of the peak AT THAT CLOCK (the nominal peaks are quoted at 2.4 GHz; the sysfs clock is the firmware's
+        average, in-kernel clock reads are lower -- tools/probes/gap_ab.py measures them on the diagnostic build)"""
+        sampler = BoardSampler(device.index or 0)
+        with torch.no_grad(), sampler:
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                for _ in range(25):
+                    r.local()
+                torch.cuda.synchronize()
+        state = sampler.summary()
+        if state['sclk_mhz']:
+            # sysfs freq1_input is the firmware's average: in the same runs the clock INSIDE the kernels
+            # (d s_memtime / d s_memrealtime of the -DSNERF_CLOCK_STAMP diagnostic build) read 8 % (16-bit) and 3 % (f16x3)
+            # lower, 0 % for fp32 -- profiles/r03_gap_ab_box*.jsonl; this fraction is therefore a LOWER bound of the one at
+            # the true clock
+            state['frac_of_peak_at_sysfs_clock'] = achieved_tflops / (nominal_peak * state['sclk_mhz'] / 2400.0)
+            state['sclk_source'] = 'sysfs hwmon freq1_input (reads 3-8 % above the in-kernel clock under fp16 load)'
+        return state
+
+    def tflops(meas):
+        return sum(meas['launch_samples']) * FLOP_PER_SAMPLE / (sum(meas['launch_ms']) * 1e-3) / 1e12
+
+    sustained_steps = 300       # ~1 s of device time
+    s = measure_headline(renderer, sustained_steps, args.warmup, fence, 1, do_settle=False)
+    s_tf = tflops(s)
+    result['sustained'] = {'steps': sustained_steps, 'value': RAYS_PER_GPU * sustained_steps / s['elapsed'], 'unit': 'rays/s',
+                           'ms_per_step': s['elapsed'] / sustained_steps * 1e3, 'achieved': s_tf,
+                           'frac': s_tf / PEAK_FP32_MFMA_TFLOPS, 'timed_region_s': s['elapsed'],
+                           'timing': step_summary(s['elapsed'], s['device_ms'], s['enqueue_ms'], sum(s['launch_ms'])),
+                           'board': board_state(renderer, s_tf, PEAK_FP32_MFMA_TFLOPS)}
+    progress('sustained leg done')
+    for key, precision, text in (
+            ('also_measured', 'f16x3', 'f16x3 (fp16 hi/lo split, 3 MFMA passes per product, fp32 accumulate; same parity tests for rendering)'),
+            ('also_measured_16bit', 'f16', 'f16 (one fp16 MFMA pass per product, fp32 accumulate; OUTSIDE the fp32 parity bar -- '
+             'colour ~1e-4, depth ~6e-4 from the fp32 path, tests/test_gpu_f16.py; BASELINE config 5 names this mode for training)'),
+            ('also_measured_bf16', 'bf16', 'bf16 (one bf16 MFMA pass per product, fp32 accumulate; BASELINE config 5\'s literal dtype, no '
+             'range limit; OUTSIDE the fp32 parity bar -- colour ~1e-3, tests/test_gpu_bf16.py)')):
+        r = make_renderer(precision, 'headline')
         a = measure_headline(r, args.steps, args.warmup, fence, 1)
-        line = headline_line(1, args.steps, args.warmup, 'fp32', a['elapsed'], a['device_ms'], a['enqueue_ms'],
+        line = headline_line(1, args.steps, args.warmup, precision, a['elapsed'], a['device_ms'], a['enqueue_ms'],
                              a['launch_ms'], a['launch_samples'], a['dropped'], a['settle_info'])
-        line['roofline']['kernel'] = 'render_fused_kernel<8,4,2,4> (K2 + K3 coarse + K4 + K5 + K3 fine + K4 in one launch)'
-        result['also_measured_fused'] = {'what': "configs['model']['hip_fused_render'] = True: bit-identical outputs (tests/test_gpu_fused.py), "
-                                                 'one launch per step instead of six', 'value': line['value'], 'unit': 'rays/s',
-                                         'ms_per_step': line['ms_per_step'], 'roofline': line['roofline'], 'timing': line['timing']}
+        if precision == 'f16x3':
+            line['roofline']['frac_of_fp16_peak'] = line['roofline']['achieved'] / PEAK_FP16_MFMA_TFLOPS
+        result[key] = {'precision': text, 'value': line['value'], 'unit': 'rays/s', 'ms_per_step': line['ms_per_step'],
+                       'roofline': line['roofline'], 'timing': line['timing'],
+                       'board': board_state(r, line['roofline']['achieved'], PRECISION_INFO[precision][0])}
         del r
-        progress('other precisions done')
-        result['also_measured_frame'] = frame_records_single(make_renderer, fence)
-        progress('frames done')
-        result['also_measured_train'] = training_record(device)
-        progress('training records done')
-    if world == 1 and gpu and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline('headline', renderer.first)
-        progress('cpu baseline done')
-    emit(result)
+    # the same fp32 step with the whole render as ONE launch (the ray group's sample tile stays in LDS: render_fused.hip)
+    r = HipRenderer('fp32', device, rank, world, 'headline', collective=False, fused=True)
+    a = measure_headline(r, args.steps, args.warmup, fence, 1)
+    line = headline_line(1, args.steps, args.warmup, 'fp32', a['elapsed'], a['device_ms'], a['enqueue_ms'],
+                         a['launch_ms'], a['launch_samples'], a['dropped'], a['settle_info'])
+    line['roofline']['kernel'] = 'render_fused_kernel<8,4,2,4> (K2 + K3 coarse + K4 + K5 + K3 fine + K4 in one launch)'
+    result['also_measured_fused'] = {'what': "configs['model']['hip_fused_render'] = True: bit-identical outputs (tests/test_gpu_fused.py), "
+                                             'one launch per step instead of six', 'value': line['value'], 'unit': 'rays/s',
+                                     'ms_per_step': line['ms_per_step'], 'roofline': line['roofline'], 'timing': line['timing']}
+    del r
+    progress('other precisions done')
+    result['also_measured_frame'] = frame_records_single(make_renderer, fence)
+    progress('frames done')
+    result['also_measured_train'] = training_record(device)
+    progress('training records done')
+    result['also_measured_train']['rank_share'] = rank_share_record(device)
+    progress('rank share done')
 
 
 def visible_gpus():
@@ -929,7 +1151,7 @@ def main(argv=None, renderer_cls=None, backend='nccl', share_devices=False, scri
     """``renderer_cls`` / ``backend`` / ``share_devices`` / ``script`` are for tests/bench_rehearsal.py only (a GPU-less
     stand-in renderer, gloo instead of RCCL, several ranks on one GPU, and the file the self-launcher starts its ranks from);
     `python bench.py` always runs HipRenderer over RCCL with one rank per GPU."""
-    global SETTLE_SECONDS
+    global SETTLE_SECONDS, VERBOSE, EXTRA_FILE
     ap = argparse.ArgumentParser()
     ap.add_argument('--train', action='store_true',
                     help='measure BASELINE config 5 (training iteration) instead of the headline render metric')
@@ -954,12 +1176,27 @@ def main(argv=None, renderer_cls=None, backend='nccl', share_devices=False, scri
                     help="arithmetic of the fused MLP kernel: fp32 MFMA; fp16 hi/lo split with 3 MFMAs per product "
                          "(fp32-grade results, same parity tests); or f16 = one fp16 MFMA per product with 16-bit saved "
                          "tensors (BASELINE config 5's 16-bit training mode, own tolerances: tests/test_gpu_f16.py)")
+    ap.add_argument('--extras', action='store_true',
+                    help='N = 1: also run the long secondary set (sustained run with board power / clock, the other precisions with '
+                         'their boards, the fused render kernel, whole frames of configs 2 and 4, config 5 in every precision and '
+                         'issue mode, the rank share of the strong-scaled iteration) -- into the side file, never onto the line')
+    ap.add_argument('--extra-file', default=None,
+                    help='side file for the full record (default: gpurun_out/bench_extra.json under the repo)')
+    ap.add_argument('--verbose', action='store_true', help='progress lines and library chatter on stderr (default: none)')
+    ap.add_argument('--cpu-threads', type=int, default=None, help='threads of the CPU baseline leg (default: the cores this job owns)')
+    ap.add_argument('--global-rows', type=int, default=None,
+                    help='--train: ONE batch of that many rows over the N ranks (BASELINE config 5 as stated: 4096; scaling: strong)')
+    ap.add_argument('--rows-per-gpu', type=int, default=None,
+                    help="--train: rows of the batch per GPU (default 4096); 512 with --force-collective = one rank's share of eight")
+    ap.add_argument('--graphed', action='store_true', help='--train, N = 1: the whole iteration replayed from one HIP graph')
     ap.add_argument('--cpu-leg', type=int, default=None, help=argparse.SUPPRESS)          # child of cpu_baseline: THREADS
     ap.add_argument('--cpu-leg-args', nargs=2, default=None, help=argparse.SUPPRESS)       # workload kind, first ray
     args = ap.parse_args(argv)
     if args.cpu_leg is not None:           # no GPU, no process group: one CPU leg, one JSON line
         print(json.dumps(cpu_leg(args.cpu_leg_args[0], int(args.cpu_leg_args[1]), args.cpu_leg)), flush=True)
         return
+    VERBOSE = bool(args.verbose)
+    EXTRA_FILE = os.path.abspath(args.extra_file) if args.extra_file else os.path.join(REPO, 'gpurun_out', 'bench_extra.json')
     if args.settle_seconds is not None:
         SETTLE_SECONDS = max(0.0, args.settle_seconds)
     if args.steps is None:
@@ -973,7 +1210,16 @@ def main(argv=None, renderer_cls=None, backend='nccl', share_devices=False, scri
             raise SystemExit(f'--gpus {args.gpus}: this node has {visible_gpus()} GPU(s); RCCL needs one device per rank')
         raise SystemExit(launch_ranks(args.gpus, script))       # nothing above this line touches the GPU
 
-    claim_stdout()
+    claim_stdout(quiet=not VERBOSE)
+    failed = True
+    try:
+        _run_rank(args, renderer_cls, backend, share_devices, standin)
+        failed = False
+    finally:
+        release_stderr(failed)
+
+
+def _run_rank(args, renderer_cls, backend, share_devices, standin):
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))

@@ -19,8 +19,38 @@ OBJ_DIR = os.path.join(CSRC, 'build')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -ffp-contract=off: the elementwise stages must round exactly like the reference's separate torch/numpy ops;
 # fused multiply-adds are written explicitly (fmaf) where they are wanted.
+# -include probe_guard.h: every translation unit refuses to compile with a diagnostic switch defined unless SNERF_PROBE_BUILD is
+# defined too (see that header).
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wall', '-Wno-unused-function', '-Wno-inline-asm',
-         f'-I{INCLUDE}']
+         f'-I{INCLUDE}', '-include', os.path.join(CSRC, 'probe_guard.h')]
+DIAGNOSTIC_PREFIXES = ('SNERF_ABL_', 'SNERF_PROBE_', 'SNERF_CLOCK_STAMP')
+# where a stray -D can come from besides ``extra_flags``: the compiler command itself and the variables hipcc / clang append
+FLAG_ENVIRONMENT = ('HIPCC', 'HIPCC_COMPILE_FLAGS_APPEND', 'HIPCC_LINK_FLAGS_APPEND', 'HIP_CLANG_FLAGS', 'CXXFLAGS', 'CPPFLAGS', 'CFLAGS',
+                    'CCC_OVERRIDE_OPTIONS')
+
+
+def diagnostic_switches(extra_flags=(), environ=None):
+    """Diagnostic macros (ablations / probes: wrong results by design) that would reach the compiler: [(where, text)]."""
+    environ = os.environ if environ is None else environ
+    found = [('extra_flags', f) for f in extra_flags if any(p in f for p in DIAGNOSTIC_PREFIXES)]
+    for name in FLAG_ENVIRONMENT:
+        value = environ.get(name, '')
+        if any(p in value for p in DIAGNOSTIC_PREFIXES):
+            found.append((name, value))
+    return found
+
+
+def check_shipped_build(extra_flags, output, environ=None):
+    """The shipped library (``output`` == LIB) is built with FLAGS alone: refuse any diagnostic switch, wherever it comes from.
+    A variant must carry -DSNERF_PROBE_BUILD and another output name (tools/probes/build_variant.py does both)."""
+    found = diagnostic_switches(extra_flags, environ)
+    if os.path.abspath(output) == os.path.abspath(LIB):
+        if found:
+            raise RuntimeError('refusing to build the shipped library with diagnostic switches (they produce wrong results by design): '
+                               + '; '.join(f'{where}: {text}' for where, text in found)
+                               + ' -- use tools/probes/build_variant.py, which writes gpurun_abl_<name>.so')
+    elif found and not any('SNERF_PROBE_BUILD' in f for f in extra_flags):
+        raise RuntimeError('a diagnostic variant must be built with -DSNERF_PROBE_BUILD (tools/probes/build_variant.py adds it)')
 
 
 def _sources():
@@ -43,6 +73,7 @@ def _stale(target, deps):
 def build_library(force: bool = False, verbose: bool = False, extra_flags=(), output: str = LIB, obj_dir: str = OBJ_DIR) -> str:
     """``extra_flags`` / ``output`` / ``obj_dir``: diagnostic variants (tools/probes/build_variant.py) -- the shipped library is
     always built with FLAGS alone."""
+    check_shipped_build(extra_flags, output)
     os.makedirs(obj_dir, exist_ok=True)
     headers = _headers()
     jobs = []

@@ -155,3 +155,53 @@ extern "C" int snerf_range_status(int clear) {
     if (!flag) return SNERF_E_HIP;
     return clear ? __atomic_exchange_n(flag, 0, __ATOMIC_ACQ_REL) : __atomic_load_n(flag, __ATOMIC_ACQUIRE);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// packed-format registry (snerf_common.h)
+#include <unordered_map>
+namespace snerf {
+namespace {
+std::mutex g_formats_mutex;
+std::unordered_map<const float*, unsigned> g_formats;
+constexpr size_t kFormatsCapacity = 1 << 16;     // distinct packed buffers remembered; beyond it the table starts over
+
+const char* formats_text(unsigned formats, char* buffer, size_t size) {
+    snprintf(buffer, size, "%s%s%s%s%s", (formats & kPackFp32) ? "fp32 " : "", (formats & kPackF16) ? "f16-training " : "",
+             (formats & kPackF16Eval) ? "f16-rendering " : "", (formats & kPackBf16) ? "bf16-training " : "",
+             (formats & kPackBf16Eval) ? "bf16-rendering " : "");
+    return buffer;
+}
+}  // namespace
+
+void packed_formats_record(const float* packed, unsigned formats) {
+    std::lock_guard<std::mutex> lock(g_formats_mutex);
+    if (g_formats.size() >= kFormatsCapacity) g_formats.clear();
+    g_formats[packed] = formats;
+}
+
+int packed_formats_require(const float* packed, unsigned needed, const char* what) {
+    unsigned have;
+    {
+        std::lock_guard<std::mutex> lock(g_formats_mutex);
+        auto it = g_formats.find(packed);
+        if (it == g_formats.end()) return SNERF_OK;       // never packed through this library instance: cannot tell
+        have = it->second;
+    }
+    if ((have & needed) == needed) return SNERF_OK;
+    char a[96], b[96];
+    return fail(SNERF_E_INVALID, "%s: this packed buffer holds the operand formats [ %s] (its last snerf_mlp_pack_for), the call reads "
+                                 "[ %s]: the missing streams are zero-filled -- pack with snerf_mlp_pack, or snerf_mlp_pack_for the "
+                                 "precision and mode it is used at", what, formats_text(have, a, sizeof a),
+                formats_text(needed, b, sizeof b));
+}
+
+unsigned packed_formats_needed(int precision, bool training) {
+    switch (precision) {
+        case SNERF_PRECISION_FP32: return kPackFp32;
+        case SNERF_PRECISION_F16X3: case SNERF_PRECISION_F16: case SNERF_PRECISION_F16S8:
+            return kPackF16 | (training ? 0u : kPackF16Eval);
+        case SNERF_PRECISION_BF16: case SNERF_PRECISION_BF16S8: return kPackBf16 | (training ? 0u : kPackBf16Eval);
+        default: return 0u;
+    }
+}
+}  // namespace snerf

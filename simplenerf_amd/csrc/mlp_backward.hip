@@ -1265,8 +1265,11 @@ extern "C" size_t snerf_mlp_backward_workspace_floats(const snerf_mlp_desc* desc
     if (plan_status == SNERF_E_UNSUPPORTED && snerf::generic_takes(desc, &layered))
         return snerf::generic_backward_workspace_floats(layered, num_rays * num_samples);
     if (plan_status != SNERF_OK) return 0;
-    return (size_t)std::max(plan_workspace(plan, num_rays * num_samples, false).total_floats,
-                            plan_workspace(plan, num_rays * num_samples, true).total_floats);
+    // every plan snerf_mlp_backward can build for this shape: fp32 / f16x3 tiles, the 16-bit tiles, and the 16-bit tiles with
+    // fp8 saved activations (its per-job chunk distribution differs: block costs of 0.8, spare redistribution -- ADVICE r4)
+    const long long total = num_rays * num_samples;
+    return (size_t)std::max({plan_workspace(plan, total, false).total_floats, plan_workspace(plan, total, true).total_floats,
+                             plan_workspace(plan, total, true, true).total_floats});
 }
 
 extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packed, const float* saved_acts,
@@ -1300,6 +1303,10 @@ extern "C" int snerf_mlp_backward(const snerf_mlp_desc* desc, const float* packe
     if (precision != SNERF_PRECISION_FP32 && !bf16) {   // the forward that saved these activations may have left the fp16 range
         const int range = snerf::report_range("mlp_backward");
         if (range != SNERF_OK) return range;
+    }
+    {   // the backward chain reads the transposed weight stream of the training layout (snerf_common.h)
+        const int formats = snerf::packed_formats_require(packed, snerf::packed_formats_needed(precision, true), "mlp_backward");
+        if (formats != SNERF_OK) return formats;
     }
     const long long total = num_rays * num_samples;
     if ((total + 127) / 128 > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_backward: too many samples");

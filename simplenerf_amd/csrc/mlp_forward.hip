@@ -110,6 +110,11 @@ static int forward_impl(const snerf_mlp_desc* desc, const float* packed, const f
         if (plan.sigma_pe)
             return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward_visibility: not built for the points-augmentation layout");
     }
+    {   // the weight streams this call reads must be the ones the buffer's last pack wrote (snerf_common.h)
+        const int formats = snerf::packed_formats_require(packed, snerf::packed_formats_needed(precision, train),
+                                                          train ? "mlp_forward_train" : "mlp_forward");
+        if (formats != SNERF_OK) return formats;
+    }
     if (num_rays == 0) return SNERF_OK;
     MlpArgs a;
     a.range_flag = nullptr;

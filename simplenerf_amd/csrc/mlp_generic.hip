@@ -251,32 +251,39 @@ int linear_forward(const float* acts_in, float* acts_out, long long row, long lo
     return launch_gemm(g, 0, s);
 }
 
-// per-device scratch of the inference entry point (the ABI gives it no workspace argument)
-struct Arena { float* base = nullptr; size_t floats = 0; };
+// Scratch of the inference entry point (the ABI gives it no workspace argument): one block per (device, stream), so that two
+// layered-shape forwards on different streams or threads of a device do not share an activation matrix (they used
+// to).  A block is NEVER freed or moved once handed out -- an in-flight kernel or a captured graph may hold its address; a
+// larger request on the same stream allocates another block and the old one stays (sizes are bounded by kInferenceChunk rows,
+// so a stream grows its block a handful of times at most).  Growing inside a graph capture is refused: the allocation would be
+// a synchronous call the capture cannot contain.
+struct ArenaBlock { int device; hipStream_t stream; float* base; size_t floats; };
 std::mutex g_arena_mutex;
-Arena g_arena[64];
+std::vector<ArenaBlock> g_arena;
 
-int arena(size_t floats, float** out) {
+int arena(size_t floats, hipStream_t stream, float** out) {
     int device = 0;
-    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return snerf::fail(SNERF_E_HIP, "mlp_forward(layered): no current HIP device");
+    if (hipGetDevice(&device) != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_forward(layered): no current HIP device");
     std::lock_guard<std::mutex> lock(g_arena_mutex);
-    Arena& a = g_arena[device];
-    if (a.floats < floats) {
-        if (a.base) {
-            (void)hipDeviceSynchronize();     // an earlier call's kernels may still read it
-            (void)hipFree(a.base);
-            a.base = nullptr; a.floats = 0;
+    for (const ArenaBlock& b : g_arena)
+        if (b.device == device && b.stream == stream && b.floats >= floats) {
+            *out = b.base;
+            return SNERF_OK;
         }
-        void* p = nullptr;
-        const hipError_t e = hipMalloc(&p, floats * sizeof(float));
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return snerf::fail(SNERF_E_HIP, "mlp_forward(layered): scratch of %zu MB: %s (a first call of this path must not be inside a "
-                                            "graph capture)", floats * sizeof(float) >> 20, hipGetErrorString(e));
-        }
-        a.base = static_cast<float*>(p); a.floats = floats;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
+        return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward(layered): the scratch block of this stream must grow to %zu MB, which a graph "
+                                                "capture cannot contain -- run one call of this size on the stream before capturing",
+                           floats * sizeof(float) >> 20);
+    (void)hipGetLastError();
+    void* p = nullptr;
+    const hipError_t e = hipMalloc(&p, floats * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return snerf::fail(SNERF_E_HIP, "mlp_forward(layered): scratch of %zu MB: %s", floats * sizeof(float) >> 20, hipGetErrorString(e));
     }
-    *out = a.base;
+    g_arena.push_back({device, stream, static_cast<float*>(p), floats});
+    *out = static_cast<float*>(p);
     return SNERF_OK;
 }
 
@@ -417,7 +424,7 @@ int generic_forward(const GenericPlan& p, const float* packed, const float* orig
         return forward_rows(p, packed, origins, dirs, view_dirs, depths, 0, total, num_samples, noise, sigma, rgb, saved_acts, s);
     const long long rays_per_chunk = std::max(1LL, kInferenceChunk / num_samples);
     float* scratch = nullptr;
-    const int rc = arena((size_t)std::min(num_rays, rays_per_chunk) * num_samples * p.row, &scratch);
+    const int rc = arena((size_t)std::min(num_rays, rays_per_chunk) * num_samples * p.row, s, &scratch);
     if (rc != SNERF_OK) return rc;
     for (long long ray = 0; ray < num_rays; ray += rays_per_chunk) {
         const long long rays = std::min(rays_per_chunk, num_rays - ray);

@@ -175,8 +175,9 @@ extern "C" size_t snerf_mlp_packed_floats(const snerf_mlp_desc* desc) {
 }
 
 namespace {
-// which 16-bit copies of the weights a pack writes besides the fp32 segments, biases and heads (everything else is zeroed)
-constexpr unsigned kPackF16 = 1u, kPackF16Eval = 2u, kPackBf16 = 4u, kPackBf16Eval = 8u, kPackFp32 = 16u, kPackAll = 31u;
+// which 16-bit copies of the weights a pack writes besides the fp32 segments, biases and heads (everything else is zeroed):
+// snerf::kPackF16 ... kPackAll (snerf_common.h); the mask of every packed buffer is recorded for the consumers' check
+using snerf::kPackF16; using snerf::kPackF16Eval; using snerf::kPackBf16; using snerf::kPackBf16Eval; using snerf::kPackFp32; using snerf::kPackAll;
 
 int pack_impl(const snerf_mlp_desc* desc, const float* const* params, int num_params, float* packed, snerf_stream_t stream,
               unsigned formats) {
@@ -269,7 +270,9 @@ int pack_impl(const snerf_mlp_desc* desc, const float* const* params, int num_pa
     }
     hipLaunchKernelGGL(copy_rows_kernel, dim3(4, ncopies), dim3(256), 0, s, copies, packed);
     if (e != hipSuccess) return snerf::fail(SNERF_E_HIP, "mlp_pack: copy: %s", hipGetErrorString(e));
-    return snerf::check_launch("mlp_pack");
+    const int launched = snerf::check_launch("mlp_pack");
+    if (launched == SNERF_OK) snerf::packed_formats_record(packed, formats);
+    return launched;
 }
 }  // namespace
 
@@ -280,14 +283,7 @@ extern "C" int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* pa
 
 extern "C" int snerf_mlp_pack_for(const snerf_mlp_desc* desc, const float* const* params, int num_params, float* packed,
                                   int precision, int training, snerf_stream_t stream) {
-    unsigned formats = 0;
-    switch (precision) {
-        case SNERF_PRECISION_FP32: formats = kPackFp32; break;
-        case SNERF_PRECISION_F16X3: case SNERF_PRECISION_F16: case SNERF_PRECISION_F16S8:
-            formats = kPackF16 | (training ? 0u : kPackF16Eval);
-            break;
-        case SNERF_PRECISION_BF16: case SNERF_PRECISION_BF16S8: formats = kPackBf16 | (training ? 0u : kPackBf16Eval); break;
-        default: return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_pack_for: unknown precision %d", precision);
-    }
+    const unsigned formats = snerf::packed_formats_needed(precision, training != 0);
+    if (!formats) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_pack_for: unknown precision %d", precision);
     return pack_impl(desc, params, num_params, packed, stream, formats);
 }

@@ -194,6 +194,10 @@ int render_forward_fused(const snerf_render_config* cfg, const snerf_render_mlp*
     const bool counts_64_128 = s_c == 64 && s_f == 128, counts_128_128 = s_c == 128 && s_f == 128;
     if (!counts_64_128 && !counts_128_128) return SNERF_E_UNSUPPORTED;
     if (!out->depths_fine) return SNERF_E_UNSUPPORTED;
+    for (int l : {0, 3}) {       // the fused kernel reads the fp32 K-segment slabs of both buffers (snerf_common.h)
+        st = packed_formats_require(mlps[l].packed, kPackFp32, "render_forward (fused)");
+        if (st != SNERF_OK) { *eligible = 1; return st; }
+    }
     FusedArgs f;
     const float* origins = cfg->ndc ? rays->rays_o_ndc : rays->rays_o;
     const float* dirs = cfg->ndc ? rays->rays_d_ndc : rays->rays_d;

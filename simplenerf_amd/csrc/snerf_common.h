@@ -57,6 +57,19 @@ constexpr int kRangeActivation = 1, kRangeWeight = 2;
 int* range_flag();
 int report_range(const char* what);
 
+// Which operand formats a packed weight buffer holds: snerf_mlp_pack_for writes only what one precision reads in one
+// mode and ZEROES the rest, so a buffer packed for (f16, training) read by an eval render -- or an fp32-packed one read at f16 --
+// used to return bias-only output with SNERF_OK.  The library keeps, on the host, the format mask of every buffer a pack call
+// has written (keyed by the buffer's address; updated at enqueue time, which is stream order for a caller that packs and
+// consumes on one stream); every entry point that consumes a weight stream asks for the bits it reads and fails with
+// SNERF_E_INVALID before enqueuing anything when the buffer's last pack did not write them.  A buffer the registry has never
+// seen (a device-to-device copy of a packed buffer) is not checked.
+constexpr unsigned kPackF16 = 1u, kPackF16Eval = 2u, kPackBf16 = 4u, kPackBf16Eval = 8u, kPackFp32 = 16u, kPackAll = 31u;
+void packed_formats_record(const float* packed, unsigned formats);
+int packed_formats_require(const float* packed, unsigned needed, const char* what);
+// the mask an entry point reads: precision (enum snerf_precision) x (training layout | rendering layout)
+unsigned packed_formats_needed(int precision, bool training);
+
 // Grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8 blocks, never more than the work.
 inline unsigned stride_grid(long long work, int block) {
     long long blocks = (work + block - 1) / block;

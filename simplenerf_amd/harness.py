@@ -452,6 +452,8 @@ class GraphedIteration:
             self.ring.advance()
         batch = self.batcher.get_next_batch(iter_num, at=self.ring.current)
         totals = self._passes(batch, self.ring.current)
+        if not whole:      # the eager warm-up: which trainable parameters does the backward leave without a gradient?
+            self._gradless = [p for p in self.model.parameters() if p.requires_grad and p.grad is None]
         allreduce_gradients(self.model.parameters(), self.world, self.group, self.force_collective)
         if whole:
             self.opt.step_at(self.ring.current)
@@ -473,6 +475,13 @@ class GraphedIteration:
         torch.cuda.current_stream(self.device).wait_stream(side)
         for p in self.model.parameters():
             p.grad = None                      # gradients are (re)allocated inside the capture: static addresses
+        if self.world > 1 or self.force_collective:
+            # ... except for parameters the backward never reaches: the all-reduce gives those a zero stand-in (every rank must
+            # flatten the same layout), and ASSIGNING ``p.grad`` inside a capture would hand the optimiser a buffer of the graph's
+            # private pool that no replay re-creates.  They get their static zero buffer here, before the capture;
+            # inside it the all-reduce only copies into buffers that exist.
+            for p in getattr(self, '_gradless', ()):
+                p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
         self.model.invalidate_packed()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

@@ -143,28 +143,29 @@ def test_two_rank_training_iteration_equals_single_process(tmp_path):
 
 
 def _run_bench(ranks, *flags):
-    import json
-    import subprocess
+    """-> (the ONE stdout line, the full record from the side file); tests/util.run_bench holds the run to the output contract"""
     import sys
+    from tests import util
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-    r = subprocess.run([sys.executable, os.path.join(repo, 'tests', 'bench_rehearsal.py'), '--standin', '--backend', 'gloo', '--',
-                        '--gpus', str(ranks), *flags], capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0, r.stdout + r.stderr
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, r.stdout
-    return json.loads(lines[0])
+    return util.run_bench([sys.executable, os.path.join(repo, 'tests', 'bench_rehearsal.py'), '--standin', '--backend', 'gloo', '--',
+                           '--gpus', str(ranks), *flags], timeout=600)
 
 
-@pytest.mark.parametrize('ranks', [2, 3])
+@pytest.mark.parametrize('ranks', [2, 3, 8])
 def test_bench_self_launches_its_ranks(ranks):
     """``python bench.py --gpus N`` with no launcher around it (how the driver calls it): bench.py starts its N rank
     processes itself, they rendezvous over torch.distributed (gloo here, RCCL on a GPU node), every rank contributes its
     1024-ray block to the gather, and the parent relays ONE JSON line whose ``collective`` object reports the ranks.  The
     renderer is replaced by the CPU stand-in (tests/bench_rehearsal.py calls bench.main with it) -- what is exercised is the launcher and the N > 1
     protocol (settle, warm-up, fenced timed region with per-step stamps, max over ranks), which needs no GPU.  The default
-    N > 1 line also carries BASELINE config 4's frame, strong-scaled over the same ranks (``also_measured_frame``)."""
-    line = _run_bench(ranks, '--steps', '3', '--warmup', '1')
+    N > 1 record also carries BASELINE config 4's frame, strong-scaled over the same ranks (``also_measured_frame``).  Round 5:
+    the stdout line is the short contract line (tests/util.run_bench), everything else is read from the side file it names;
+    ``ranks = 8`` is the driver's ``--gpus 8`` command line run once without hardware (eight 1024-ray blocks, the 8-way
+    ``per_rank`` table, 190-ray frame shards)."""
+    short, line = _run_bench(ranks, '--steps', '3', '--warmup', '1')
+    assert short['collective'] == {'backend': 'gloo', 'ranks': ranks, 'bytes': 1024 * 16,
+                                   'gather_ms_p50': pytest.approx(line['collective']['gather_ms']['p50'], rel=1e-4, abs=1e-9)}
+    assert short['value'] == pytest.approx(line['value'], rel=1e-4) and 'timing' not in short and 'also_measured_frame' not in short
     assert line['n_gpus'] == ranks and line['steps'] == 3 and line['warmup'] == 1 and line['scaling'] == 'weak'
     assert line['collective']['backend'] == 'gloo' and line['collective']['ranks'] == ranks
     assert line['collective']['bytes'] == 1024 * 16
@@ -185,13 +186,14 @@ def test_bench_self_launches_its_ranks(ranks):
     assert frames['collective']['bytes_per_rank_and_frame'] == -(-rays // ranks) * 28
 
 
-@pytest.mark.parametrize('ranks', [1, 2, 3])
+@pytest.mark.parametrize('ranks', [1, 2, 3, 8])
 def test_bench_frame_mode_strong_scales_one_frame(ranks):
     """``python bench.py --gpus N --frame re10k`` (BASELINE config 4: one full frame, rays block-sharded over the ranks, one
     gather to rank 0): the stand-in frame has 1517 rays -- ragged over 2 and 3 ranks -- and rank 0 checks every gathered
     frame element by element inside bench.py."""
-    line = _run_bench(ranks, '--frame', 're10k', '--steps', '2', '--warmup', '1')
+    short, line = _run_bench(ranks, '--frame', 're10k', '--steps', '2', '--warmup', '1')
     rays = 37 * 41
+    assert short['scaling'] == 'strong' and short['config']['rays_per_gpu'] == -(-rays // ranks)
     assert line['n_gpus'] == ranks and line['steps'] == 2 and line['scaling'] == 'strong' and line['data'] == 'stand-in'
     assert line['config']['rays_per_frame'] == rays and line['config']['rays_per_gpu'] == -(-rays // ranks)
     assert line['value'] == pytest.approx(rays / (line['ms_per_step'] * 1e-3), rel=1e-9)
@@ -204,7 +206,7 @@ def test_bench_frame_mode_strong_scales_one_frame(ranks):
 def test_bench_force_collective_runs_the_multi_rank_protocol_with_one_rank(mode):
     """``--force-collective`` at N = 1: a one-rank process group, barriers in the fences, the gather in every step and the
     max-over-ranks reduction -- the code the N > 1 line runs (under RCCL on a GPU box: tests/test_gpu_dist.py)."""
-    line = _run_bench(1, '--force-collective', '--steps', '2', '--warmup', '1', *mode)
+    _, line = _run_bench(1, '--force-collective', '--steps', '2', '--warmup', '1', *mode)
     assert line['n_gpus'] == 1 and line['collective']['backend'] == 'gloo' and line['collective']['ranks'] == 1
     if not mode:
         assert len(line['collective']['per_rank']) == 1 and 'gather' in line['config']['parallelism']
@@ -255,12 +257,10 @@ def test_bench_under_the_drivers_launcher():
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-                        '--master-port', str(port), os.path.join(repo, 'tests', 'bench_rehearsal.py'), '--standin', '--backend', 'gloo',
-                        '--', '--gpus', '2', '--steps', '3', '--warmup', '1'], capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, r.stdout
-    line = json.loads(lines[0])
+    from tests import util
+    short, line = util.run_bench([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                                  '127.0.0.1', '--master-port', str(port), os.path.join(repo, 'tests', 'bench_rehearsal.py'), '--standin',
+                                  '--backend', 'gloo', '--', '--gpus', '2', '--steps', '3', '--warmup', '1'], env=env, timeout=600)
+    assert short['n_gpus'] == 2 and short['collective']['ranks'] == 2
     assert line['n_gpus'] == 2 and line['steps'] == 3 and line['warmup'] == 1 and line['scaling'] == 'weak'
     assert line['collective']['ranks'] == 2 and line['value'] > 0 and len(line['timing']['step_trace_ms']) == 3

@@ -1,0 +1,165 @@
+"""The model run the way the REFERENCE runs it: wrapped in ``torch.nn.DataParallel(model, device_ids=[0])``
+(src/Trainer01.py:513-514, src/Tester01.py:39-43 -- the reference ALWAYS wraps, also on one GPU), driven by the trainer's own
+loop (Trainer.train_one_iter, src/Trainer01.py:61-107: zero_grad(set_to_none=True), sub-batches sliced out of every tensor of
+the batch, ``common_data`` copied per sub-batch, ``self.model(sub_input_batch)``, ``compute_losses``, ``TotalLoss.backward()``,
+``optimizer.step()`` of a ``torch.optim.Adam(list(model.parameters()))``), saved with ``model.state_dict()`` (keys
+``module.…``, :352-366) and loaded back into a second wrapped model as ``NerfTester.load_model`` does (src/Tester01.py:45-49),
+then rendered with ``self.model(input_dict, sec_views_vis=False)`` under ``no_grad`` (:57-66).
+
+Everything of the batch passes through DataParallel's ``scatter`` on the way in -- the per-row ``global_rows`` / ``indices``
+tensors, ``common_data`` with its leading replica axis, the plain ints ``iter_num`` / ``num_frames``, the ``retraw=`` /
+``sec_views_vis=`` keyword arguments -- and the C++ autograd node writes ``p.grad`` of parameters that live under
+``module.``.  Gate: gradients, parameters and rendered outputs BIT-equal to the unwrapped model driven by
+``harness.train_one_iter``; and the wrapped model against the reference's end-to-end goldens at north_star's tolerances.
+"""
+import numpy
+import pytest
+import torch
+
+from oracle import nerf_oracle as oracle
+from simplenerf_amd import harness, synth
+from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
+from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
+from simplenerf_amd.lr_decayers.LearningRateDecayerFactory import get_lr_decayer
+from simplenerf_amd.models.ModelFactory import get_model
+from tests import util
+from tests.test_gpu_model import build, check_outputs
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _fresh_model(cfg, seed=7):
+    model = get_model(cfg, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed, 200.0, 8.0).items()})
+    return model
+
+
+def _reference_train_one_iter(model, loss_computer, optimizer, input_batch, configs):
+    """Trainer.train_one_iter (src/Trainer01.py:79-102), statement for statement, on an already assembled batch."""
+    optimizer.zero_grad(set_to_none=True)
+    actual_batch_size = input_batch['rays_o'].shape[0]
+    sub_batch_size = configs.get('sub_batch_size', actual_batch_size)
+    totals = {}
+    for start_idx in range(0, actual_batch_size, sub_batch_size):
+        sub_input_batch = {}
+        for key in input_batch.keys():
+            if isinstance(input_batch[key], torch.Tensor):
+                sub_input_batch[key] = input_batch[key][start_idx: start_idx + sub_batch_size]
+            elif key == 'common_data':
+                sub_input_batch[key] = input_batch[key].copy()
+            else:
+                sub_input_batch[key] = input_batch[key]
+        sub_output_batch = model(sub_input_batch)
+        sub_iter_losses_dict = loss_computer.compute_losses(sub_input_batch, sub_output_batch)
+        sub_iter_losses_dict['TotalLoss'].backward()
+        for name, entry in sub_iter_losses_dict.items():
+            value = entry['loss_value'] if isinstance(entry, dict) else entry
+            totals[name] = totals.get(name, 0.0) + float(value)
+    optimizer.step()
+    return totals
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'f16'])
+def test_reference_trainer_and_tester_drive_the_wrapped_model(precision, tmp_path):
+    cfg = synth.training_configs(precision, num_rays=2048, num_sparse=2048)       # BASELINE config 5's 4096-row batch
+    scene = synth.training_scene(sparse_points=2048 * 16)
+    wrapped = torch.nn.DataParallel(_fresh_model(cfg), device_ids=[0])             # Trainer01.py:513-514
+    wrapped.to(DEV)                                                                # Trainer01.py:58
+    plain = _fresh_model(cfg).to(DEV)
+    make_adam = lambda m: torch.optim.Adam(list(m.parameters()), lr=cfg['optimizer']['lr_initial'],
+                                           betas=(cfg['optimizer']['beta1'], cfg['optimizer']['beta2']))   # Trainer01.py:516-517
+    opt_w, opt_p = make_adam(wrapped), make_adam(plain)
+    decayer = get_lr_decayer(cfg)
+    losses_w, losses_p = LossComputer(cfg), LossComputer(cfg)
+    batcher_w, batcher_p = BatchAssembler(cfg, scene, DEV), BatchAssembler(cfg, scene, DEV)
+    wrapped.train()
+    plain.train()
+    names = [n for n, _ in plain.named_parameters()]
+    assert [n for n, _ in wrapped.named_parameters()] == ['module.' + n for n in names]
+    for it in (20000, 20001, 20002):
+        lr = decayer.get_updated_learning_rate(it)
+        for opt in (opt_w, opt_p):
+            for group in opt.param_groups:
+                group['lr'] = lr                                                   # Trainer01.py:293-295
+        batch_w, batch_p = batcher_w.get_next_batch(it), batcher_p.get_next_batch(it)
+        assert batch_w['rays_o'].shape[0] == 4096 and batch_w['common_data']['poses'].dim() == 4      # leading replica axis
+        assert isinstance(batch_w['iter_num'], int) and batch_w['global_rows'].shape == (4096,)
+        keys_before = list(batch_w.keys())
+        totals_w = _reference_train_one_iter(wrapped, losses_w, opt_w, batch_w, cfg)
+        totals_p = harness.train_one_iter(plain, losses_p, opt_p, batch_p, cfg['sub_batch_size'])
+        assert list(batch_w.keys()) == keys_before
+        assert set(totals_w) == set(totals_p)
+        for name in totals_w:
+            assert totals_w[name] == pytest.approx(float(totals_p[name]), rel=1e-6, abs=1e-12), (it, name)      # (fp64 vs fp32 sum of two values)
+        for (name, pw), pp in zip(wrapped.named_parameters(), plain.parameters()):
+            assert pw.grad is not None and torch.equal(pw.grad, pp.grad), (it, name)
+            assert torch.equal(pw.detach(), pp.detach()), (it, name)
+    assert float(totals_w['TotalLoss']) > 0 and all(numpy.isfinite(v) for v in totals_w.values())
+    # the step moved the weights and the next forward saw them (re-pack through the wrapper)
+    first = dict(_fresh_model(cfg).named_parameters())
+    assert any(not torch.equal(p.detach().cpu(), first[n].detach()) for n, p in plain.named_parameters())
+
+    # Trainer.save_model (Trainer01.py:352-366) -> NerfTester.build_model / load_model (Tester01.py:39-49)
+    path = tmp_path / 'Model_Iter020003.tar'
+    torch.save({'iteration_num': 20003, 'model_state_dict': wrapped.state_dict(), 'optimizer_state_dict': opt_w.state_dict()}, path)
+    tester_model = torch.nn.DataParallel(get_model(cfg, None), device_ids=[0])
+    tester_model.to(DEV)
+    checkpoint_state = torch.load(path, map_location=DEV)
+    assert all(k.startswith('module.') for k in checkpoint_state['model_state_dict'])
+    assert sorted(checkpoint_state['model_state_dict']) == sorted('module.' + n for n in names)
+    result = tester_model.load_state_dict(checkpoint_state['model_state_dict'])
+    assert not result.missing_keys and not result.unexpected_keys and checkpoint_state['iteration_num'] == 20003
+    tester_model.eval()
+    plain.eval()
+    # NerfTester.predict_frame (Tester01.py:57-66): a full-frame batch slice, no_grad, sec_views_vis=False
+    cam = synth.camera('fern', 0)
+    h, w = cam['resolution']
+    input_dict = harness.frame_batch(cam, True, DEV, (h // 2) * w, 3000)
+    with torch.no_grad():
+        output_dict = tester_model(input_dict, sec_views_vis=False)
+        expected = plain(input_dict, sec_views_vis=False)
+        raw = tester_model(input_dict, retraw=True, sec_views_vis=False)            # Trainer.run_validation's call (:194)
+    assert list(output_dict.keys()) == list(expected.keys()) and 'rgb_fine' in output_dict and 'z_vals_fine' not in output_dict
+    for key in expected:
+        assert output_dict[key].device.type == 'cuda' and torch.equal(output_dict[key], expected[key]), key
+    assert 'z_vals_fine' in raw and 'raw_sigma_fine' in raw and torch.equal(raw['rgb_fine'], expected['rgb_fine'])
+    assert float(expected['acc_fine'].mean()) > 0.05          # not an empty frame
+    display = harness.retrieve_inference_outputs(cfg, (1, 3000), output_dict)
+    assert display['image'].dtype == numpy.uint8 and display['image'].shape == (1, 3000, 3)
+
+
+@pytest.mark.parametrize('kind,profile', [('config2', 'consistent'), ('config1', 'dense'), ('headline', 'consistent')])
+def test_wrapped_model_matches_the_reference_goldens(kind, profile):
+    """The reference's end-to-end eval goldens (G6) through ``DataParallel(model, device_ids=[0])``: same gates as the unwrapped
+    model (tests/test_gpu_model.py), and outputs bit-equal to it."""
+    g = util.load(f'e2e_{kind}_{profile}.npz')
+    cfg = synth.make_configs(kind)
+    inner = build(cfg, g).eval()
+    wrapped = torch.nn.DataParallel(inner, device_ids=[0]).eval()
+    batch = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
+    with torch.no_grad():
+        out = wrapped(batch, retraw=True)
+        direct = inner(batch, retraw=True)
+        plain = wrapped(batch)
+    ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
+    check_outputs(out, ref, strict_fine=(profile == 'consistent'), tag=f'dataparallel/{kind}/{profile}', dense=(profile == 'dense'))
+    assert list(out.keys()) == list(direct.keys()) and all(torch.equal(out[k], direct[k]) for k in out)
+    assert sorted(plain.keys()) == sorted(g['eval_keys'].tolist())
+
+
+def test_wrapped_training_forward_matches_the_reference_golden():
+    """Training-mode forward of config 3 (both augmentation MLPs; all 50 output keys) through the wrapper, the reference's CPU
+    draws replayed and injected on the wrapped module."""
+    g = util.load('e2e_config3_train_det_consistent.npz')
+    cfg = synth.with_overrides(synth.make_configs('config3'), perturb=bool(g['perturb']), raw_noise_std=float(g['raw_noise_std']))
+    wrapped = torch.nn.DataParallel(build(cfg, g), device_ids=[0]).train()
+    batch = {k: v.to(DEV) for k, v in util.golden_batch(g).items()}
+    draws = oracle.replay_reference_draws(cfg, batch['rays_o'].shape[0], int(g['torch_seed']))
+    wrapped.module.set_random_draws(draws[0])
+    with torch.no_grad():
+        out = wrapped(batch)
+    ref = {k[4:]: v for k, v in g.items() if k.startswith('out_')}
+    assert len(ref) == 50
+    check_outputs(out, ref, strict_fine=True, tag='dataparallel/train/det/consistent')

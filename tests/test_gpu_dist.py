@@ -89,19 +89,15 @@ def test_two_rank_training_reproduces_the_single_process_run(tmp_path, precision
 
 
 def _bench(*flags):
-    import json
-    import subprocess
+    """-> the full record of a two-rank rehearsal run (the stdout line is held to the output contract by tests/util.run_bench)"""
     import sys
+    from tests import util
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     # two ranks share the box's one GPU: RCCL refuses that, gloo carries the collectives (tests/bench_rehearsal.py hands
     # bench.main the backend and the permission to share a device; bench.py itself has neither switch)
-    r = subprocess.run([sys.executable, os.path.join(repo, 'tests', 'bench_rehearsal.py'), '--backend', 'gloo', '--share-devices', '--',
-                        '--gpus', '2', *flags], capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    _, full = util.run_bench([sys.executable, os.path.join(repo, 'tests', 'bench_rehearsal.py'), '--backend', 'gloo', '--share-devices',
+                              '--', '--gpus', '2', *flags], timeout=900)
+    return full
 
 
 def test_bench_two_ranks_with_the_real_renderer():
@@ -132,15 +128,7 @@ def test_bench_training_line_counts_full_size_iterations_only():
     """``python bench.py --train --precision f16``: every timed iteration of BASELINE config 5 runs 2048 pixel + 2048
     sparse-depth rows (the synthetic scene's sparse-depth epoch is a whole number of batches; until round 3 every third
     iteration was 1 572 rows short and the line still divided by 4096), and the line says so (``timing.short_batches``)."""
-    import json
-    import subprocess
-    import sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--train', '--precision', 'f16', '--steps', '7', '--warmup', '2',
-                        '--no-alt', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    line = _plain_bench('--train', '--precision', 'f16', '--steps', '7', '--warmup', '2', '--no-alt', '--no-cpu-baseline', timeout=600)
     assert line['config']['rows_per_gpu'] == 4096 and line['steps'] == 7 and line['dtype'].startswith('f16')
     assert line['timing']['short_batches'] == 0
     trace = line['timing']['step_trace_ms']
@@ -210,19 +198,15 @@ def test_rccl_executes_every_collective_of_the_multi_gpu_path():
     assert record['calls'] == ['barrier', 'gather', 'all_reduce(sum)', 'all_reduce(max)', 'all_gather']
 
 
-def _plain_bench(*flags, timeout=900):
-    import json
-    import subprocess
+def _plain_bench(*flags, timeout=900, short=False):
+    """``python bench.py <flags>`` held to the output contract (tests/util.run_bench: the last non-empty line of stdout + stderr
+    merged is the ONE short JSON line -- RCCL's version banner, printed on stdout when the first communicator is created, and
+    every other library's chatter must not reach either stream).  -> the full record from the side file (or (line, full))"""
     import sys
+    from tests import util
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), *flags], capture_output=True, text=True, timeout=timeout,
-                       env=_clean_env())
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    # stdout is the ONE JSON line and nothing else (RCCL's version banner, printed on stdout when the first communicator is
-    # created, must not reach it)
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1 and lines[0].startswith('{'), r.stdout[-2000:]
-    return json.loads(lines[0])
+    line, full = util.run_bench([sys.executable, os.path.join(repo, 'bench.py'), *flags], env=_clean_env(), timeout=timeout)
+    return (line, full) if short else full
 
 
 def test_bench_force_collective_runs_the_n_gpu_line_on_rccl():
@@ -320,3 +304,29 @@ def test_gradient_all_reduce_is_captured_in_the_whole_iteration_graph_on_rccl():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     record = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert record == {'backend': 'nccl', 'identical': True, 'replays': 6}
+
+
+def test_default_bench_line_is_what_the_driver_parses():
+    """``python bench.py --gpus 1 --steps 20 --warmup 5`` -- the driver's round-end command, byte for byte.  VERDICT r4 #1: round
+    4's 21.7 KB line with progress lines behind it left BENCH_r04.json ``parsed: null``.  The line must be < 2 KB, the last thing
+    on stdout + stderr, carry ``roofline`` (frac from live HIP-event durations) and ``cpu_baseline`` (one bounded leg on the
+    cores the job owns), and the whole run must stay well under the default's few minutes."""
+    import time
+    t0 = time.perf_counter()
+    line, full = _plain_bench('--gpus', '1', '--steps', '20', '--warmup', '5', short=True)
+    took = time.perf_counter() - t0
+    assert line['metric'].startswith('rays/sec') and line['unit'] == 'rays/s' and line['n_gpus'] == 1
+    assert line['steps'] == 20 and line['warmup'] == 5 and line['dtype'] == 'f32' and line['vs_baseline'] is None
+    roof = line['roofline']
+    assert roof['bound'] == 'mfma' and roof['peak'] == 157.3 and roof['unit'] == 'TFLOP/s' and roof['launches'] == 40
+    assert roof['frac'] == pytest.approx(roof['achieved'] / roof['peak'], rel=1e-4) and 0.5 < roof['frac'] < 1.0
+    assert roof['kernel'].startswith('mlp_forward_kernel') and roof['avg_launch_ms'] > 0
+    # the line's throughput and the kernel's event time describe the same run: two launches per step fit inside a step
+    assert 2 * roof['avg_launch_ms'] <= line['ms_per_step'] * 1.001
+    assert line['value'] == pytest.approx(1024 / (line['ms_per_step'] * 1e-3), rel=1e-4)
+    cpu = line['cpu_baseline']
+    assert cpu['kind'] == 'port' and cpu['unit'] == 'rays/s' and 1 <= cpu['cores'] <= 16 and cpu['value'] and cpu['value'] > 50
+    also = line['also']
+    assert set(also) == {'f16x3', 'f16', 'bf16', 'train_f16', 'train_bf16s8'} and all(v is not None for v in also.values()), also
+    assert full['timing']['step_ms']['p50'] > 0 and len(full['timing']['step_trace_ms']) == 20
+    assert took < 240, took

@@ -510,6 +510,46 @@ def test_selective_pack_gives_the_same_bits_as_the_full_pack(precision, size, la
     assert ops.range_status(clear=True) == 0
 
 
+@pytest.mark.parametrize('packed_for,used_at,training_call', [
+    (('f16', True), ('f16', False), False),          # packed for training, rendered from (the m16 stream is zero-filled)
+    (('bf16', True), ('bf16', False), False),
+    (('fp32', False), ('f16', False), False),        # packed for fp32, used at f16
+    (('f16', False), ('fp32', False), False),        # ... and the reverse
+    (('f16', False), ('bf16', False), False),
+    (('fp32', False), ('f16x3', True), True),        # the storing forward of another precision
+])
+def test_a_stream_packed_for_another_precision_or_mode_is_refused(packed_for, used_at, training_call):
+    """snerf_mlp_pack_for zero-fills the operand formats it does not write, and a consumer of such a format
+    used to return bias-only output with SNERF_OK.  The library now remembers what every packed buffer holds and each entry
+    point that reads a weight stream fails with SNERF_E_INVALID -- before enqueuing anything -- when the buffer's last pack did
+    not write it; after a matching re-pack (or a full snerf_mlp_pack) the same call succeeds."""
+    cfg, sd, inputs, (g_sigma, g_rgb) = mlp_case('main', (8, 256, 128))
+    plist = abi_param_list({k: torch.from_numpy(v_).to(DEV) for k, v_ in sd.items()})
+    dev = [t.to(DEV) for t in inputs]
+    stream = ops.PackedMlp(cfg, DEV)
+    stream.pack(plist, ops.PRECISIONS[packed_for[0]], training=packed_for[1])
+    prec = ops.PRECISIONS[used_at[0]]
+    call = (lambda: stream.forward_train(*dev, prec)) if training_call else (lambda: stream.forward(*dev, prec))
+    with pytest.raises(RuntimeError, match='holds the operand formats'):
+        call()
+    # the buffer's own (precision, mode) still works, and so does the refused call after a matching pack / a full pack
+    own = ops.PRECISIONS[packed_for[0]]
+    (stream.forward_train if packed_for[1] else stream.forward)(*dev, own)
+    stream.pack(plist, prec, training=used_at[1])
+    first = call()
+    stream.pack(plist)
+    second = call()
+    assert torch.equal(first[0], second[0]) and torch.equal(first[1], second[1]) and float(first[0].abs().max()) > 0
+    if packed_for == ('fp32', False):     # the backward chain reads the training layout's transposed stream
+        stream.pack(plist, ops.PRECISIONS['f16'], training=True)
+        sigma, rgb, saved = stream.forward_train(*dev, ops.PRECISIONS['f16'])
+        stream.pack(plist, ops.PRECISIONS['fp32'], training=True)
+        with pytest.raises(RuntimeError, match='holds the operand formats'):
+            stream.backward(saved, sigma, rgb, g_sigma.to(DEV), g_rgb.to(DEV), [tuple(p.shape) for p in plist], ops.PRECISIONS['f16'])
+    torch.cuda.synchronize()
+    ops.range_status(clear=True)
+
+
 def test_model_repacks_when_a_render_follows_training_steps():
     """The model keys its packed streams by (precision, keeps activations): an evaluation render between training iterations
     reads the rendering layout, which the training pack does not write -- it must trigger a re-pack, not read zeros."""

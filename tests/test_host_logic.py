@@ -1,6 +1,7 @@
 """CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol, the plugin factory
 follows the reference's naming rule, and the parameter container reproduces the reference's state_dict layout."""
 import ctypes
+import json
 
 import numpy
 import os
@@ -397,3 +398,109 @@ def test_torch_sum_and_cumsum_orders_that_the_resampling_kernel_reproduces():
     spec.loader.exec_module(mod)
     for n in (5, 62, 126, 190, 700):
         assert mod.mismatches(n, rows=40) == (0, 0), n
+
+
+def test_bench_stdout_line_is_short_whatever_the_record_holds(tmp_path, capfd):
+    """BENCH_r04.json had ``parsed: null`` -- the stdout line had grown to 21.7 KB and progress lines followed it.
+    ``emit`` now writes the full record to a side file and prints ONE line < 2 KB holding only the contract's keys; a record
+    the size of round 4's (every secondary measurement attached) comes out the same short line."""
+    bench = _bench_module()
+    steps = 50
+    full = bench.headline_line(1, steps, 5, 'fp32', 0.164, [3.28] * steps, [0.4] * steps, [1.07, 2.18] * steps, [131072, 262144] * steps,
+                               dropped=0, settle_info=(184, 0.61))
+    full['cpu_baseline'] = {'value': 1353.123456789, 'unit': 'rays/s', 'cores': 16, 'kind': 'port', 'sample': 'x' * 120,
+                            'leg': {'runs': 9}, 'host': {'os_cpu_count': 256}}
+    full['also'] = {k: {'rays_s': 2671234.5678, 'frac': 0.5431234} for k in ('f16x3', 'f16', 'bf16')}
+    full['collective'] = {'backend': 'nccl', 'ranks': 8, 'bytes': 16384, 'pattern': 'p' * 80, 'gather_ms': {'p50': 0.0251234, 'max': 0.1},
+                          'per_rank': [{'rank': i, 'step_ms_p50': 3.3, 'elapsed_s': 0.1} for i in range(8)]}
+    for key in ('also_measured', 'also_measured_train', 'also_measured_frame', 'sustained'):      # round 4's ballast
+        full[key] = {'blob': [{'trace': list(range(64)), 'text': 'y' * 200} for _ in range(12)]}
+    assert len(json.dumps(full)) > 20000
+    bench.EXTRA_FILE = str(tmp_path / 'side' / 'extra.json')
+    bench.emit(full)
+    out, err = capfd.readouterr()
+    assert err == '' and out.endswith('\n') and out.count('\n') == 1
+    assert len(out) < 2048, len(out)
+    line = json.loads(out)
+    assert set(line) == {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                         'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'collective', 'also', 'extra'}
+    assert set(line['roofline']) == {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_algorithmic', 'traffic_source',
+                                     'kernel', 'launches', 'avg_launch_ms'}
+    assert set(line['cpu_baseline']) == {'value', 'unit', 'cores', 'kind', 'sample'} and line['cpu_baseline']['cores'] == 16
+    assert line['collective'] == {'backend': 'nccl', 'ranks': 8, 'bytes': 16384, 'gather_ms_p50': 0.0251234}
+    assert line['roofline']['frac'] == pytest.approx(full['roofline']['frac'], rel=1e-5)
+    assert line['value'] == pytest.approx(full['value'], rel=1e-5)
+    # the side file holds the full record, untouched
+    with open(line['extra']) as f:
+        assert json.load(f) == json.loads(json.dumps(full))
+    # the measured-traffic source names the commit the counters were collected at
+    if line['roofline']['traffic'] is not None:
+        assert 'profiles/pmc_traffic.json @ ' in line['roofline']['traffic_source']
+
+
+def test_bench_cpu_leg_uses_the_cores_the_job_owns():
+    """The CPU leg's thread count: affinity mask, capped by the cgroup quota and by 16 (round 4's 256-thread leg on a 16-core
+    share never finished a pass and cost the default run 45 s)."""
+    bench = _bench_module()
+    assert bench.host_cores(affinity=256, quota=16.0) == 16
+    assert bench.host_cores(affinity=256, quota=None) == 16          # no quota visible: the pool's per-GPU share
+    assert bench.host_cores(affinity=8, quota=None) == 8
+    assert bench.host_cores(affinity=8, quota=2.5) == 2 + (1 if 2.5 + 0.5 >= 3 else 0)
+    assert bench.host_cores(affinity=4, quota=0.3) == 1
+    assert 1 <= bench.host_cores() <= 16
+    quota = bench.cgroup_cpu_quota()
+    assert quota is None or quota > 0
+
+
+def test_bench_strong_scaling_rows(monkeypatch):
+    """``--train --global-rows 4096`` is BASELINE config 5 as stated: ONE 4096-row batch over the N ranks (512 rows per rank at
+    N = 8), not 4096 rows per GPU."""
+    import argparse
+    bench = _bench_module()
+    ns = lambda **kw: argparse.Namespace(global_rows=kw.get('g'), rows_per_gpu=kw.get('r'))
+    assert bench.train_rows_per_gpu(ns(g=4096), 8) == (512, True)
+    assert bench.train_rows_per_gpu(ns(g=4096), 1) == (4096, True)
+    assert bench.train_rows_per_gpu(ns(), 8) == (4096, False)
+    assert bench.train_rows_per_gpu(ns(r=512), 1) == (512, False)
+    with pytest.raises(SystemExit):
+        bench.train_rows_per_gpu(ns(g=4096 + 2), 8)
+    assert '256 pixel + 256' in bench.train_workload(512, 8, True) and '4096-row batch over 8' in bench.train_workload(512, 8, True)
+
+
+def test_every_diagnostic_switch_is_guarded():
+    """the ablation / probe switches inside the product kernels (wrong results by design) cannot reach the shipped
+    library.  (i) every such macro the sources test is listed in csrc/probe_guard.h, which is force-included into every
+    translation unit and #errors unless SNERF_PROBE_BUILD is defined; (ii) build.py refuses them for the shipped library's name
+    wherever they come from (extra flags, HIPCC, HIPCC_COMPILE_FLAGS_APPEND, CXXFLAGS ...); (iii) a real compile of a library
+    source with -DSNERF_PROBE_HALF_X fails, and passes once SNERF_PROBE_BUILD is there too."""
+    import subprocess
+    from simplenerf_amd import build
+    csrc = build.CSRC
+    guard = open(os.path.join(csrc, 'probe_guard.h')).read()
+    used = set()
+    for name in os.listdir(csrc):
+        if name.endswith(('.hip', '.h')) and name != 'probe_guard.h':
+            used |= set(re.findall(r'\b(SNERF_(?:ABL|PROBE)_[A-Z0-9_]+|SNERF_CLOCK_STAMP)\b', open(os.path.join(csrc, name)).read()))
+    used.discard('SNERF_PROBE_BUILD')
+    assert used and all(f'defined({m})' in guard for m in used), sorted(m for m in used if f'defined({m})' not in guard)
+    assert '-include' in build.FLAGS and build.FLAGS[build.FLAGS.index('-include') + 1].endswith('probe_guard.h')
+    # (ii)
+    with pytest.raises(RuntimeError, match='refusing to build the shipped library'):
+        build.check_shipped_build(['-DSNERF_PROBE_HALF_X'], build.LIB, environ={})
+    for var in ('HIPCC', 'HIPCC_COMPILE_FLAGS_APPEND', 'CXXFLAGS'):
+        with pytest.raises(RuntimeError, match=var):
+            build.check_shipped_build([], build.LIB, environ={var: '/opt/rocm/bin/hipcc -DSNERF_ABL_NODMA'})
+    with pytest.raises(RuntimeError, match='SNERF_PROBE_BUILD'):
+        build.check_shipped_build(['-DSNERF_PROBE_HALF_X'], '/tmp/variant.so', environ={})
+    build.check_shipped_build(['-DSNERF_PROBE_BUILD', '-DSNERF_PROBE_HALF_X'], '/tmp/variant.so', environ={})
+    build.check_shipped_build([], build.LIB, environ={'CXXFLAGS': '-O2'})
+    with pytest.raises(RuntimeError, match='refusing'):
+        build.build_library(extra_flags=['-DSNERF_PROBE_HALF_X'])
+    # (iii) the compiler itself (host pass only: seconds)
+    source = os.path.join(csrc, 'display.hip')
+    cmd = [build.HIPCC, *build.FLAGS, '--cuda-host-only', '-fsyntax-only', source]
+    bad = subprocess.run(cmd + ['-DSNERF_PROBE_HALF_X'], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and 'diagnostic switch' in bad.stderr, bad.stderr[-2000:]
+    for extra in ([], ['-DSNERF_PROBE_HALF_X', '-DSNERF_PROBE_BUILD']):
+        ok = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=300)
+        assert ok.returncode == 0, ok.stderr[-2000:]

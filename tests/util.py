@@ -158,3 +158,43 @@ def loss_case(golden: dict, device='cpu'):
         input_dict['sparse_depth_values'] = t(batch['sparse_depth_values'])
     output_dict = {k: t(batch[k]).clone().requires_grad_(True) for k in LOSS_OUTPUT_KEYS}
     return configs, input_dict, output_dict
+
+
+# ---------------------------------------------------------------------------------------------------- bench.py's output contract
+BENCH_LINE_KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                   'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'collective', 'also', 'extra'}
+BENCH_ROOFLINE_KEYS = {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_algorithmic', 'traffic_source', 'kernel',
+                       'launches', 'avg_launch_ms'}
+
+
+def run_bench(command, env=None, timeout=900):
+    """Run a bench command (``[python, bench.py | tests/bench_rehearsal.py ..., flags]``) the way a driver might capture it --
+    stdout and stderr MERGED into one stream -- and hold it to the output contract (bench.py's docstring):
+    the last non-empty line of that stream is the ONE JSON line, it is shorter than 2 KB, carries only the contract's keys, and
+    names the side file with the full record.  -> (line, full record)"""
+    import json
+    import subprocess
+    import tempfile
+    env = dict(os.environ if env is None else env)
+    for key in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(key, None)
+    with tempfile.TemporaryDirectory() as tmp:
+        side = os.path.join(tmp, 'extra.json')
+        r = subprocess.run(list(command) + ['--extra-file', side], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           timeout=timeout, env=env)
+        assert r.returncode == 0, r.stdout[-6000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert lines and lines[-1].startswith('{'), r.stdout[-3000:]
+        assert len([ln for ln in lines if ln.startswith('{"metric"')]) == 1, r.stdout[-3000:]
+        text = lines[-1]
+        assert len(text) < 2048, len(text)
+        line = json.loads(text)
+        assert set(line) <= BENCH_LINE_KEYS, set(line) - BENCH_LINE_KEYS
+        if 'roofline' in line:
+            assert set(line['roofline']) <= BENCH_ROOFLINE_KEYS, set(line['roofline']) - BENCH_ROOFLINE_KEYS
+        assert line['extra'] == side
+        with open(side) as f:
+            full = json.load(f)
+    for key in ('metric', 'n_gpus', 'steps', 'warmup', 'scaling', 'data'):
+        assert line[key] == full[key], key
+    return line, full
