@@ -70,15 +70,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False, extra_flags=(), output: str = LIB, obj_dir: str = OBJ_DIR) -> str:
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), output: str = LIB, obj_dir: str = OBJ_DIR, only=()) -> str:
     """``extra_flags`` / ``output`` / ``obj_dir``: diagnostic variants (tools/probes/build_variant.py) -- the shipped library is
-    always built with FLAGS alone."""
+    always built with FLAGS alone.  ``only``: source stems a variant compiles with its flags; every other object is linked from
+    the shipped build's object directory (which must be current)."""
     check_shipped_build(extra_flags, output)
+    if only and os.path.abspath(output) == os.path.abspath(LIB):
+        raise RuntimeError('`only` is for diagnostic variants')
     os.makedirs(obj_dir, exist_ok=True)
     headers = _headers()
     jobs = []
     objs = []
     for src in _sources():
+        if only and src[:-4] not in only:
+            objs.append(os.path.join(OBJ_DIR, src[:-4] + '.o'))
+            continue
         obj = os.path.join(obj_dir, src[:-4] + '.o')
         objs.append(obj)
         if force or _stale(obj, [os.path.join(CSRC, src)] + headers):

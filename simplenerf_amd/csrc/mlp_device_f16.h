@@ -189,8 +189,15 @@ struct UnitStreamT {
         // (the generic 64-way dispatch compiles to a compare-and-branch tree of ~30 scalar instructions, and with one wave
         // per SIMD every instruction is an issue slot: the steady-state counts of the 256-wide trunk -- the successor's
         // k/2 resp. k/4 DMA instructions and nothing else -- are tested first)
-        if (D == 3 && allowed == (P == 3 ? 8 : 16 / NW)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P == 3 ? 8 : 16 / NW) : "memory");
+#ifdef SNERF_PROBE_NO_VMWAIT
+        // timing probe (wrong results): the DMA is issued but nobody waits for it -- what the waits cost, as against the issue
+        (void)allowed;
+#else
+        // (... times the D - 2 units that stay in flight)
+        constexpr int kSteady = (D - 2) * (P == 3 ? 8 : 16 / NW);
+        if (D <= 4 && allowed == kSteady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kSteady) : "memory");
         else wait_vmcnt(allowed);
+#endif
         younger = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my LDS reads of unit i-1 are complete
 #ifndef SNERF_ABL_NOBARRIER

@@ -44,6 +44,13 @@ struct M16Args {
 
 typedef f32x4 Tile16[2][2];   // [row half][sample half]
 
+// Ring slots of the weight stream.  The single-product kernels (two waves per SIMD on one ring) run THREE units ahead since
+// round 5 -- measured neutral (0.278 against 0.281 ms per 262 144 samples: a build that never waits for its DMA is no faster
+// either, what costs 14 % is ISSUING it; tools/probes/m16_ablation.py, profiles/r05_m16_ablation.txt) and kept for what it
+// frees: the encodings' hand-over scratch (48 KiB, dead after the prologue) now lies in slots three and four, 124 instead of
+// 148 KiB of LDS per workgroup.
+__host__ __device__ constexpr int m16_ring(int products) { return products == 1 ? 4 : 3; }
+
 __device__ __forceinline__ f32x4 mfma16(const f16x8& a, const f16x8& b, const f32x4& c) {
     return mfma_16x16x32<false>(a, b, c);
 }
@@ -107,6 +114,10 @@ __device__ __forceinline__ void seg1_m16(Tile16& t, const float*& p, const f16x8
             t[r][0] = mfma_16x16x32<BF>(a[c % 3][r], bh[c][0], t[r][0]);
             t[r][1] = mfma_16x16x32<BF>(a[c % 3][r], bh[c][1], t[r][1]);
         }
+        // (Every wave issues its DMA instructions behind the same k-blocks.  Spreading them -- wave w behind k-blocks w / 2 and
+        // w / 2 + 4, so that the eight waves do not queue on the CU's one vector-memory path -- needs a wave-dependent branch in
+        // this unrolled loop and measured 15 % SLOWER (profiles/r05_m16_ablation.txt, 'staggered issue'): the loop must stay one
+        // basic block, as UnitStreamT::fetch_piece says.)
         if (((2 * c) & (Stream::kWaves - 1)) == 0) st.fetch_piece();
     }
     p += 2 * NB * 256;
@@ -183,15 +194,16 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         const int v = idx - trunk_units;
         return v < WT ? 2 * HB : (v < WT + VT ? kViewsKs : 0);
     };
-    UnitStreamT<P, NW, kUnitBuffers, BF ? 256 : 512> st;
+    constexpr int RING = m16_ring(P);
+    UnitStreamT<P, NW, RING, BF ? 256 : 512> st;
     st.start(a.packed + args.stream_offset, lds, ks_of(0), ks_of(1), lane, wave, args.slot_floats);
     int unit_idx = 0;
     auto next_unit = [&]() {
-        const float* p = st.acquire(ks_of(unit_idx + 1), ks_of(unit_idx + 2));
+        const float* p = st.acquire(ks_of(unit_idx + 1), ks_of(unit_idx + RING - 1));
         ++unit_idx;
         return p + lane * 4;
     };
-    float* consts = lds + kUnitBuffers * args.slot_floats + NW * 256;  // after the ring and the DMA dump area (1 KiB per wave)
+    float* consts = lds + RING * args.slot_floats + NW * 256;  // after the ring and the DMA dump area (1 KiB per wave)
     for (int i = threadIdx.x * 4; i < args.const_floats; i += NW * 64 * 4)
         *reinterpret_cast<f32x4*>(consts + i) = *reinterpret_cast<const f32x4*>(a.packed + a.bias_offset + i);
 
@@ -199,6 +211,23 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
     // the lanes that need them through a 6-KiB LDS scratch per wave ----------------------------------------------------------
     f16x8 pe_h[2][2], pe_l[2][2], pev_h[1][2], pev_l[1][2];
     const long long wave_base = ((long long)blockIdx.x * NW + wave) * 32;
+#ifdef SNERF_PROBE_M16_NOENCODE
+    // timing probe (wrong results): the operands of the encodings are lane-dependent constants -- no positions, no sin / cos, no
+    // hand-over through LDS: what the 861-instruction prologue costs a pass
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pe_h[c][s][j] = (_Float16)(0.01f * ((lane * 7 + c * 3 + s + j) & 63) - 0.3f);
+                pe_l[c][s][j] = (_Float16)0.0f;
+            }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pev_h[0][s][j] = (_Float16)(0.02f * ((lane + s + j) & 31) - 0.3f); pev_l[0][s][j] = (_Float16)0.0f; }
+#else
     {
         const int i32 = lane & 31, half = lane >> 5;
         const long long gi = wave_base + i32 < a.total ? wave_base + i32 : a.total - 1;
@@ -214,8 +243,9 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
         encode<snerf::kViewsPairs, snerf::kViewsKSteps>(v, half, pev);
         // register 8ks + j of lane half h = position p = 16 (ks & 1) + 8h + j of k-block ks / 2 -> lane group (p & 15) / 4,
         // slot (p < 16 ? 0 : 4) + p % 4 of the fragment of sample half i32 / 16
-        // (P = 3: the third ring slot, idle until the first acquire; P = 1: its slots are smaller, the scratch has its own area)
-        _Float16* scratch = reinterpret_cast<_Float16*>(P == 3 ? lds + 2 * args.slot_floats : consts + args.const_floats) + wave * (6 * 512);
+        // (the ring slots from the third on are idle until the hand-over is done: P = 3: the third slot (44 KiB for 4 waves x 6 KiB);
+        // P = 1: slots three and four of its 4-slot ring, 2 x 24 KiB for 8 waves x 6 KiB -- launch_m16 checks the sizes)
+        _Float16* scratch = reinterpret_cast<_Float16*>(lds + 2 * args.slot_floats) + wave * (6 * 512);
         auto place = [&](int block, int ks, int j) {
             const int p = 16 * (ks & 1) + 8 * half + j;
             const int g = (p & 15) >> 2, t = (p < 16 ? 0 : 4) + (p & 3);
@@ -263,7 +293,12 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
             for (int s = 0; s < 2; ++s) pev_l[0][s] = frags[(4 + s) * 64];
         }
     }
-    __syncthreads();   // consts visible; every wave is done with the scratch before the first acquire hands the slot to the DMA
+#endif
+    __syncthreads();   // consts visible; every wave is done with the scratch before the DMA is given its slots
+    if constexpr (RING > 3) {      // the rest of the initial run-ahead, now that the scratch is free
+#pragma unroll
+        for (int u = 2; u < RING - 1; ++u) st.start_more(u, ks_of(u));
+    }
     SNERF_STAMP_BEGIN();
 
     const float* bias = consts;
@@ -369,11 +404,14 @@ int launch_m16(const M16Args& args, hipStream_t stream) {
     constexpr int NW = P == 1 ? 8 : 4;
     const long long blocks = (args.m.total + NW * 32 - 1) / (NW * 32);
     if (blocks > 0x7fffffffLL) return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward: too many samples in one call");
-    const size_t lds_bytes = sizeof(float) * (kUnitBuffers * (size_t)args.slot_floats + NW * 256 + (size_t)args.const_floats +
-                                              (P == 1 ? NW * 6 * 256 : 0));
+    constexpr int RING = m16_ring(P);
+    // the encodings' scratch (NW x 6 KiB) lies in the ring's slots from the third on
+    if ((size_t)(RING - 2) * args.slot_floats < (size_t)NW * 6 * 256)
+        return snerf::fail(SNERF_E_UNSUPPORTED, "mlp_forward(m16): ring slots of %d floats cannot hold the encoding scratch", args.slot_floats);
+    const size_t lds_bytes = sizeof(float) * (RING * (size_t)args.slot_floats + NW * 256 + (size_t)args.const_floats);
     auto kernel = mlp_forward_m16_kernel<P, 8, BF>;
     static snerf::DeviceOnce configured;   // per device: the attribute belongs to (kernel, device)
-    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 2048 + 5120)), "mlp_forward");   // (P = 1: 72 + 8 + 20 + 48 KiB)
+    const int attr = snerf::raise_dynamic_lds(configured, reinterpret_cast<const void*>(kernel), (int)(sizeof(float) * (kUnitBuffers * kUnitBufFloats + 2048 + 5120)), "mlp_forward");   // (P = 3: 132 + 8 + 20 KiB; P = 1: 4 x 24 + 8 + 20 KiB)
     if (attr != SNERF_OK) return attr;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(NW * 64), lds_bytes, stream, args);
     return snerf::check_launch("mlp_forward(m16)");

@@ -444,7 +444,7 @@ def test_config4_re10k_full_frame_properties_and_eight_way_shards(resolution):
     assert numpy.array_equal(frame['image'].reshape(-1, 3), ref_img) and numpy.array_equal(frame['depth'].reshape(-1), ref_depth)
 
 
-K_SELF = 1.5          # allowance vs the committed fp32 reference outputs = K_SELF x the reference's own evaluation-order noise
+K_SELF = 1.25         # allowance vs the committed fp32 reference outputs = K_SELF x the reference's own evaluation-order noise (1.5 until round 4; VERDICT r4: observed <= 1.12 x)
 K_EXACT = 1.25        # allowance vs the reference in double precision = K_EXACT x the reference's own fp32 error against it
 SLACK_RAYS = 4        # + 4 rays of 4096 (0.1 %) on either gate: fractions of a few rays are counting noise
 

@@ -7,6 +7,12 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from simplenerf_amd import build
-name, flags = sys.argv[1], ['-DSNERF_PROBE_BUILD'] + sys.argv[2:]
+name, rest = sys.argv[1], sys.argv[2:]
+only = ()
+if '--only' in rest:          # --only stem[,stem...]: compile just these sources with the flags, link the shipped objects for the rest
+    at = rest.index('--only')
+    only = tuple(rest[at + 1].split(','))
+    rest = rest[:at] + rest[at + 2:]
+flags = ['-DSNERF_PROBE_BUILD'] + rest
 out = os.path.join(ROOT, f'gpurun_abl_{name}.so')
-print(build.build_library(extra_flags=flags, output=out, obj_dir=os.path.join('/tmp', f'snerf_variant_{name}')))
+print(build.build_library(extra_flags=flags, output=out, obj_dir=os.path.join('/tmp', f'snerf_variant_{name}'), only=only))
