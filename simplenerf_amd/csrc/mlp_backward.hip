@@ -1157,7 +1157,11 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
             // (a lone job of fewer than 64 tile products -- the views layer's 4 x 9 -- ends every workgroup with a 144 KB
             // partial: at least SNERF_MID_BLOCKS blocks of operands per workgroup; config 5: 128 instead of 256 workgroups
             // for a 64-samples-per-ray pass is worth 0.04 ms per iteration, 64 costs 0.25)
-            if (j.out_tiles * j.in_tiles < 64 && chunks > blocks / SNERF_MID_BLOCKS) chunks = std::max<long long>(blocks / SNERF_MID_BLOCKS, 1);
+            // (round 5: ... but never fewer than 64 workgroups while a workgroup still gets four blocks -- one rank's share of a
+            // strong-scaled batch, 256 rays x 64 samples = 512 blocks, left this job on 16 CUs: 33 us per launch for 0.3 us of
+            // operand traffic, profiles/r05_train_share_512_kernel_stats.csv)
+            if (j.out_tiles * j.in_tiles < 64 && chunks > blocks / SNERF_MID_BLOCKS)
+                chunks = std::min(chunks, std::max<long long>({blocks / SNERF_MID_BLOCKS, std::min<long long>(64, blocks / 4), 1}));
             cap = blocks / 8;
         } else {
 #ifndef SNERF_SMALL_CHUNKS_FP32

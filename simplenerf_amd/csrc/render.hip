@@ -3,6 +3,9 @@
 // instead of one per stage.  Orchestration only: every stage is one of the library's own entry points (K2 depths.hip,
 // K3 mlp_forward*.hip, K4/K6 composite.hip, K5 depths.hip, K7 mlp_backward*.hip).
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "snerf_common.h"
 
@@ -24,6 +27,72 @@ namespace {
 struct Marching {
     const float *origins, *dirs;
 };
+
+// ---- levels side by side (round 5) -----------------------------------------------------------------------------------------
+// The MLP levels of one render are independent of each other except main coarse -> (resampling) -> fine: with few rays per call
+// -- one rank's share of a batch that is strong-scaled over 8 GPUs: 256 rays = 16 384 coarse samples = 64 workgroups for 256 CUs
+// -- each level's kernels leave most of the chip idle and a call costs the SUM of their latencies (a chain or storing-forward
+// launch takes ~70 us whether it covers 16 k or 65 k samples).  Below kSideBySideSamples samples per coarse level the
+// augmentation levels run on side streams beside the main levels (forward: {main coarse -> fine} | points-aug | views-aug;
+// backward: all four side by side), forked from and joined to the caller's stream with events -- still enqueue-only, and a
+// capture of the caller's stream captures the side streams with it (fork / join is what a HIP graph records as parallel
+// branches).  Side streams and events are created once per (device, caller's stream) and kept.  Above the threshold every CU is
+// busy with one level and the levels stay on the caller's stream, in order (two backward calls side by side measured the same
+// as back to back there: DESIGN_LOG 12.4).
+constexpr long long kSideBySideSamples = 65536;
+constexpr int kSideStreams = 3;
+
+struct SideStreams {
+    hipStream_t stream[kSideStreams] = {};
+    hipEvent_t fork = nullptr, join[kSideStreams] = {};
+    bool ok = false;
+};
+std::mutex g_side_mutex;
+std::map<std::pair<int, hipStream_t>, SideStreams> g_side;
+
+SideStreams* side_streams(hipStream_t main) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    SideStreams& s = g_side[{device, main}];
+    if (!s.ok) {
+        bool good = hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < kSideStreams && good; ++i)
+            good = hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&s.join[i], hipEventDisableTiming) == hipSuccess;
+        if (!good) {
+            (void)hipGetLastError();
+            return nullptr;          // (the caller falls back to one stream)
+        }
+        s.ok = true;
+    }
+    return &s;
+}
+
+// fork: the side streams wait for what the caller's stream holds so far; join: the caller's stream waits for them
+int fork_streams(SideStreams* s, hipStream_t main, int count) {
+    if (hipEventRecord(s->fork, main) != hipSuccess) return snerf::fail(SNERF_E_HIP, "render: hipEventRecord(fork) failed");
+    for (int i = 0; i < count; ++i)
+        if (hipStreamWaitEvent(s->stream[i], s->fork, 0) != hipSuccess) return snerf::fail(SNERF_E_HIP, "render: hipStreamWaitEvent(fork) failed");
+    return SNERF_OK;
+}
+int join_streams(SideStreams* s, hipStream_t main, int count) {
+    for (int i = 0; i < count; ++i) {
+        if (hipEventRecord(s->join[i], s->stream[i]) != hipSuccess) return snerf::fail(SNERF_E_HIP, "render: hipEventRecord(join) failed");
+        if (hipStreamWaitEvent(main, s->join[i], 0) != hipSuccess) return snerf::fail(SNERF_E_HIP, "render: hipStreamWaitEvent(join) failed");
+    }
+    return SNERF_OK;
+}
+
+bool side_by_side(const snerf_render_config* cfg, const snerf_render_mlp* mlps, long long num_rays) {
+#ifdef SNERF_PROBE_NO_SIDE_BY_SIDE
+    return false;      // A/B builds (tools/probes/share_ab.py)
+#endif
+    if (num_rays * cfg->num_coarse > kSideBySideSamples) return false;
+    int levels = 0;
+    for (int l = 0; l < SNERF_RENDER_LEVELS; ++l) levels += mlps[l].desc ? 1 : 0;
+    return levels > 2 || (levels == 2 && !mlps[SNERF_LEVEL_MAIN_FINE].desc);
+}
 
 int check_common(const snerf_render_config* cfg, const snerf_render_mlp* mlps, const snerf_render_rays* rays, long long n,
                  const snerf_render_outputs* out, const char* who) {
@@ -101,7 +170,7 @@ extern "C" int snerf_render_forward(const snerf_render_config* cfg, const snerf_
         coarse_weights = workspace;
     }
 
-    auto shade = [&](int l, const float* depths, int samples) -> int {
+    auto shade = [&](int l, const float* depths, int samples, snerf_stream_t stream) -> int {
         const snerf_render_level_out& o = out->level[l];
         const float* dirs = mlps[l].desc->use_view_dirs ? rays->view_dirs : nullptr;
         const bool vis = mlps[l].desc->predict_visibility != 0;
@@ -147,40 +216,58 @@ extern "C" int snerf_render_forward(const snerf_render_config* cfg, const snerf_
 
     rc = snerf_coarse_depths(rays->near, rays->far, n, cfg->num_coarse, cfg->lindisp, rays->t_rand, out->depths_coarse, stream);
     if (rc != SNERF_OK) return rc;
-    for (int l = 0; l < 3; ++l) {
-        if (!mlps[l].desc) continue;
-        rc = shade(l, out->depths_coarse, cfg->num_coarse);
+    // the coarse augmentation levels beside {main coarse -> fine} when the call is small (see side_by_side)
+    SideStreams* side = side_by_side(cfg, mlps, n) && (mlps[1].desc || mlps[2].desc) ? side_streams((hipStream_t)stream) : nullptr;
+    int forked = 0;
+    // (from the fork on every return joins the side streams first)
+    auto done = [&](int status) { return side ? (join_streams(side, (hipStream_t)stream, forked) == SNERF_OK ? status : (status != SNERF_OK ? status : SNERF_E_HIP)) : status; };
+    if (side) {
+        forked = (mlps[1].desc ? 1 : 0) + (mlps[2].desc ? 1 : 0);
+        rc = fork_streams(side, (hipStream_t)stream, forked);
         if (rc != SNERF_OK) return rc;
     }
-    if (!fine) return SNERF_OK;
+    // the main coarse level FIRST: the fine level waits for it, so its workgroups must not queue behind the augmentation levels'
+    // (enqueued last it ran last: 140 us instead of 86 and the fine pass started that much later, r05 trace of a 512-row pass)
+    rc = shade(0, out->depths_coarse, cfg->num_coarse, stream);
+    if (rc != SNERF_OK) return done(rc);
+    int used = 0;
+    for (int l = 1; l < 3; ++l) {
+        if (!mlps[l].desc) continue;
+        rc = shade(l, out->depths_coarse, cfg->num_coarse, side ? (snerf_stream_t)side->stream[used++] : stream);
+        if (rc != SNERF_OK) return done(rc);
+    }
+    if (!fine) return done(SNERF_OK);
     const float* depths_fine = rays->depths_fine;
     if (!depths_fine) {
         if (!fuse_resample) {     // (else the main coarse level's kernel has written them already)
             rc = snerf_resample_depths(out->depths_coarse, coarse_weights, n, cfg->num_coarse, cfg->num_fine, rays->u,
                                        out->depths_fine, stream);
-            if (rc != SNERF_OK) return rc;
+            if (rc != SNERF_OK) return done(rc);
         }
         depths_fine = out->depths_fine;
     }
     for (int l = 3; l < SNERF_RENDER_LEVELS; ++l) {
         if (!mlps[l].desc) continue;
-        rc = shade(l, depths_fine, cfg->num_coarse + cfg->num_fine);
-        if (rc != SNERF_OK) return rc;
+        rc = shade(l, depths_fine, cfg->num_coarse + cfg->num_fine, stream);
+        if (rc != SNERF_OK) return done(rc);
     }
-    return SNERF_OK;
+    return done(SNERF_OK);
 }
 
 extern "C" size_t snerf_render_backward_workspace_floats(const snerf_render_config* cfg, const snerf_render_mlp* mlps,
                                                          long long num_rays) {
     if (!cfg || !mlps || num_rays < 0 || cfg->num_coarse < 1 || cfg->num_fine < 0) return 0;
-    size_t samples = 0, inner = 0;
+    size_t samples = 0, inner = 0, every = 0;
     for (int l = 0; l < SNERF_RENDER_LEVELS; ++l) {
         if (!mlps[l].desc) continue;
         const int s = l < 3 ? cfg->num_coarse : cfg->num_coarse + cfg->num_fine;
+        const size_t level_inner = snerf_mlp_backward_workspace_floats(mlps[l].desc, num_rays, s);
         samples = std::max(samples, (size_t)num_rays * (size_t)s);
-        inner = std::max(inner, snerf_mlp_backward_workspace_floats(mlps[l].desc, num_rays, s));
+        inner = std::max(inner, level_inner);
+        every += 4 * (size_t)num_rays * (size_t)s + (level_inner + 63) / 64 * 64;
     }
-    return 4 * samples + inner;
+    // levels side by side (small calls): each level its own gradient columns and inner workspace
+    return side_by_side(cfg, mlps, num_rays) ? every : 4 * samples + inner;
 }
 
 extern "C" int snerf_render_backward(const snerf_render_config* cfg, const snerf_render_mlp* mlps, const snerf_render_rays* rays,
@@ -196,33 +283,75 @@ extern "C" int snerf_render_backward(const snerf_render_config* cfg, const snerf
     size_t samples_max = 0;
     for (int l = 0; l < SNERF_RENDER_LEVELS; ++l)
         if (mlps[l].desc) samples_max = std::max(samples_max, (size_t)n * (size_t)(l < 3 ? cfg->num_coarse : cfg->num_coarse + cfg->num_fine));
-    float* d_sigma = workspace;
-    float* d_rgb = workspace + samples_max;
-    float* inner = workspace + 4 * samples_max;
-    for (int l = 0; l < SNERF_RENDER_LEVELS; ++l) {
-        if (!mlps[l].desc) continue;
+    // one level's backward on `s`: compositing backward (K6) -> raw-output gradients added -> MLP backward (K7)
+    auto level_backward = [&](int l, float* d_sigma, float* d_rgb, float* inner, snerf_stream_t s_l) -> int {
         const snerf_render_level_grads& g = grads[l];
-        if (!g.param_grads || !(g.rgb || g.acc || g.depth || g.depth_ndc || g.sigma || g.raw_rgb)) continue;
         const int s = l < 3 ? cfg->num_coarse : cfg->num_coarse + cfg->num_fine;
         const float* depths = l < 3 ? out->depths_coarse : (rays->depths_fine ? rays->depths_fine : out->depths_fine);
         const snerf_render_level_out& o = out->level[l];
-        rc = snerf_composite_backward(o.sigma, o.raw_rgb, depths, march_d, cfg->ndc ? rays->rays_o : nullptr,
-                                      cfg->ndc ? rays->rays_d : nullptr, n, s, cfg->ndc, cfg->white_bkgd, g.rgb, g.acc, g.depth,
-                                      g.depth_ndc, d_sigma, d_rgb, stream);
-        if (rc != SNERF_OK) return rc;
+        int st = snerf_composite_backward(o.sigma, o.raw_rgb, depths, march_d, cfg->ndc ? rays->rays_o : nullptr,
+                                          cfg->ndc ? rays->rays_d : nullptr, n, s, cfg->ndc, cfg->white_bkgd, g.rgb, g.acc, g.depth,
+                                          g.depth_ndc, d_sigma, d_rgb, s_l);
+        if (st != SNERF_OK) return st;
         if (g.sigma) {
-            hipLaunchKernelGGL(add_kernel, dim3(snerf::stride_grid(n * s, 256)), dim3(256), 0, (hipStream_t)stream, d_sigma, g.sigma, n * s);
-            rc = snerf::check_launch("render_backward(add sigma)");
-            if (rc != SNERF_OK) return rc;
+            hipLaunchKernelGGL(add_kernel, dim3(snerf::stride_grid(n * s, 256)), dim3(256), 0, (hipStream_t)s_l, d_sigma, g.sigma, n * s);
+            st = snerf::check_launch("render_backward(add sigma)");
+            if (st != SNERF_OK) return st;
         }
         if (g.raw_rgb) {
-            hipLaunchKernelGGL(add_kernel, dim3(snerf::stride_grid(3 * n * s, 256)), dim3(256), 0, (hipStream_t)stream, d_rgb, g.raw_rgb, 3 * n * s);
-            rc = snerf::check_launch("render_backward(add rgb)");
+            hipLaunchKernelGGL(add_kernel, dim3(snerf::stride_grid(3 * n * s, 256)), dim3(256), 0, (hipStream_t)s_l, d_rgb, g.raw_rgb, 3 * n * s);
+            st = snerf::check_launch("render_backward(add rgb)");
+            if (st != SNERF_OK) return st;
+        }
+        return snerf_mlp_backward(mlps[l].desc, mlps[l].packed, o.saved_acts, o.sigma, o.raw_rgb, d_sigma, d_rgb, n, s, inner,
+                                  g.param_grads, g.num_params, cfg->precision, g.accumulate, s_l);
+    };
+    auto wanted = [&](int l) {
+        const snerf_render_level_grads& g = grads[l];
+        return mlps[l].desc && g.param_grads && (g.rgb || g.acc || g.depth || g.depth_ndc || g.sigma || g.raw_rgb);
+    };
+    int levels = 0;
+    for (int l = 0; l < SNERF_RENDER_LEVELS; ++l) levels += wanted(l) ? 1 : 0;
+    SideStreams* side = side_by_side(cfg, mlps, n) && levels > 1 ? side_streams((hipStream_t)stream) : nullptr;
+    if (!side) {
+        float* d_sigma = workspace;
+        float* d_rgb = workspace + samples_max;
+        float* inner = workspace + 4 * samples_max;
+        for (int l = 0; l < SNERF_RENDER_LEVELS; ++l) {
+            if (!wanted(l)) continue;
+            rc = level_backward(l, d_sigma, d_rgb, inner, stream);
             if (rc != SNERF_OK) return rc;
         }
-        rc = snerf_mlp_backward(mlps[l].desc, mlps[l].packed, o.saved_acts, o.sigma, o.raw_rgb, d_sigma, d_rgb, n, s, inner,
-                                g.param_grads, g.num_params, cfg->precision, g.accumulate, stream);
-        if (rc != SNERF_OK) return rc;
+        return SNERF_OK;
     }
-    return SNERF_OK;
+    // side by side: the heaviest level (main fine, else the first wanted) stays on the caller's stream, the others take the side
+    // streams in turn; each level has its own region of the workspace (snerf_render_backward_workspace_floats)
+    const int forked = std::min(levels - 1, kSideStreams);
+    rc = fork_streams(side, (hipStream_t)stream, forked);
+    if (rc != SNERF_OK) return rc;
+    int keep = wanted(SNERF_LEVEL_MAIN_FINE) ? SNERF_LEVEL_MAIN_FINE : -1;
+    for (int l = 0; keep < 0 && l < SNERF_RENDER_LEVELS; ++l)
+        if (wanted(l)) keep = l;
+    // each level's region of the workspace, in level order
+    float* d_sigma_of[SNERF_RENDER_LEVELS] = {};
+    float* region = workspace;
+    size_t samples_of[SNERF_RENDER_LEVELS] = {};
+    for (int l = 0; l < SNERF_RENDER_LEVELS; ++l) {
+        if (!mlps[l].desc) continue;
+        const int s_l = l < 3 ? cfg->num_coarse : cfg->num_coarse + cfg->num_fine;
+        samples_of[l] = (size_t)n * (size_t)s_l;
+        d_sigma_of[l] = region;
+        region += 4 * samples_of[l] + (snerf_mlp_backward_workspace_floats(mlps[l].desc, n, s_l) + 63) / 64 * 64;
+    }
+    // the kept (heaviest) level is enqueued first -- enqueued last, its kernels queued behind everybody else's and the call ended
+    // with it -- then the others, each on its side stream
+    int used = 0;
+    rc = level_backward(keep, d_sigma_of[keep], d_sigma_of[keep] + samples_of[keep], d_sigma_of[keep] + 4 * samples_of[keep], stream);
+    for (int l = 0; l < SNERF_RENDER_LEVELS && rc == SNERF_OK; ++l) {
+        if (!wanted(l) || l == keep) continue;
+        rc = level_backward(l, d_sigma_of[l], d_sigma_of[l] + samples_of[l], d_sigma_of[l] + 4 * samples_of[l],
+                            (snerf_stream_t)side->stream[used++ % forked]);
+    }
+    const int joined = join_streams(side, (hipStream_t)stream, forked);
+    return rc != SNERF_OK ? rc : joined;
 }

@@ -484,6 +484,9 @@ class SimpleNeRFHip(torch.nn.Module):
                 if present[level]:
                     draws[('noise', level)] = draw(_NOISE_KEYS[level], (n, s_c + s_f, 1), True)
 
+        # (Re-packing the stale streams side by side on forked torch streams -- they are independent, ~25 us of small dependent
+        # launches each -- was built and measured in round 5: neutral at 512 rows, and 5 % SLOWER on the graphed 4096-row
+        # iteration, whose graph then starts with four parallel branches; profiles/r05_share_ab.jsonl.  They stay in order.)
         packed = [self._packed_mlp(name, with_grad) if name else None for name in present]
         per_sample = ('alpha', 'visibility', 'weights') if retraw else ('alpha',)
         predicts = [name is not None and getattr(self, name).predict_visibility for name in present]

@@ -1,7 +1,7 @@
-# rocprofv3 kernel stats of one rank's share (512 rows) of the strong-scaled config-5 iteration, and of the full 4096-row one
+# rocprofv3 kernel trace of one rank's share (512 rows) of the strong-scaled config-5 iteration: one model pass, whole iteration
+# replayed from one HIP graph (python bench.py --train --precision f16 --rows-per-gpu 512 --single-pass --graphed)
 mkdir -p gpurun_out
+root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-for rows in 512 4096; do
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_share_$rows -o share -- python3 $GRAFT_REPO_ROOT/bench.py --train --precision f16 --rows-per-gpu $rows --steps 20 --warmup 5 --extra-file $GRAFT_REPO_ROOT/gpurun_out/prof_share_$rows.json > $GRAFT_REPO_ROOT/gpurun_out/prof_share_$rows.line 2>&1
-done
-cd $GRAFT_REPO_ROOT; find gpurun_out/prof_share_512 gpurun_out/prof_share_4096 -name "*kernel_stats.csv" | head; find gpurun_out/prof_share_512 -name "*kernel_trace.csv" -size +30M -delete; find gpurun_out/prof_share_4096 -name "*kernel_trace.csv" -size +30M -delete
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_share_512sp -o share -- python3 $root/bench.py --train --precision f16 --rows-per-gpu 512 --single-pass --graphed --steps 20 --warmup 5 --extra-file $root/gpurun_out/prof_share_512sp.json > $root/gpurun_out/prof_share_512sp.line 2>&1
+cd $root; ls gpurun_out/prof_share_512sp/
