@@ -96,14 +96,22 @@ struct UnitStreamT {
     static constexpr int kWaves = NW;
     static constexpr int kSlots = D;
     int hist[D > 3 ? D - 3 : 1];   // vector-memory instructions of the D - 3 units before the current one, newest first
-    const float* fetch_ptr;  // global address of the next unit to request
+    // The stream is addressed through a buffer descriptor (round 5): `buffer_load_dwordx4 ... lds` with the lane's 16 bytes in a
+    // CONSTANT offset register and the piece's position in a scalar -- no per-piece 64-bit vector address arithmetic.  In the
+    // trunk's skeleton the LDS-DMA of the weight stream costs 8 % with global_load_lds and 5.4 % this way
+    // (tools/probes/m64_skeleton.hip, profiles/r05_m64_skeleton.txt).
+    // Measured on the kernels (same box, profiles/r05_srd_ab.txt): 16-bit rendering +2-3 %, the bf16s8 iteration -1 %, the
+    // split-precision (P = 3) rendering kernel 1.3 % slower -- P = 3 keeps the global form.
+    __amdgpu_buffer_rsrc_t rsrc;
     const float* stream_base;
+    int lane_bytes;          // this lane's 16 bytes inside a KiB piece
+    int fetch_off;           // byte offset (from the stream's first byte) of the next unit to request
     float* lds;
     int slot;                // ring slot of the unit about to be consumed
     int lane, wave;
     int slot_floats;         // size of one ring slot (kUnitBufFloats, or less when the caller sized the ring to its units)
 
-    const float* pend_src;   // unit being requested piecewise (one DMA instruction per call of fetch_piece)
+    int pend_off;            // byte offset of the piece requested last (one DMA instruction per call of fetch_piece)
     float* pend_dst;
     int pend_left;           // DMA instructions this wave still has to issue for it
     int issued;              // DMA instructions issued for the youngest requested unit (>= its piece count)
@@ -120,9 +128,17 @@ struct UnitStreamT {
         return;
 #endif
         const int adv = pend_left > 0 ? NW * 256 : 0;
-        pend_src += adv; pend_dst += adv;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pend_src + lane * 4),
-                                         (__attribute__((address_space(3))) void*)pend_dst, 16, 0, 0);
+        pend_off += adv * 4; pend_dst += adv;
+        if constexpr (P == 1) {
+            // (Also tried: the same instruction as one asm statement, M0 saved and restored around it, and the tiles' bias vectors
+            // read one tile ahead by asm reads so that the compiler's own `s_waitcnt lgkmcnt(1)` -- it cannot see the asm fragment
+            // reads in flight -- no longer sits in front of every tile's first MFMA: 192 -> 14 such waits, 4 spilled registers,
+            // and no faster: 0.270 against 0.264 ms, profiles/r05_srd_ab.txt.  Not kept.)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)pend_dst, 16, lane_bytes, pend_off, 0, 0);
+        } else {      // (the split-precision kernels measured 1.3 % SLOWER with the descriptor form: they keep global_load_lds)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(stream_base + (pend_off >> 2) + lane * 4),
+                                             (__attribute__((address_space(3))) void*)pend_dst, 16, 0, 0);
+        }
         pend_left -= pend_left > 0 ? 1 : 0;
         ++issued;
     }
@@ -134,17 +150,17 @@ struct UnitStreamT {
     // No further unit to request: the (branch-free) fetch_piece calls of the remaining k-steps re-read one valid KiB of
     // the stream into a per-wave dump area instead of touching a live buffer.
     __device__ __forceinline__ void issued_next_none() {
-        pend_src = stream_base;
+        pend_off = 0;
         pend_dst = lds + D * slot_floats + wave * 256;  // dump: NW KiB right after the ring
         pend_left = 0;
         issued = 0;
     }
     __device__ __forceinline__ void begin_fetch(int ksteps, int into_slot) {
-        pend_src = fetch_ptr + wave * 256 - NW * 256;   // fetch_piece pre-increments
+        pend_off = fetch_off + (wave * 256 - NW * 256) * 4;   // fetch_piece pre-increments
         pend_dst = lds + into_slot * slot_floats + wave * 256 - NW * 256;
         pend_left = P == 3 ? ksteps >> 1 : (ksteps + NW - 1) / NW;
         issued = 0;
-        fetch_ptr += ksteps * KF;
+        fetch_off += ksteps * KF * 4;
     }
     __device__ __forceinline__ void fetch(int ksteps, int into_slot) {
         begin_fetch(ksteps, into_slot);
@@ -152,7 +168,11 @@ struct UnitStreamT {
     }
     __device__ __forceinline__ void start(const float* first, float* lds_base, int ks0, int ks1, int lane_, int wave_,
                                           int slot_floats_ = kUnitBufFloats) {
-        fetch_ptr = first; stream_base = first; lds = lds_base; slot = 0; lane = lane_; wave = wave_; pend_left = 0; issued = 0;
+        // (the descriptor covers 2 GiB from the stream's first byte: the streams are a few MB; wave-uniform inputs only)
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first), 0, 0x7ffffff0, 0x00020000);
+        stream_base = first;
+        fetch_off = 0; lds = lds_base; slot = 0; lane = lane_; wave = wave_; pend_left = 0; issued = 0;
+        lane_bytes = lane_ * 16;
         younger = 0; slot_floats = slot_floats_;
 #pragma unroll
         for (int i = 0; i < (D > 3 ? D - 3 : 1); ++i) hist[i] = 0;

@@ -122,6 +122,85 @@ __global__ void __launch_bounds__(512, 2) skeleton32(const f16x8* __restrict__ w
     if (sum == 12345.678f) out[0] = sum;
 }
 
+// ------------------------------------------------------------------------------------------------ shape 32 + the weight stream's DMA
+// What does ISSUING the weight stream cost (the real kernel without its LDS-DMA is 14 % faster, r05_m16_ablation.txt)?  The shipped
+// shape with, per tile (= staging unit: 16 KiB for the 8 waves), two 1-KiB loads per wave of a 1.2 MB global stream:
+//   MODE 1: global_load_lds_dwordx4 into a 16-KiB area beside the resident weights (never read: the timing of the DMA alone)
+//   MODE 2: the same bytes by global_load_dwordx4 into registers (kept alive by an empty asm, never used): vector-memory issue and
+//           L2 -> CU traffic without the LDS write
+//   MODE 4: MODE 1 through buffer_load_dwordx4 ... lds
+//   MODE 3: MODE 1 + the counted wait and the workgroup barrier of the ring's hand-over at every tile
+template <int MODE>
+__global__ void __launch_bounds__(512, 2) skeleton32_dma(const f16x8* __restrict__ weights, const f16x8* __restrict__ operands,
+                                                         const float* __restrict__ bias_g, float* out, const float* __restrict__ stream) {
+    extern __shared__ __attribute__((aligned(16))) f16x8 lds[];
+    const int lane = threadIdx.x & 63, grp = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < kLayerFrags * 64; i += blockDim.x) lds[i] = weights[i];
+    float* bias = reinterpret_cast<float*>(lds + kLayerFrags * 64);
+    if (threadIdx.x < 256) bias[threadIdx.x] = bias_g[threadIdx.x];
+    float* ring = bias + 256;                  // 4096 floats
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds + lane * 16;
+    f16x8 xh[8][2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) xh[c][s] = operands[((c * 2 + s) * 64 + lane) % (16 * 64)];
+    f32x4 acc[8][2][2];
+    int unit = 0;
+    f32x4 sink = {0, 0, 0, 0};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stream), 0, (320 * 1024 + 8192) * 4, 0x00020000);
+    for (int pass = 0; pass < kPasses; ++pass) {
+        for (int layer = 0; layer < kLayers; ++layer) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (MODE == 3) {
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 32 * u + 4 * grp);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + 32 * u + 16 + 4 * grp);
+                acc[u][0][0] = b0; acc[u][0][1] = b0; acc[u][1][0] = b1; acc[u][1][1] = b1;
+                const int soff = __builtin_amdgcn_readfirstlane((((unit * 4096) % (300 * 1024)) + wave * 256) * 4);
+                const float* src = stream + (size_t)((unit * 4096) % (300 * 1024)) + wave * 256 + lane * 4;
+                float* dst = ring + wave * 256;       // (one 16-KiB slot written over and over: nobody reads it)
+                tile_kloop<2>(lds0 + u * 16 * 1024, acc[u], xh, [&](int c) __attribute__((always_inline)) {
+                    if (c == 0 || c == 4) {
+                        const int piece = c >> 2;
+                        if (MODE == 1 || MODE == 3) {
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 2048),
+                                                             (__attribute__((address_space(3))) void*)(dst + piece * 2048), 16, 0, 0);
+                        } else if (MODE == 4) {
+                            // the same piece by buffer_load_dwordx4 ... lds: descriptor in SGPRs, the lane's 16 bytes in a constant
+                            // voffset register, the piece's position in the scalar offset -- no per-piece vector address arithmetic
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + piece * 2048), 16,
+                                                                 lane * 16, soff + piece * 8192, 0, 0);
+                        } else if (MODE == 2) {
+                            f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + piece * 2048));
+                            asm volatile("" : "+v"(v));
+                            sink = v;      // (overwritten, never accumulated: the load's register is free again at the next piece)
+                        }
+                    }
+                });
+                ++unit;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) to_operand(acc[u][0][s], acc[u][1][s], xh[u][s]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float sum = sink[0];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) sum += (float)xh[c][s][0] + (float)xh[c][s][5];
+    if (sum == 12345.678f) out[0] = sum;
+}
+
 // ------------------------------------------------------------------------------------------------ pipelined layers (the proposal)
 // one layer: operands `in` -> `next`; tile u's epilogue is dealt out, one sample tile per 8 / NS k-blocks, behind tile u + 1's
 // MFMAs (and the last tile's behind nothing: it is the layer's tail).  NS = 4: the 64-sample wave tile (one wave per SIMD);
@@ -188,16 +267,26 @@ int main(int argc, char** argv) {
     for (auto& v : w) v = (_Float16)(rnd() * 0.11f);      // (keeps the activations O(1) through the layers: random, non-trivial operands)
     for (auto& v : x) v = (_Float16)(rnd() > 0 ? rnd() * 0.7f : 0.0f);
     for (auto& v : b) v = rnd() * 0.1f;
-    f16x8 *dw, *dx; float *db, *dout;
+    f16x8 *dw, *dx; float *db, *dout, *dstream;
     hipMalloc(&dw, w.size() * 2); hipMalloc(&dx, x.size() * 2); hipMalloc(&db, b.size() * 4); hipMalloc(&dout, 4);
+    {   // the global weight stream of the DMA variants: 1.2 MB + slack, random
+        std::vector<float> st(320 * 1024 + 8192);
+        for (auto& v : st) v = rnd();
+        hipMalloc(&dstream, st.size() * 4);
+        hipMemcpy(dstream, st.data(), st.size() * 4, hipMemcpyHostToDevice);
+    }
     hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(dx, x.data(), x.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice);
-    const size_t ldsb = kLayerFrags * 1024 + kBiasBytes;
+    const size_t ldsb = kLayerFrags * 1024 + kBiasBytes + 16384;
     struct Variant { const char* name; const void* fn; int threads; };
     const Variant variants[] = {{"32 (as shipped: 2 waves/SIMD, tiles kept, converted after the layer)", (const void*)skeleton32, 512},
                                 {"32p (2 waves/SIMD, tile u converted behind tile u+1's MFMAs)", (const void*)skeleton_pipelined<2>, 512},
-                                {"64p (1 wave/SIMD, 64-sample wave tile, pipelined)", (const void*)skeleton_pipelined<4>, 256}};
+                                {"64p (1 wave/SIMD, 64-sample wave tile, pipelined)", (const void*)skeleton_pipelined<4>, 256},
+                                {"32 + LDS-DMA of the weight stream (2 x 1 KiB per wave and tile), never waited for", (const void*)skeleton32_dma<1>, 512},
+                                {"32 + the same bytes by global_load_dwordx4 into registers", (const void*)skeleton32_dma<2>, 512},
+                                {"32 + LDS-DMA + counted wait + workgroup barrier per tile", (const void*)skeleton32_dma<3>, 512},
+                                {"32 + LDS-DMA by buffer_load ... lds (descriptor + scalar offset, no vector address arithmetic)", (const void*)skeleton32_dma<4>, 512}};
     for (const Variant& v : variants) {
         hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipFuncAttributes at;
@@ -212,7 +301,7 @@ int main(int argc, char** argv) {
             auto t0 = std::chrono::steady_clock::now();
             long launches = 0;
             double elapsed = 0;
-            void* args[] = {(void*)&dw, (void*)&dx, (void*)&db, (void*)&dout};
+            void* args[] = {(void*)&dw, (void*)&dx, (void*)&db, (void*)&dout, (void*)&dstream};
             while (elapsed < seconds) {
                 for (int i = 0; i < 10; ++i) hipLaunchKernel(v.fn, dim3(blocks), dim3(v.threads), args, ldsb, 0);
                 hipDeviceSynchronize();
