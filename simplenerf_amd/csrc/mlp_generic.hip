@@ -44,49 +44,86 @@ struct GemmArgs {
     long long split_stride;                    // C + z * split_stride (a partial-sum buffer); 0 = no split
 };
 
-constexpr int kBM = 64, kBN = 64, kBK = 32, kPad = 1;
+constexpr int kBK = 32, kPad = 1;
 
-__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
-    __shared__ float As[2][kBK][kBM + kPad];
-    __shared__ float Bs[2][kBK][kBN + kPad];
+// BM x BN output tile per 256-thread workgroup = a 2 x 2 grid of waves, each (BM / 2) x (BN / 2) = TM x TN MFMA tiles of 32 x 32.
+// <64, 64>: one tile per wave (the round-4 kernel: 0.40 of the fp32 matrix peak at width 512 -- per staged byte and per barrier
+// it does a quarter of the matrix work of) <128, 128> (round 5): four tiles per wave, every operand value read from LDS feeds
+// two MFMAs, 64 KiB of LDS for the two stages; used wherever the product is at least 128 x 128.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int LA = BM * kBK / 256, LB = BN * kBK / 256;      // elements of a stage per thread
+    __shared__ float As[2][kBK][BM + kPad];
+    __shared__ float Bs[2][kBK][BN + kPad];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const long long k_lo = g.split_stride ? (long long)blockIdx.z * g.k_chunk : 0;
     const long long k_hi = g.split_stride ? (k_lo + g.k_chunk < g.K ? k_lo + g.k_chunk : g.K) : g.K;
     float* C = g.C + (g.split_stride ? (long long)blockIdx.z * g.split_stride : 0);
 
-    // thread -> elements of a stage: 8 of A (kBM x kBK) and 8 of B (kBK x kBN), walking the contiguous dimension first
+    // thread -> elements of a stage: LA of A (BM x kBK) and LB of B (kBK x BN), walking the contiguous dimension first.
+    // Element e of a thread sits a FIXED step from element e - 1, in memory and in LDS: one 32-bit byte offset per operand and
+    // thread (computed once), a wave-uniform base per stage and element (scalar arithmetic), immediate LDS offsets.  (Round 4
+    // computed m * a_rs + k * a_cs in 64 bits per element and stage: 1 021 vector instructions beside 16 MFMAs, 2 785 beside 64
+    // in the first 128 x 128 build -- the kernel was bound by its address arithmetic, not by the matrix pipe.)
     const bool a_m_major = g.a_rs == 1;        // A contiguous along m (the transposed operand of the weight gradient)
     const bool b_n_major = g.b_cs == 1;
-    float ra[8], rb[8];
+    const int a_m = a_m_major ? (tid & (BM - 1)) : (tid / kBK), a_k = a_m_major ? (tid / BM) : (tid & (kBK - 1));
+    const int a_dm = a_m_major ? 0 : 256 / kBK, a_dk = a_m_major ? 256 / BM : 0;            // element e + 1 relative to e
+    const int b_n = b_n_major ? (tid & (BN - 1)) : (tid / kBK), b_k = b_n_major ? (tid / BN) : (tid & (kBK - 1));
+    const int b_dn = b_n_major ? 0 : 256 / kBK, b_dk = b_n_major ? 256 / BN : 0;
+    const unsigned a_byte = (unsigned)((long long)a_m * g.a_rs + (long long)a_k * g.a_cs) * 4u;   // (a_m < BM, a_k < 32: fits)
+    const unsigned b_byte = (unsigned)((long long)b_k * g.b_rs + (long long)b_n * g.b_cs) * 4u;
+    // (a thread's elements span < 16 steps of at most 8 rows or 4 k-columns: byte offsets inside the tile stay far below 2^31
+    // for any row length the activation matrix can have)
+    const unsigned a_step32 = (unsigned)(((long long)a_dm * g.a_rs + (long long)a_dk * g.a_cs) * 4);
+    const unsigned b_step32 = (unsigned)(((long long)b_dk * g.b_rs + (long long)b_dn * g.b_cs) * 4);
+    const int m_left = g.M - m0, n_left = g.N - n0;           // rows / columns of the tile inside the matrix
+    const char* const a_tile = reinterpret_cast<const char*>(g.A + (long long)m0 * g.a_rs);
+    const char* const b_tile = reinterpret_cast<const char*>(g.B + (long long)n0 * g.b_cs);
+    float ra[LA], rb[LB];
+    unsigned a_inside = 0, b_inside = 0;      // bit e: element e of the stage in flight lies inside the matrix
     auto load_stage = [&](long long k0) {
+        const char* a_stage = a_tile + k0 * g.a_cs * 4;
+        const char* b_stage = b_tile + k0 * g.b_rs * 4;
+        const int k_left = (int)(k_hi - k0 < kBK ? k_hi - k0 : kBK);       // 32 except in the last stage of a ragged K
+        // branch-free: an element outside the matrix reads the stage's first element (always inside) and is replaced by zero
+        // WHEN IT IS STORED, after this stage's MFMAs (a predicated load per element compiles to one exec-masked basic block per
+        // load, and a select right here makes the MFMAs wait for the loads they are meant to hide)
+        a_inside = b_inside = 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int idx = tid + 256 * e;
-            const int am = a_m_major ? (idx & (kBM - 1)) : (idx / kBK), ak = a_m_major ? (idx / kBM) : (idx & (kBK - 1));
-            const long long m = m0 + am, k = k0 + ak;
-            ra[e] = (m < g.M && k < k_hi) ? g.A[m * g.a_rs + k * g.a_cs] : 0.0f;
-            const int bn = b_n_major ? (idx & (kBN - 1)) : (idx / kBK), bk = b_n_major ? (idx / kBN) : (idx & (kBK - 1));
-            const long long n = n0 + bn, kb = k0 + bk;
-            rb[e] = (n < g.N && kb < k_hi) ? g.B[kb * g.b_rs + n * g.b_cs] : 0.0f;
+        for (int e = 0; e < LA; ++e) {
+            const bool inside = a_m + e * a_dm < m_left && a_k + e * a_dk < k_left;
+            a_inside |= inside ? 1u << e : 0u;
+            ra[e] = *reinterpret_cast<const float*>(a_stage + (inside ? a_byte + (unsigned)e * a_step32 : 0u));
+        }
+#pragma unroll
+        for (int e = 0; e < LB; ++e) {
+            const bool inside = b_n + e * b_dn < n_left && b_k + e * b_dk < k_left;
+            b_inside |= inside ? 1u << e : 0u;
+            rb[e] = *reinterpret_cast<const float*>(b_stage + (inside ? b_byte + (unsigned)e * b_step32 : 0u));
         }
     };
+    float* const as0 = &As[0][a_k][a_m];
+    float* const bs0 = &Bs[0][b_k][b_n];
+    const int as_step = a_dk * (BM + kPad) + a_dm, bs_step = b_dk * (BN + kPad) + b_dn;
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int idx = tid + 256 * e;
-            const int am = a_m_major ? (idx & (kBM - 1)) : (idx / kBK), ak = a_m_major ? (idx / kBM) : (idx & (kBK - 1));
-            As[buf][ak][am] = ra[e];
-            const int bn = b_n_major ? (idx & (kBN - 1)) : (idx / kBK), bk = b_n_major ? (idx / kBN) : (idx & (kBK - 1));
-            Bs[buf][bk][bn] = rb[e];
-        }
+        for (int e = 0; e < LA; ++e) as0[buf * (kBK * (BM + kPad)) + e * as_step] = (a_inside >> e) & 1u ? ra[e] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < LB; ++e) bs0[buf * (kBK * (BN + kPad)) + e * bs_step] = (b_inside >> e) & 1u ? rb[e] : 0.0f;
     };
 
-    // wave (wm, wn) owns the 32 x 32 sub-tile; MFMA operands: A(m = lane & 31, k = lane >> 5), B(k = lane >> 5, n = lane & 31)
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, i = lane & 31, h = lane >> 5;
-    f32x16 acc;
+    // wave (wm, wn) owns a (32 TM) x (32 TN) sub-tile; MFMA operands: A(m = lane & 31, k = lane >> 5), B(k = lane >> 5, n = lane & 31)
+    const int wm = (wave >> 1) * (32 * TM), wn = (wave & 1) * (32 * TN), i = lane & 31, h = lane >> 5;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
     if (k_lo < k_hi) {
         load_stage(k_lo);
         store_stage(0);
@@ -95,9 +132,20 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         for (long long k0 = k_lo; k0 < k_hi; k0 += kBK) {
             const bool more = k0 + kBK < k_hi;
             if (more) load_stage(k0 + kBK);                     // in flight during this stage's MFMAs
+            const float* a_rd = &As[buf][h][wm + i];
+            const float* b_rd = &Bs[buf][h][wn + i];
 #pragma unroll
-            for (int p = 0; p < kBK / 2; ++p)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][2 * p + h][wm + i], Bs[buf][2 * p + h][wn + i], acc, 0, 0, 0);
+            for (int p = 0; p < kBK / 2; ++p) {
+                float av[TM], bv[TN];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) av[tm] = a_rd[2 * p * (BM + kPad) + 32 * tm];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bv[tn] = b_rd[2 * p * (BN + kPad) + 32 * tn];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+            }
             if (more) {
                 store_stage(buf ^ 1);
                 __syncthreads();
@@ -106,19 +154,24 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         }
     }
     // D layout: lane (i = column, h), register r -> row (r & 3) + 8 (r >> 2) + 4 h of the 32 x 32 tile
-    const long long n = n0 + wn + i;
-    if (n >= g.N) return;
-    const float bias = g.bias ? g.bias[n] : 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const long long m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= g.M) continue;
-        float v = acc[r] + bias;
-        float* dst = C + m * g.c_rs + n * g.c_cs;
-        if (g.accumulate) v += *dst;
-        if (g.relu) v = fmaxf(v, 0.0f);
-        if (g.mask) v = g.mask[m * g.mask_rs + n] > 0.0f ? v : 0.0f;
-        *dst = v;
+    for (int tn = 0; tn < TN; ++tn) {
+        const long long n = n0 + wn + 32 * tn + i;
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                float v = acc[tm][tn][r] + bias;
+                float* dst = C + m * g.c_rs + n * g.c_cs;
+                if (g.accumulate) v += *dst;
+                if (g.relu) v = fmaxf(v, 0.0f);
+                if (g.mask) v = g.mask[m * g.mask_rs + n] > 0.0f ? v : 0.0f;
+                *dst = v;
+            }
     }
 }
 
@@ -235,8 +288,18 @@ __global__ void __launch_bounds__(256) copy_kernel(float* __restrict__ dst, cons
 // ------------------------------------------------------------------------------------------------------------ host side
 int launch_gemm(const GemmArgs& g, int splits, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return SNERF_OK;
-    const dim3 grid((g.N + kBN - 1) / kBN, (g.M + kBM - 1) / kBM, splits > 0 ? splits : 1);
-    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, g);
+    // (the same arithmetic per output element either way: each is one fp32 FMA chain over k in order -- the tile only decides
+    // which workgroup computes it)
+    // ... the large tile only where it still fills the chip twice over: a 256 x 256 weight gradient split 32 ways is 128 workgroups
+    // of 128 x 128 (22.6 -> 25.5 ms for the 8 x 256 / 2 x 128 backward before this condition)
+    const long long large_tiles = (long long)((g.N + 127) / 128) * ((g.M + 127) / 128) * (splits > 0 ? splits : 1);
+    if (g.M >= 128 && g.N >= 128 && large_tiles >= 512) {
+        const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, splits > 0 ? splits : 1);
+        hipLaunchKernelGGL((gemm_kernel<128, 128>), grid, dim3(256), 0, s, g);
+    } else {
+        const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, splits > 0 ? splits : 1);
+        hipLaunchKernelGGL((gemm_kernel<64, 64>), grid, dim3(256), 0, s, g);
+    }
     return snerf::check_launch("mlp_generic(gemm)");
 }
 

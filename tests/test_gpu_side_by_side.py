@@ -1,0 +1,102 @@
+"""Levels side by side (csrc/render.hip, round 5): below 65 536 coarse samples per call the augmentation levels of a training pass
+run on side streams forked from and joined to the caller's stream -- forward {main coarse -> fine} | points-aug | views-aug,
+backward all four side by side, each level with its own region of the workspace.  Every parity test with few rays already runs
+this way; here: (i) the results do not depend on it -- a 512-ray pass (side by side) equals the same rays evaluated as part of a
+2048-ray pass (131 072 coarse samples: levels in order on one stream) bit for bit, outputs and every parameter gradient of a
+per-ray loss; (ii) repeated passes are bit-identical (a race between levels would show as run-to-run noise); (iii) inside a HIP
+graph: GraphedTrainStep at 256 rows replays bit-identically to the eager pass (tests/test_gpu_optim.py covers the graphs at
+larger sizes)."""
+import pytest
+import torch
+
+from simplenerf_amd import synth
+from simplenerf_amd.models.ModelFactory import get_model
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _model(precision, binding):
+    cfg = synth.with_overrides(synth.make_configs('config3'), hip_precision=precision, hip_host_binding=binding, perturb=True,
+                               raw_noise_std=1.0)
+    cfg['seed'] = 11
+    model = get_model(cfg, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 7, 200.0, 8.0).items()})
+    return model.to(DEV).train()
+
+
+def _batch(n, first=0):
+    from simplenerf_amd import harness
+    cam = synth.camera('fern', 0)
+    h, w = cam['resolution']
+    batch = harness.frame_batch(cam, True, DEV, (h // 2) * w + first, n)
+    batch['iter_num'] = 5
+    batch['global_rows'] = torch.arange(first, first + n, dtype=torch.int64, device=DEV)
+    return batch
+
+
+def _loss(out, rows=slice(None)):
+    keys = ('rgb_coarse', 'rgb_fine', 'depth_ndc_fine', 'points_augmentation_rgb_coarse', 'views_augmentation_depth_ndc_coarse',
+            'points_augmentation_depth_ndc_coarse', 'views_augmentation_rgb_coarse')
+    return sum((out[k][rows] ** 2).sum() for k in keys)
+
+
+@pytest.mark.parametrize('precision,binding', [('fp32', 'torch_ext'), ('f16', 'torch_ext'), ('f16', 'ctypes')])
+def test_side_by_side_levels_equal_levels_in_order(precision, binding):
+    model = _model(precision, binding)
+    # 2048 rays x 64 = 131 072 coarse samples: one stream; its first 512 rays alone: 32 768 samples, side by side.  The draws are
+    # keyed by (iteration, global row), so the 512 rays see the same jitter and noise either way.
+    big, small = _batch(2048), _batch(512)
+    out_big = model(big)
+    model.zero_grad(set_to_none=True)
+    _loss(out_big, slice(0, 512)).backward()          # only the first 512 rays carry a gradient
+    grads_big = [p.grad.clone() for p in model.parameters()]
+    out_small = model(small)
+    for key, value in out_small.items():
+        assert torch.equal(value, out_big[key][:512]), key
+    model.zero_grad(set_to_none=True)
+    _loss(out_small).backward()
+    if precision == 'fp32':
+        # the weight gradients' partial sums are grouped by workgroup, and the grouping follows the sample count: equal to
+        # rounding, not to the bit
+        for (name, p), ref in zip(model.named_parameters(), grads_big):
+            scale = float(ref.abs().max()) + 1e-30
+            assert float((p.grad - ref).abs().max()) <= 2e-5 * scale, name
+    # (ii) the same small pass again, several times: bit-identical outputs and gradients
+    ref_out = {k: v.clone() for k, v in out_small.items()}
+    ref_grads = [p.grad.clone() for p in model.parameters()]
+    for _ in range(5):
+        again = model(small)
+        model.zero_grad(set_to_none=True)
+        _loss(again).backward()
+        assert all(torch.equal(again[k], ref_out[k]) for k in ref_out)
+        assert all(torch.equal(p.grad, g) for p, g in zip(model.parameters(), ref_grads))
+    assert float(sum(g.abs().sum() for g in ref_grads)) > 0
+
+
+def test_side_by_side_levels_inside_a_graph():
+    from simplenerf_amd import harness
+    from simplenerf_amd.data_preprocessors.BatchAssembler01 import BatchAssembler
+    from simplenerf_amd.loss_functions.LossComputer01 import LossComputer
+    cfg = synth.training_configs('f16', num_rays=192, num_sparse=64)          # 256 rows: every level side by side
+    cfg['losses'] = synth.loss_configs(iter_weighted=False)
+    scene = synth.training_scene(0, 3, 48, 64, sparse_fraction=0.05)
+    models = []
+    for _ in range(2):
+        m = get_model(cfg, None)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, 9, 200.0, 8.0).items()})
+        models.append(m.to(DEV).train())
+    eager, graphed = models
+    batcher, losses = BatchAssembler(cfg, scene, DEV), LossComputer(cfg)
+    step = harness.GraphedTrainStep(graphed, losses, batcher.get_next_batch(0))
+    for it in range(4):
+        batch = batcher.get_next_batch(it)
+        eager.zero_grad(set_to_none=True)
+        ref = losses.compute_losses(dict(batch, common_data=dict(batch['common_data'])), eager(batch))
+        ref['TotalLoss'].backward()
+        totals = step(batch)
+        assert float(totals['TotalLoss']) == float(ref['TotalLoss'].detach()), it
+        for (name, a), b in zip(eager.named_parameters(), graphed.parameters()):
+            assert torch.equal(a.grad, b.grad), (it, name)
