@@ -421,9 +421,8 @@ def pmc_train_traffic(precision):
     if 'hbm_gb_per_iteration' not in record:
         return None
     return {'hbm_gb_per_iteration': record['hbm_gb_per_iteration'],
-            'source': f"profiles/{name}: separate rocprofv3 --pmc passes of `bench.py --train --precision {precision}` over "
-                      f"{record.get('iterations')} iterations (FETCH_SIZE | WRITE_SIZE, gfx950 correction), collected at commit "
-                      f"{record.get('commit', 'unrecorded')} -- NOT measured in this run"}
+            'source': f"profiles/{name} @ {record.get('commit', 'unrecorded')} (separate rocprofv3 --pmc passes of `bench.py --train --precision "
+                      f"{precision}`, all kernels, not this run)"}
 
 
 # ---------------------------------------------------------------------------------------------- timing protocol

@@ -8,7 +8,7 @@ On the GPU box, one pass per counter set (--pmc never together with the trace do
         rocprofv3 --pmc $set --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/<tag>_${set%% *} -o p -- python3 <command>
     done
 here:  python tools/collect_pmc_kernels.py gpurun_out/<tag> profiles/<name>.json "<command, for the record>" [kernel-name filter ...]
-       [--iterations N]    the command ran N iterations of the step: adds `hbm_gb_per_iteration` = sum over ALL kernels of
+       [--iterations N|auto]    the command ran N iterations of the step (auto: half the adam_kernel dispatches): adds `hbm_gb_per_iteration` = sum over ALL kernels of
                            (HBM bytes per dispatch x dispatches) / N -- what `bench.py --train` reports as its `traffic`
 
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reports half of a wide streaming read, WRITE_SIZE is
@@ -45,14 +45,16 @@ def main():
     iterations = None
     if '--iterations' in filters:
         at = filters.index('--iterations')
-        iterations = int(filters[at + 1])
+        iterations = filters[at + 1]          # a number, or `auto`: one iteration = two launches of adam_kernel (counted below)
         filters = filters[:at] + filters[at + 2:]
     sq, sq_t = load(f'{tag}_SQ_VALU_MFMA_BUSY_CYCLES/p_counter_collection.csv')
-    fetch, _ = load(f'{tag}_FETCH_SIZE/p_counter_collection.csv')
-    write, _ = load(f'{tag}_WRITE_SIZE/p_counter_collection.csv')
+    fetch, fetch_t = load(f'{tag}_FETCH_SIZE/p_counter_collection.csv')
+    write, write_t = load(f'{tag}_WRITE_SIZE/p_counter_collection.csv')
     mean = lambda xs: sum(xs) / len(xs)
     rows = []
     every_kernel_bytes = 0.0
+    fetch_bytes = sum(2 * sum(fetch[k]['FETCH_SIZE']) * 1024 for k in fetch)
+    write_bytes = sum(sum(write[k]['WRITE_SIZE']) * 1024 for k in write)
     for k in fetch:
         if k in write:
             every_kernel_bytes += (2 * sum(fetch[k]['FETCH_SIZE']) + sum(write[k]['WRITE_SIZE'])) * 1024
@@ -80,8 +82,19 @@ def main():
     head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__)))
     out['commit'] = head.stdout.strip() or 'unrecorded'
     if iterations:
-        out['iterations'] = iterations
-        out['hbm_gb_per_iteration'] = every_kernel_bytes / iterations / 1e9
+        if iterations == 'auto':
+            # the passes are separate runs, and a run's settle phase is timed, not counted: each pass has its own iteration count
+            def count(times):
+                adam = [len(times[k]) for k in times if k.endswith('adam_kernel')]
+                if not adam:
+                    raise SystemExit('--iterations auto: no adam_kernel dispatches in the trace')
+                return adam[0] // 2
+            out['iterations'] = {'sq_pass': count(sq_t), 'fetch_pass': count(fetch_t), 'write_pass': count(write_t)}
+            out['hbm_gb_per_iteration'] = (fetch_bytes / count(fetch_t) + write_bytes / count(write_t)) / 1e9
+        else:
+            iterations = int(iterations)
+            out['iterations'] = iterations
+            out['hbm_gb_per_iteration'] = every_kernel_bytes / iterations / 1e9
     with open(dst, 'w') as f:
         json.dump(out, f, indent=1)
     for r in rows:
