@@ -671,7 +671,6 @@ def training_step(precision, rank, world, device, single_pass=False, graphed=Fal
                                       force_collective=collective)
 
     step.short_batches = 0
-    step.model = model
     return step, 2 * rows
 
 

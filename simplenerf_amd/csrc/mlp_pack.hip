@@ -23,13 +23,17 @@ struct SegmentTable {
     const float* w[kSegmentsPerLaunch];
     snerf::Segment seg[kSegmentsPerLaunch];
 };
-constexpr int kStagesPerLaunch = 8;
+// (20 since round 5, 8 before: the 19 stages a 16-bit training re-pack writes -- forward + transposed stream of an 8 x 256 MLP -- go in ONE
+// launch instead of three; a re-pack is launch-latency-bound, ~4.6 us per dependent launch, and a training iteration re-packs
+// four MLPs.  The table travels as a kernel argument: it must stay under the 4-KiB limit.)
+constexpr int kStagesPerLaunch = 20;
 struct StageTable {
     const float* w[kStagesPerLaunch][3];
     snerf::MlpPlan::HalfStage stage[kStagesPerLaunch];
     int m16[kStagesPerLaunch];   // 1: fragment layout of the 16x16x32 MFMA (mlp_forward_m16.hip)
     int* weight_range;           // word of the packed buffer: kRangeWeight is OR-ed in when a weight does not fit fp16
 };
+static_assert(sizeof(StageTable) <= 3968, "StageTable is passed by value: kernel arguments are limited to 4 KiB");
 constexpr int kCopiesPerLaunch = 16;
 struct CopyTable {
     const float* src[kCopiesPerLaunch];

@@ -54,6 +54,11 @@ SideStreams* side_streams(hipStream_t main) {
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(g_side_mutex);
+    // (streams and events are kept for the life of the process -- a captured graph may hold them; a caller that keeps creating
+    // streams gets side streams for the first kMaxSideSets of them and plain in-order levels afterwards)
+    constexpr size_t kMaxSideSets = 64;
+    auto found = g_side.find({device, main});
+    if (found == g_side.end() && g_side.size() >= kMaxSideSets) return nullptr;
     SideStreams& s = g_side[{device, main}];
     if (!s.ok) {
         bool good = hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess;
