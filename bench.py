@@ -1061,10 +1061,18 @@ def quick_also(args, device, make_renderer, fence, result):
         key = f'train_{precision}'
         try:
             ms, fwd_ms, bwd_ms, rows = time_training(precision, device, 10, 3)
+            retimed = None
+            if time_training.timing['step_ms']['max'] > 3 * time_training.timing['step_ms']['p50']:
+                # a one-off host stall inside a 10-step region (seen once: 105 ms of enqueue in the first timed step, 8.0 ms in
+                # every other) would be a third of this scalar: the region is timed once more and both are recorded
+                retimed = {'first_attempt_ms_per_step': ms, 'first_attempt_timing': time_training.timing}
+                ms, fwd_ms, bwd_ms, rows = time_training(precision, device, 10, 3)
             tflops = rows * TRAIN_FLOP_PER_RAY / (ms * 1e-3) / 1e12
             full[key] = {'workload': TRAIN_WORKLOAD, 'dtype': TRAIN_DTYPE[precision], 'ms_per_step': ms, 'rows': rows,
                          'value': rows / (ms * 1e-3), 'algorithmic_tflops': tflops, 'peak_tflops': PEAK_FP16_MFMA_TFLOPS,
                          'mlp_forward_ms_per_step': fwd_ms, 'mlp_backward_ms_per_step': bwd_ms, 'timing': time_training.timing}
+            if retimed:
+                full[key]['retimed_after_a_stall'] = retimed
             also[key] = {'ms': ms, 'frac': tflops / PEAK_FP16_MFMA_TFLOPS}
         except Exception as err:            # noqa: BLE001
             also[key], full[key] = None, {'error': repr(err)[:500]}

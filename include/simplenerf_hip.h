@@ -100,7 +100,13 @@ int snerf_mlp_pack(const snerf_mlp_desc* desc, const float* const* params, int n
  * two (the fp32 precision: the fp32 segments alone).  This variant writes what calls at ONE precision (enum snerf_precision, below) in ONE mode will read -- training != 0:
  * snerf_mlp_forward_train / snerf_mlp_backward / the render ops with saved activations; training == 0: additionally the
  * rendering layout -- and zeroes the rest: the caller re-packs when it changes precision or mode (the Python model keys its
- * packed streams by both).  No counterpart in the reference (its modules read their parameters directly). */
+ * packed streams by both).  No counterpart in the reference (its modules read their parameters directly).
+ *
+ * Round 5: the library remembers, per packed buffer (by address, host side), which formats its last pack call wrote, and every
+ * entry point that reads a weight stream (snerf_mlp_forward[_train|_visibility], snerf_mlp_backward, the render calls) returns
+ * SNERF_E_INVALID before enqueuing anything when the buffer does not hold what the call reads -- a stream packed for (f16,
+ * training) used by an eval render used to multiply the zero-filled rendering layout and return bias-only output with SNERF_OK.
+ * A buffer no pack call of this library instance has written (a device-to-device copy of a packed buffer) is not checked. */
 int snerf_mlp_pack_for(const snerf_mlp_desc* desc, const float* const* params, int num_params, float* packed, int precision,
                        int training, snerf_stream_t stream);
 
@@ -315,7 +321,15 @@ typedef struct snerf_render_outputs {
     snerf_render_level_out level[SNERF_RENDER_LEVELS];
 } snerf_render_outputs;
 
-/* Scratch of snerf_render_forward in floats (the main coarse weights, when level[0].weights is NULL). */
+/* Scratch of snerf_render_forward in floats (the main coarse weights, when level[0].weights is NULL).
+ *
+ * Round 5: below 65 536 coarse samples per call (num_rays x num_coarse) and with more than two MLP levels, snerf_render_forward and
+ * snerf_render_backward run the levels SIDE BY SIDE on streams of the library's own -- forward {main coarse -> fine} | points-aug
+ * | views-aug, backward every level -- forked from `stream` and joined back to it with events before the call returns: the call
+ * is still enqueue-only, work enqueued on `stream` afterwards is ordered after all of it, and a graph capture of `stream`
+ * records the side streams as parallel branches.  Results are bit-identical to the levels in order.  The side streams and
+ * events are created on first use per (device, stream) and kept for the life of the process (at most 64 sets; further caller
+ * streams get the levels in order). */
 size_t snerf_render_workspace_floats(const snerf_render_config* cfg, long long num_rays);
 int snerf_render_forward(const snerf_render_config* cfg, const snerf_render_mlp* mlps, const snerf_render_rays* rays,
                          long long num_rays, const snerf_render_outputs* out, float* workspace, snerf_stream_t stream);
@@ -328,7 +342,8 @@ typedef struct snerf_render_level_grads {   /* dL/d(output) of one level, each (
 } snerf_render_level_grads;
 
 /* Scratch of snerf_render_backward in floats: d sigma + d rgb of the largest level + the largest snerf_mlp_backward
- * workspace among the present levels (levels run one after another on the stream and share it). */
+ * workspace among the present levels (levels run one after another on the stream and share it); for a call whose levels run
+ * side by side (above) the SUM over the levels -- each level its own region.  Always ask this function. */
 size_t snerf_render_backward_workspace_floats(const snerf_render_config* cfg, const snerf_render_mlp* mlps, long long num_rays);
 /* `out` = the buffers snerf_render_forward (keep_activations != 0) filled for the same cfg / mlps / rays.  A level whose
  * param_grads is NULL, or whose six gradient pointers are all NULL, is skipped (its param_grads are not touched). */

@@ -65,9 +65,15 @@ SideStreams* side_streams(hipStream_t main) {
         for (int i = 0; i < kSideStreams && good; ++i)
             good = hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking) == hipSuccess &&
                    hipEventCreateWithFlags(&s.join[i], hipEventDisableTiming) == hipSuccess;
-        if (!good) {
+        if (!good) {                 // (the caller falls back to one stream; nothing half-made stays behind)
             (void)hipGetLastError();
-            return nullptr;          // (the caller falls back to one stream)
+            if (s.fork) (void)hipEventDestroy(s.fork);
+            for (int i = 0; i < kSideStreams; ++i) {
+                if (s.join[i]) (void)hipEventDestroy(s.join[i]);
+                if (s.stream[i]) (void)hipStreamDestroy(s.stream[i]);
+            }
+            g_side.erase({device, main});
+            return nullptr;
         }
         s.ok = true;
     }

@@ -1,6 +1,6 @@
 """The model run the way the REFERENCE runs it: wrapped in ``torch.nn.DataParallel(model, device_ids=[0])``
-(src/Trainer01.py:513-514, src/Tester01.py:39-43 -- the reference ALWAYS wraps, also on one GPU), driven by the trainer's own
-loop (Trainer.train_one_iter, src/Trainer01.py:61-107: zero_grad(set_to_none=True), sub-batches sliced out of every tensor of
+(src/Trainer01.py:513-514, src/Tester01.py:39-43 -- the reference ALWAYS wraps, also on one GPU), driven by the trainer's
+loop (Trainer.train_one_iter, src/Trainer01.py:61-107, restated in `_trainer_iteration`: zero_grad(set_to_none=True), sub-batches sliced out of every tensor of
 the batch, ``common_data`` copied per sub-batch, ``self.model(sub_input_batch)``, ``compute_losses``, ``TotalLoss.backward()``,
 ``optimizer.step()`` of a ``torch.optim.Adam(list(model.parameters()))``), saved with ``model.state_dict()`` (keys
 ``module.…``, :352-366) and loaded back into a second wrapped model as ``NerfTester.load_model`` does (src/Tester01.py:45-49),
@@ -36,29 +36,25 @@ def _fresh_model(cfg, seed=7):
     return model
 
 
-def _reference_train_one_iter(model, loss_computer, optimizer, input_batch, configs):
-    """Trainer.train_one_iter (src/Trainer01.py:79-102), statement for statement, on an already assembled batch."""
+def _trainer_iteration(model, loss_computer, optimizer, batch, configs):
+    """What Trainer.train_one_iter does with an assembled batch (src/Trainer01.py:79-102), restated: gradients cleared to None;
+    the batch cut into ``sub_batch_size`` pieces by slicing EVERY tensor of the dict along dim 0 (which is how the per-row
+    ``global_rows`` / ``indices`` travel), ``common_data`` shallow-copied per piece, everything else passed through; per piece
+    ``model(piece)`` -> ``compute_losses(piece, outputs)`` -> ``TotalLoss.backward()``; one ``optimizer.step()`` at the end.
+    Loss values are read with ``float()`` per piece, as the reference's ``.item()`` does."""
     optimizer.zero_grad(set_to_none=True)
-    actual_batch_size = input_batch['rays_o'].shape[0]
-    sub_batch_size = configs.get('sub_batch_size', actual_batch_size)
-    totals = {}
-    for start_idx in range(0, actual_batch_size, sub_batch_size):
-        sub_input_batch = {}
-        for key in input_batch.keys():
-            if isinstance(input_batch[key], torch.Tensor):
-                sub_input_batch[key] = input_batch[key][start_idx: start_idx + sub_batch_size]
-            elif key == 'common_data':
-                sub_input_batch[key] = input_batch[key].copy()
-            else:
-                sub_input_batch[key] = input_batch[key]
-        sub_output_batch = model(sub_input_batch)
-        sub_iter_losses_dict = loss_computer.compute_losses(sub_input_batch, sub_output_batch)
-        sub_iter_losses_dict['TotalLoss'].backward()
-        for name, entry in sub_iter_losses_dict.items():
-            value = entry['loss_value'] if isinstance(entry, dict) else entry
-            totals[name] = totals.get(name, 0.0) + float(value)
+    rows = batch['rays_o'].shape[0]
+    piece_rows = configs.get('sub_batch_size', rows)
+    sums = {}
+    for first in range(0, rows, piece_rows):
+        piece = {name: (value[first:first + piece_rows] if torch.is_tensor(value) else
+                        (value.copy() if name == 'common_data' else value)) for name, value in batch.items()}
+        terms = loss_computer.compute_losses(piece, model(piece))
+        terms['TotalLoss'].backward()
+        for name, term in terms.items():
+            sums[name] = sums.get(name, 0.0) + float(term['loss_value'] if isinstance(term, dict) else term)
     optimizer.step()
-    return totals
+    return sums
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'f16'])
@@ -87,7 +83,7 @@ def test_reference_trainer_and_tester_drive_the_wrapped_model(precision, tmp_pat
         assert batch_w['rays_o'].shape[0] == 4096 and batch_w['common_data']['poses'].dim() == 4      # leading replica axis
         assert isinstance(batch_w['iter_num'], int) and batch_w['global_rows'].shape == (4096,)
         keys_before = list(batch_w.keys())
-        totals_w = _reference_train_one_iter(wrapped, losses_w, opt_w, batch_w, cfg)
+        totals_w = _trainer_iteration(wrapped, losses_w, opt_w, batch_w, cfg)
         totals_p = harness.train_one_iter(plain, losses_p, opt_p, batch_p, cfg['sub_batch_size'])
         assert list(batch_w.keys()) == keys_before
         assert set(totals_w) == set(totals_p)

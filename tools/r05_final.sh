@@ -9,3 +9,10 @@ bash tools/profile_bench.sh ${tag} > gpurun_out/${tag}_profile_bench.log 2>&1; e
 bash tools/profile_train.sh ${tag} f16 > gpurun_out/${tag}_profile_train.log 2>&1; echo profile_train rc $?
 bash tools/pmc_passes.sh ${tag}_pmc_train_f16 bench.py --train --precision f16 --steps 8 --warmup 2 > gpurun_out/${tag}_pmc_train.log 2>&1; echo pmc_train rc $?
 bash tools/pmc_passes.sh ${tag}_pmc_train_bf16s8 bench.py --train --precision bf16s8 --steps 8 --warmup 2 > gpurun_out/${tag}_pmc_train_s8.log 2>&1; echo pmc_train_s8 rc $?
+# LDS and wave-state counters of the 16-bit rendering kernels (one pass each)
+root=$(pwd)
+for prec in f16 f16x3; do
+  o=$root/gpurun_out/${tag}_pmc_lds_$prec; rm -rf $o
+  (cd /tmp && export TMPDIR=/tmp && cd $root && rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $o -o p -- python3 bench.py --precision $prec --no-cpu-baseline --no-alt --steps 10 --warmup 2 > $o.log 2>&1); echo pmc_lds_$prec rc $?
+  find $o -name '*kernel_trace*' -delete; find $o -name '*.db' -delete
+done
