@@ -16,6 +16,13 @@ from .models.SimpleNeRFHip01 import global_rows
 
 Tensor = torch.Tensor
 DEFAULT_KEYS = ('rgb_fine', 'depth_fine', 'depth_var_fine')
+# Stream-capture mode of the two graphed steps below.  torch's default, 'global', makes EVERY thread's capture-unsafe HIP call
+# fail while the capture is open -- and with a process group alive, torch.distributed's NCCL watchdog thread polls the events of
+# earlier collectives (hipEventQuery) whenever it likes: if a poll falls inside the capture window the watchdog dies with
+# hipErrorStreamCaptureUnsupported and takes the process with it (round 5: one of three `bench.py --extras` runs, in the
+# rank-share leg, right after an eager all-reduce).  'thread_local' confines the check to the capturing thread, whose calls are
+# the stream-ordered launches the capture is there to record.
+CAPTURE_MODE = 'thread_local'
 
 
 def shard_range(num_rays: int, rank: int, world_size: int) -> Tuple[int, int]:
@@ -335,7 +342,7 @@ class GraphedTrainStep:
             p.grad = None                      # gradients are (re)allocated inside the capture: static addresses
         self.model.invalidate_packed()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
             self.totals = self._pass()
 
     def __call__(self, batch: Dict[str, object]) -> Dict[str, Tensor]:
@@ -484,7 +491,7 @@ class GraphedIteration:
                 p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
         self.model.invalidate_packed()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
             self.totals = self._body(iter_num, whole=True)
 
     def __call__(self, iter_num: int) -> Dict[str, Tensor]:
