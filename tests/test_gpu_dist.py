@@ -330,3 +330,17 @@ def test_default_bench_line_is_what_the_driver_parses():
     assert set(also) == {'f16x3', 'f16', 'bf16', 'train_f16', 'train_bf16s8'} and all(v is not None for v in also.values()), also
     assert full['timing']['step_ms']['p50'] > 0 and len(full['timing']['step_trace_ms']) == 20
     assert took < 240, took
+
+
+def test_bench_strong_scaled_training_two_ranks_with_the_real_kernels():
+    """``python bench.py --gpus 2 --train --global-rows 4096`` -- BASELINE config 5 as it is stated: ONE 4096-row batch over the
+    ranks.  Two self-launched ranks share the box's GPU (gloo carries the gradient all-reduce; tests/bench_rehearsal.py),
+    each holds 1024 pixel + 1024 sparse-depth rows of the same global index stream and runs them as two sub-batches; the line says
+    `scaling: strong` and counts the 4096 rows once."""
+    line = _bench('--train', '--global-rows', '4096', '--precision', 'f16', '--steps', '3', '--warmup', '1')
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['steps'] == 3
+    assert line['config']['rows_per_gpu'] == 2048 and line['config']['global_rows'] == 4096
+    assert '4096-row batch over 2' in line['config']['workload'] and '1024 pixel + 1024' in line['config']['workload']
+    assert line['collective']['ranks'] == 2 and line['collective']['bytes'] == 2265488 * 4 and len(line['collective']['per_rank']) == 2
+    assert line['value'] == pytest.approx(4096 / (line['ms_per_step'] * 1e-3), rel=1e-6) and line['value'] > 1e4
+    assert line['timing']['short_batches'] == 0
