@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _model(precision, binding):
-    cfg = synth.with_overrides(synth.make_configs('config3'), hip_precision=precision, hip_host_binding=binding, perturb=True,
+def _model(precision, binding, kind='config3'):
+    cfg = synth.with_overrides(synth.make_configs(kind), hip_precision=precision, hip_host_binding=binding, perturb=True,
                                raw_noise_std=1.0)
     cfg['seed'] = 11
     model = get_model(cfg, None)
@@ -38,13 +38,18 @@ def _batch(n, first=0):
 
 def _loss(out, rows=slice(None)):
     keys = ('rgb_coarse', 'rgb_fine', 'depth_ndc_fine', 'points_augmentation_rgb_coarse', 'views_augmentation_depth_ndc_coarse',
-            'points_augmentation_depth_ndc_coarse', 'views_augmentation_rgb_coarse')
-    return sum((out[k][rows] ** 2).sum() for k in keys)
+            'points_augmentation_depth_ndc_coarse', 'views_augmentation_rgb_coarse',
+            # config3f: augmentation MLPs at the fine level too -- six levels, the backward's side streams taken in turn
+            'points_augmentation_rgb_fine', 'views_augmentation_rgb_fine', 'views_augmentation_depth_ndc_fine')
+    return sum((out[k][rows] ** 2).sum() for k in keys if k in out)
 
 
-@pytest.mark.parametrize('precision,binding', [('fp32', 'torch_ext'), ('f16', 'torch_ext'), ('f16', 'ctypes')])
-def test_side_by_side_levels_equal_levels_in_order(precision, binding):
-    model = _model(precision, binding)
+@pytest.mark.parametrize('precision,binding,kind', [('fp32', 'torch_ext', 'config3'), ('f16', 'torch_ext', 'config3'),
+                                                    ('f16', 'ctypes', 'config3'), ('fp32', 'torch_ext', 'config3f'),
+                                                    ('bf16s8', 'ctypes', 'config3f')])
+def test_side_by_side_levels_equal_levels_in_order(precision, binding, kind):
+    model = _model(precision, binding, kind)
+    assert (kind == 'config3f') == hasattr(model, 'pts_aug_fine_model')
     # 2048 rays x 64 = 131 072 coarse samples: one stream; its first 512 rays alone: 32 768 samples, side by side.  The draws are
     # keyed by (iteration, global row), so the 512 rays see the same jitter and noise either way.
     big, small = _batch(2048), _batch(512)
