@@ -614,7 +614,7 @@ class HipRenderer:
 
 
 # ---------------------------------------------------------------------------------------------- config 5 (training)
-def training_step(precision, rank, world, device, single_pass=False, graphed=False, collective=False, rows_per_gpu=4096):
+def training_step(precision, rank, world, device, single_pass=False, graphed=False, collective=False, rows_per_gpu=4096, graph_scope=None):
     """BASELINE config 5: a callable running ONE iteration of the reference's training loop (Trainer.train_one_iter,
     src/Trainer01.py:60-107) with every stage on the device: batch assembly (pixel rows + as many sparse-depth rows, each rank
     a slice of one global index stream), four MLPs forward, nine losses, backward, ONE all-reduce of the flattened gradients
@@ -648,10 +648,17 @@ def training_step(precision, rank, world, device, single_pass=False, graphed=Fal
     decayer = get_lr_decayer(cfg)
     state = {'iter': 20000}
 
-    graph = None
-    if graphed:      # the WHOLE iteration -- batch assembly, draws, pass, Adam -- replayed from ONE HIP graph (GraphedIteration)
+    # --graphed.  scope 'iteration' (default for one rank): the WHOLE iteration -- batch assembly, draws, pass, all-reduce, Adam --
+    # replayed from ONE HIP graph (harness.GraphedIteration).  scope 'pass' (default for N > 1): the model pass -- re-pack, forwards,
+    # losses, backward -- from one graph (harness.GraphedTrainStep), batch assembly / gradient all-reduce / Adam enqueued around it:
+    # no collective inside a capture, so it runs on any backend and any number of ranks (a captured all-reduce has only ever run with
+    # one rank: ADVICE r4), and the host still saves the ~100 launches of the pass -- which is what bounds a small per-rank share.
+    graph, pass_graph = None, None
+    scope = (graph_scope or ('iteration' if world == 1 else 'pass')) if graphed else None
+    if scope == 'iteration':
         if world > 1:
-            raise SystemExit('the graphed training iteration is a single-GPU measurement')
+            raise SystemExit("--graph-scope iteration captures the gradient all-reduce, which has only been exercised with one rank; "
+                             "N > 1 runs --graph-scope pass")
         # (with single_pass: ONE model pass, i.e. the reference's loop with sub_batch_size = batch size -- Trainer01.py:82)
         graph = harness.GraphedIteration(model, losses, opt, batcher, decayer, sub_batch_size=None if single_pass else cfg['sub_batch_size'],
                                          force_collective=collective)
@@ -667,9 +674,17 @@ def training_step(precision, rank, world, device, single_pass=False, graphed=Fal
             group['lr'] = decayer.get_updated_learning_rate(it)
         batch = batcher.get_next_batch(it)
         step.short_batches += int(batch['rays_o'].shape[0] != 2 * rows)
+        if scope == 'pass':
+            if step.pass_graph is None:       # captured on the first (full) batch; a short batch at an epoch's end runs eagerly inside it
+                step.pass_graph = harness.GraphedTrainStep(model, losses, batch, sub_batch_size=None if single_pass else cfg['sub_batch_size'])
+            totals = step.pass_graph(batch)
+            harness.allreduce_gradients(model.parameters(), world, force=collective)
+            opt.step()
+            return totals
         return harness.train_one_iter(model, losses, opt, batch, cfg['sub_batch_size'], world, single_pass=single_pass,
                                       force_collective=collective)
 
+    step.pass_graph = pass_graph
     step.short_batches = 0
     return step, 2 * rows
 
@@ -704,7 +719,7 @@ def train_bench(args, rank, world, device, dist):
     ``--rows-per-gpu 512 --force-collective`` on one GPU is what one rank of eight then does, all-reduce included."""
     per_gpu, strong = train_rows_per_gpu(args, world)
     step, per_gpu = training_step(args.precision, rank, world, device, args.single_pass, graphed=args.graphed,
-                                  collective=dist is not None, rows_per_gpu=per_gpu)
+                                  collective=dist is not None, rows_per_gpu=per_gpu, graph_scope=args.graph_scope)
 
     def fence():
         if dist is not None:
@@ -728,7 +743,8 @@ def train_bench(args, rank, world, device, dist):
             'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': TRAIN_DTYPE[args.precision], 'data': 'synthetic',
             'config': {'workload': train_workload(per_gpu, world, strong), 'rows_per_gpu': per_gpu, 'global_rows': per_gpu * world,
-                       'single_pass': bool(args.single_pass), 'graphed': bool(args.graphed),
+                       'single_pass': bool(args.single_pass),
+                       'graphed': (args.graph_scope or ('iteration' if world == 1 else 'pass')) if args.graphed else False,
                        'parallelism': f'row-shard x{world}' + (' + 1 gradient all-reduce/step' if dist is not None else '')},
             'algorithmic_tflops': per_gpu * TRAIN_FLOP_PER_RAY * world * args.steps / elapsed / 1e12,
             'timing': step_summary(elapsed, device_ms, enqueue_ms, None)}
@@ -971,7 +987,10 @@ def main(argv=None, renderer_cls=None, backend='nccl', share_devices=False, scri
                     help='--train: ONE batch of that many rows over the N ranks (BASELINE config 5 as stated: 4096; scaling: strong)')
     ap.add_argument('--rows-per-gpu', type=int, default=None,
                     help="--train: rows of the batch per GPU (default 4096); 512 with --force-collective = one rank's share of eight")
-    ap.add_argument('--graphed', action='store_true', help='--train, N = 1: the whole iteration replayed from one HIP graph')
+    ap.add_argument('--graphed', action='store_true', help='--train: replay the iteration from a HIP graph (see --graph-scope)')
+    ap.add_argument('--graph-scope', choices=('iteration', 'pass'), default=None,
+                    help="--train --graphed: 'iteration' = batch assembly, draws, pass, all-reduce and Adam in ONE graph (default for N = 1; "
+                         "one rank only); 'pass' = the model pass in one graph, batch assembly / all-reduce / Adam around it (default for N > 1)")
     ap.add_argument('--cpu-leg', type=int, default=None, help=argparse.SUPPRESS)          # child of cpu_baseline: THREADS
     ap.add_argument('--cpu-leg-args', nargs=2, default=None, help=argparse.SUPPRESS)       # workload kind, first ray
     args = ap.parse_args(argv)

@@ -19,12 +19,12 @@ def bind(bench_module):
 
 
 def time_training(precision, device, steps, warmup, single_pass=False, board_seconds=0.0, graphed=False, rows_per_gpu=4096,
-                  collective=False):
+                  collective=False, graph_scope=None):
     """Config 5 on one GPU: (ms per iteration, ms of MLP forward launches, ms of MLP backward calls, rows, timing summary)
     from ``steps`` timed iterations after a settle phase and ``warmup`` iterations.  ``rows_per_gpu`` / ``collective``: one
     rank's share of the 4096-row batch with the gradient all-reduce in the loop (a one-rank RCCL group)."""
     _, ops, _, _ = B._pkg()
-    step, rows = B.training_step(precision, 0, 1, device, single_pass, graphed, collective, rows_per_gpu)
+    step, rows = B.training_step(precision, 0, 1, device, single_pass, graphed, collective, rows_per_gpu, graph_scope)
     B.settle(step, None, chunk=2)
     ops.profile_enable(64 * (steps + warmup))
     for _ in range(warmup):
@@ -130,7 +130,10 @@ def rank_share_record(device, steps=20, warmup=5, precisions=('f16', 'bf16s8')):
     try:
         for precision in precisions:
             entry = {}
+            # (`pass_graph`: only the model pass from a graph, batch assembly / all-reduce / Adam enqueued around it -- what
+            # `bench.py --gpus N --train --graphed` runs for N > 1, where the all-reduce is not captured)
             for name, kwargs in (('sub_batched_eager', {}), ('sub_batched_graphed', {'graphed': True}),
+                                 ('sub_batched_pass_graph', {'graphed': True, 'graph_scope': 'pass'}),
                                  ('single_pass_eager', {'single_pass': True}), ('single_pass_graphed', {'single_pass': True, 'graphed': True})):
                 full_ms, _, _, _ = time_training(precision, device, steps, warmup, collective=True, **kwargs)
                 rows_ms = {}

@@ -344,3 +344,20 @@ def test_bench_strong_scaled_training_two_ranks_with_the_real_kernels():
     assert line['collective']['ranks'] == 2 and line['collective']['bytes'] == 2265488 * 4 and len(line['collective']['per_rank']) == 2
     assert line['value'] == pytest.approx(4096 / (line['ms_per_step'] * 1e-3), rel=1e-6) and line['value'] > 1e4
     assert line['timing']['short_batches'] == 0
+
+
+def test_bench_strong_scaled_training_two_ranks_from_a_pass_graph():
+    """``--graphed`` with N > 1: the model pass of every rank replayed from one HIP graph, batch assembly, the gradient all-reduce
+    and Adam enqueued around it (`--graph-scope pass`, the default for N > 1: no collective inside a capture, so any backend and
+    any rank count) -- the host cost of a small per-rank share without the captured all-reduce that has only ever run with one
+    rank.  And `--graph-scope iteration` is refused for N > 1."""
+    line = _bench('--train', '--global-rows', '2048', '--precision', 'f16', '--graphed', '--steps', '4', '--warmup', '2')
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['config']['graphed'] == 'pass'
+    assert line['config']['rows_per_gpu'] == 1024 and line['collective']['ranks'] == 2 and line['value'] > 1e4
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, 'tests', 'bench_rehearsal.py'), '--backend', 'gloo', '--share-devices', '--',
+                        '--gpus', '2', '--train', '--global-rows', '2048', '--graphed', '--graph-scope', 'iteration', '--steps', '1',
+                        '--warmup', '0'], capture_output=True, text=True, timeout=600, env=_clean_env())
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
