@@ -23,6 +23,13 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # defined too (see that header).
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wall', '-Wno-unused-function', '-Wno-inline-asm',
          f'-I{INCLUDE}', '-include', os.path.join(CSRC, 'probe_guard.h')]
+# Files of small fp32 kernels that run BESIDE the MLP kernels when the levels of a pass go side by side (render.hip), built without the
+# SLP vectoriser: it packs neighbouring scalar fp32 operations into v_pk_*_f32 and, when a shared factor sits in the odd register
+# of a pair, selects it with op_sel:[0,1] -- the one operand selection that miscomputes beside another kernel's MFMAs on MI355X
+# (opaque_pair() in csrc/mlp_device.h; tools/probes/pk_opsel_hazard.hip).  These kernels are memory-bound: nothing to lose.
+FILE_FLAGS = {'composite': ['-fno-slp-vectorize'], 'losses': ['-fno-slp-vectorize']}
+OBJDUMP = os.environ.get('LLVM_OBJDUMP', '/opt/rocm/lib/llvm/bin/llvm-objdump')
+HAZARDOUS_PACKED_FORM = r'v_pk_\w+_f32 .*op_sel:\[0,1'     # low result <- HIGH register of the second source
 DIAGNOSTIC_PREFIXES = ('SNERF_ABL_', 'SNERF_PROBE_', 'SNERF_CLOCK_STAMP')
 # where a stray -D can come from besides ``extra_flags``: the compiler command itself and the variables hipcc / clang append
 FLAG_ENVIRONMENT = ('HIPCC', 'HIPCC_COMPILE_FLAGS_APPEND', 'HIPCC_LINK_FLAGS_APPEND', 'HIP_CLANG_FLAGS', 'CXXFLAGS', 'CPPFLAGS', 'CFLAGS',
@@ -88,7 +95,7 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
         obj = os.path.join(obj_dir, src[:-4] + '.o')
         objs.append(obj)
         if force or _stale(obj, [os.path.join(CSRC, src)] + headers):
-            jobs.append([HIPCC, *FLAGS, *extra_flags, '-c', os.path.join(CSRC, src), '-o', obj])
+            jobs.append([HIPCC, *FLAGS, *FILE_FLAGS.get(src[:-4], []), *extra_flags, '-c', os.path.join(CSRC, src), '-o', obj])
 
     def run(cmd):
         if verbose:
@@ -108,7 +115,42 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
             list(pool.map(run, jobs))
     if jobs or force or _stale(output, objs):
         run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', output])
+        found = hazardous_packed_forms(output)
+        if found and os.path.abspath(output) == os.path.abspath(LIB):
+            os.remove(output)
+            raise RuntimeError('the built library contains packed fp32 instructions with the operand selection that miscomputes beside '
+                               'MFMA kernels on MI355X (see opaque_pair() in csrc/mlp_device.h):\n'
+                               + '\n'.join(f'  {kernel}: {text}' for kernel, text in found[:20]))
     return output
+
+
+def hazardous_packed_forms(library: str):
+    """[(kernel, instruction)] for every packed fp32 instruction in ``library``'s gfx950 code objects whose low result reads the high
+    register of its second source (HAZARDOUS_PACKED_FORM).  Needs llvm-objdump; ~6 s for the shipped library."""
+    import glob
+    import re
+    import shutil
+    import tempfile
+    if not os.path.exists(OBJDUMP):
+        raise RuntimeError(f'{OBJDUMP} not found (set LLVM_OBJDUMP): the built library cannot be checked')
+    pattern = re.compile(HAZARDOUS_PACKED_FORM)
+    found = []
+    with tempfile.TemporaryDirectory() as tmp:
+        copy = os.path.join(tmp, 'library.so')       # (llvm-objdump --offloading writes the code objects beside its input)
+        shutil.copy(library, copy)
+        subprocess.run([OBJDUMP, '--offloading', copy], capture_output=True, cwd=tmp, check=True)
+        objects = sorted(glob.glob(copy + '.*gfx950'))
+        if not objects:
+            raise RuntimeError(f'no gfx950 code object found in {library}')
+        for obj in objects:
+            text = subprocess.run([OBJDUMP, '-d', '--no-show-raw-insn', obj], capture_output=True, text=True, check=True).stdout
+            kernel = '?'
+            for line in text.splitlines():
+                if line.endswith('>:'):
+                    kernel = line.split('<', 1)[1][:-2]
+                elif pattern.search(line):
+                    found.append((kernel, ' '.join(line.split())))
+    return found
 
 
 TORCH_EXT_DIR = os.path.join(HERE, 'csrc_torch')

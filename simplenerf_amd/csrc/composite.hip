@@ -157,6 +157,9 @@ __global__ void __launch_bounds__(256) composite_backward_kernel(CompositeBwdArg
             const float u = (1.0f - alpha[c]) + 1e-10f;
             const float dalpha = g[c] * T[c] - __fdiv_rn(after, u);
             a.d_sigma[ray * s + j] = dalpha * (delta[c] * (1.0f - alpha[c]));
+            // (the file is compiled without the SLP vectoriser -- build.py FILE_FLAGS: packed into v_pk_mul_f32, these products
+            // took the operand selection described at opaque_pair(), mlp_device.h, and once in ~10^5 times sixteen lanes of
+            // d rgb came out 0.0 when this kernel ran beside another level's MLP backward)
             a.d_rgb[(ray * s + j) * 3 + 0] = w[c] * gr;
             a.d_rgb[(ray * s + j) * 3 + 1] = w[c] * gg;
             a.d_rgb[(ray * s + j) * 3 + 2] = w[c] * gb;

@@ -296,23 +296,46 @@ __device__ __forceinline__ float sigmoidf(float x) { return __fdiv_rn(1.0f, 1.0f
 // ------------------------------------------------------------------------------------------------
 // positional encoding
 // ------------------------------------------------------------------------------------------------
+// Two copies of `v` in one register pair that the compiler has to treat as two unrelated values.
+// Why: a packed fp32 instruction whose LOW result reads the HIGH register of its second source (`op_sel:[0,1]` on v_pk_mul_f32 /
+// v_pk_add_f32, `op_sel:[0,1,0]` on v_pk_fma_f32 -- how the compiler broadcasts a scalar that happens to live in the odd register
+// of a pair) returns a wrong low half for a quarter wave about once in 10^4..10^5 executions on MI355X WHILE waves of another
+// kernel issue MFMAs on the same SIMD; never when the kernel runs alone, and no other operand selection does it
+// (tools/probes/pk_opsel_hazard.hip, profiles/r05_pk_opsel_hazard.txt).  Found as parameter gradients that differed in the last
+// bits between repetitions once the levels of a small pass ran side by side (render.hip).  With the scalar spelled as an opaque
+// pair the packed instruction reads lo from lo and hi from hi -- no operand selection at all.  simplenerf_amd/build.py scans
+// the built library for the form and refuses it.
+__device__ __forceinline__ f32x2 opaque_pair(float v) {
+    f32x2 p = {v, v};
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
 // sin and cos of 2*pi*turns.  The frequencies are exact powers of two, so `turns` = x * 2^k / (2 pi) is formed once
 // per coordinate in fp64 and the reduction to [-1/8, 1/8] turns is exact; only the final polynomial is fp32.
+// PAIRED: the sine and the cosine polynomial each read their own copy of th^2 (opaque_pair): where the compiler packs the two
+// polynomials' steps into v_pk_fma_f32 it then needs no broadcast of th^2 (mlp_forward_m16.hip: the packing halves the
+// encoding's VALU count, and 30 of its 60 packed steps had taken the form described above).  Same arithmetic either way.
+template <bool PAIRED = false>
 __device__ __forceinline__ void sincos_turns(double turns, float& s, float& c) {
     const double f = turns - rint(turns);   // [-1/2, 1/2]
     const double q = rint(4.0 * f);         // quadrant, -2 .. 2
     const double g = f - 0.25 * q;          // [-1/8, 1/8]
     const float th = (float)(g * 6.283185307179586476925);
-    const float t2 = th * th;
+    float t2 = th * th, t2c = t2;
+    if constexpr (PAIRED) {
+        const f32x2 both = opaque_pair(t2);
+        t2 = both.x; t2c = both.y;
+    }
     float sp = fmaf(t2, 2.7557319e-6f, -1.9841270e-4f);
     sp = fmaf(sp, t2, 8.3333333e-3f);
     sp = fmaf(sp, t2, -1.6666667e-1f);
     sp = fmaf(th * t2, sp, th);
-    float cp = fmaf(t2, -2.7557319e-7f, 2.4801587e-5f);
-    cp = fmaf(cp, t2, -1.3888889e-3f);
-    cp = fmaf(cp, t2, 4.1666667e-2f);
-    cp = fmaf(cp, t2, -0.5f);
-    cp = fmaf(cp, t2, 1.0f);
+    float cp = fmaf(t2c, -2.7557319e-7f, 2.4801587e-5f);
+    cp = fmaf(cp, t2c, -1.3888889e-3f);
+    cp = fmaf(cp, t2c, 4.1666667e-2f);
+    cp = fmaf(cp, t2c, -0.5f);
+    cp = fmaf(cp, t2c, 1.0f);
     const int qi = ((int)q) & 3;
     const float s0 = (qi & 1) ? cp : sp;
     const float c0 = (qi & 1) ? sp : cp;
@@ -321,7 +344,7 @@ __device__ __forceinline__ void sincos_turns(double turns, float& s, float& c) {
 }
 
 // Fill the PE operand registers of this lane half (layout: mlp_layout.h pe_feature()).
-template <int PAIRS, int NREG>
+template <int PAIRS, int NREG, bool PAIRED = false>
 __device__ __forceinline__ void encode(const float (&x)[3], int half, float (&pe)[NREG]) {
     constexpr double kInvTwoPi = 0.15915494309189533576888;
     const double r0 = (double)x[0] * kInvTwoPi, r1 = (double)x[1] * kInvTwoPi, r2 = (double)x[2] * kInvTwoPi;
@@ -335,7 +358,7 @@ __device__ __forceinline__ void encode(const float (&x)[3], int half, float (&pe
         const double a1 = d1 == 0 ? r0 : (d1 == 1 ? r1 : r2);
         const double f0 = (double)(1 << (c0 / 3)), f1 = (double)(1 << (c1 / 3));
         const double turns = half ? a1 * f1 : a0 * f0;
-        sincos_turns(turns, pe[2 * m], pe[2 * m + 1]);
+        sincos_turns<PAIRED>(turns, pe[2 * m], pe[2 * m + 1]);
     }
     pe[PAIRS] = half ? x[2] : x[0];
     pe[PAIRS + 1] = half ? 0.0f : x[1];

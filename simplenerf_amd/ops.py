@@ -238,10 +238,15 @@ class PackedMlp:
         _lib.check(st, 'snerf_mlp_forward_train')
         return sigma, rgb, saved
 
+    def backward_workspace_floats(self, n: int, s: int) -> int:
+        return int(_lib.load().snerf_mlp_backward_workspace_floats(ctypes.byref(self.desc), n, s))
+
     def backward(self, saved: Tensor, sigma: Tensor, rgb: Tensor, d_sigma: Tensor, d_rgb: Tensor,
-                 param_shapes: List[tuple], precision: int = 0, into: Optional[List[Tensor]] = None) -> List[Tensor]:
+                 param_shapes: List[tuple], precision: int = 0, into: Optional[List[Tensor]] = None,
+                 work: Optional[Tensor] = None) -> List[Tensor]:
         """dL/dparam for every parameter (C-ABI order), given dL/dsigma (n,S[,1]) and dL/drgb (n,S,3).  ``into``: existing
-        gradient tensors to ADD to (the kernel accumulates; no separate add launches) instead of fresh ones."""
+        gradient tensors to ADD to (the kernel accumulates; no separate add launches) instead of fresh ones.  ``work``: the
+        caller's scratch (at least ``backward_workspace_floats(n, s)`` floats) instead of a fresh allocation."""
         lib = _lib.load()
         n, s = sigma.shape[0], sigma.shape[1]
         dev = sigma.device
@@ -258,8 +263,11 @@ class PackedMlp:
                 if tuple(g.shape) != tuple(shape) or g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous():
                     raise RuntimeError(f'backward(into=...): expected a contiguous float32 GPU tensor of shape {tuple(shape)}')
         grads = into if into is not None else [torch.empty(tuple(shape), dtype=torch.float32, device=dev) for shape in param_shapes]
-        work = torch.empty(lib.snerf_mlp_backward_workspace_floats(ctypes.byref(self.desc), n, s), dtype=torch.float32,
-                           device=dev)
+        need = self.backward_workspace_floats(n, s)
+        if work is None:
+            work = torch.empty(need, dtype=torch.float32, device=dev)
+        elif work.dtype != torch.float32 or not work.is_cuda or not work.is_contiguous() or work.numel() < need:
+            raise RuntimeError(f'backward(work=...): expected a contiguous float32 GPU tensor of at least {need} floats')
         arr = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
         with torch.cuda.device(dev):
             st = lib.snerf_mlp_backward(ctypes.byref(self.desc), _ptr(self.buffer), _ptr(saved), _ptr(sigma), _ptr(rgb),

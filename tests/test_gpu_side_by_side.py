@@ -68,10 +68,12 @@ def test_side_by_side_levels_equal_levels_in_order(precision, binding, kind):
         for (name, p), ref in zip(model.named_parameters(), grads_big):
             scale = float(ref.abs().max()) + 1e-30
             assert float((p.grad - ref).abs().max()) <= 2e-5 * scale, name
-    # (ii) the same small pass again, several times: bit-identical outputs and gradients
+    # (ii) the same small pass again, many times: bit-identical outputs and gradients.  (Thirty: with five, one pass in five of the
+    # six-level 16-bit model differed in the last bits and the test passed two times in three -- the compositing backward's packed
+    # multiply beside another level's MFMAs, see opaque_pair() in csrc/mlp_device.h; each repetition is a few milliseconds.)
     ref_out = {k: v.clone() for k, v in out_small.items()}
     ref_grads = [p.grad.clone() for p in model.parameters()]
-    for _ in range(5):
+    for _ in range(30):
         again = model(small)
         model.zero_grad(set_to_none=True)
         _loss(again).backward()

@@ -504,3 +504,36 @@ def test_every_diagnostic_switch_is_guarded():
     for extra in ([], ['-DSNERF_PROBE_HALF_X', '-DSNERF_PROBE_BUILD']):
         ok = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=300)
         assert ok.returncode == 0, ok.stderr[-2000:]
+
+
+def test_no_packed_fp32_instruction_reads_the_high_register_into_the_low_result(tmp_path):
+    """Round 5: ``v_pk_{mul,add,fma}_f32`` with ``op_sel:[0,1...]`` -- the low result reading the HIGH register of the second
+    source -- returns wrong low halves beside another kernel's MFMAs on MI355X (tools/probes/pk_opsel_hazard.hip,
+    profiles/r05_pk_opsel_hazard.txt; found as gradients that differed between repetitions once levels ran side by side).
+    (i) the shipped library holds no such instruction (build.py checks the same after every link and refuses the library);
+    (ii) the scan itself finds the form in a kernel written to contain it."""
+    import subprocess
+    from simplenerf_amd import build
+    assert os.path.exists(build.OBJDUMP), build.OBJDUMP
+    found = build.hazardous_packed_forms(build.LIB)
+    assert not found, found[:10]
+    assert build.FILE_FLAGS['composite'] == ['-fno-slp-vectorize'] and build.FILE_FLAGS['losses'] == ['-fno-slp-vectorize']
+    source = tmp_path / 'form.hip'
+    source.write_text('#include <hip/hip_runtime.h>\n'
+                      'typedef float f32x2 __attribute__((ext_vector_type(2)));\n'
+                      '__global__ void has_the_form(f32x2* p) {\n'
+                      '    f32x2 a = p[threadIdx.x], b = p[threadIdx.x + 64], d;\n'
+                      '    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(a), "v"(b));\n'
+                      '    p[threadIdx.x] = d;\n'
+                      '}\n'
+                      '__global__ void has_a_safe_form(f32x2* p) {\n'
+                      '    f32x2 a = p[threadIdx.x], b = p[threadIdx.x + 64], d;\n'
+                      '    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(a), "v"(b));\n'
+                      '    p[threadIdx.x] = d;\n'
+                      '}\n')
+    lib = tmp_path / 'form.so'
+    done = subprocess.run([build.HIPCC, '--offload-arch=gfx950', '-O3', '-shared', '-fPIC', str(source), '-o', str(lib)],
+                          capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    seen = build.hazardous_packed_forms(str(lib))
+    assert len(seen) == 1 and 'has_the_form' in seen[0][0] and 'op_sel:[0,1]' in seen[0][1], seen
