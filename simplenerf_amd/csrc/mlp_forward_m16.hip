@@ -239,8 +239,13 @@ __global__ void __launch_bounds__(P == 1 ? 512 : 256, P == 1 ? 2 : 1) mlp_forwar
 #pragma unroll
         for (int k = 0; k < 3; ++k) v[k] = a.view_dirs[ray * 3 + k];
         float pe[snerf::kPointsKSteps], pev[snerf::kViewsKSteps];
-        encode<snerf::kPointsPairs, snerf::kPointsKSteps, true>(x, half, pe);      // (true: see opaque_pair, mlp_device.h)
-        encode<snerf::kViewsPairs, snerf::kViewsKSteps, true>(v, half, pev);
+#ifdef SNERF_PROBE_M16_UNPAIRED     // A/B build: the encoding as before the opaque pair (contains the hazardous packed form)
+        constexpr bool kPaired = false;
+#else
+        constexpr bool kPaired = true;     // (see opaque_pair, mlp_device.h)
+#endif
+        encode<snerf::kPointsPairs, snerf::kPointsKSteps, kPaired>(x, half, pe);
+        encode<snerf::kViewsPairs, snerf::kViewsKSteps, kPaired>(v, half, pev);
         // register 8ks + j of lane half h = position p = 16 (ks & 1) + 8h + j of k-block ks / 2 -> lane group (p & 15) / 4,
         // slot (p < 16 ? 0 : 4) + p % 4 of the fragment of sample half i32 / 16
         // (the ring slots from the third on are idle until the hand-over is done: P = 3: the third slot (44 KiB for 4 waves x 6 KiB);
