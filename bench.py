@@ -973,7 +973,7 @@ def main(argv=None, renderer_cls=None, backend='nccl', share_devices=False, scri
                          'one-GPU box')
     ap.add_argument('--precision', choices=('fp32', 'f16x3', 'f16', 'bf16', 'f16s8', 'bf16s8'), default='fp32',
                     help="arithmetic of the fused MLP kernel: fp32 MFMA; fp16 hi/lo split with 3 MFMAs per product "
-                         "(fp32-grade results, same parity tests); or f16 = one fp16 MFMA per product with 16-bit saved "
+                         "(fp32-grade results: same rendering parity tests, looser class for training gradients); or f16 = one fp16 MFMA per product with 16-bit saved "
                          "tensors (BASELINE config 5's 16-bit training mode, own tolerances: tests/test_gpu_f16.py)")
     ap.add_argument('--extras', action='store_true',
                     help='N = 1: also run the long secondary set (sustained run with board power / clock, the other precisions with '

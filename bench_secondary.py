@@ -58,7 +58,7 @@ def time_training(precision, device, steps, warmup, single_pass=False, board_sec
 
 def training_record(device, steps=10, warmup=3):
     """The ``also_measured_train`` object of the default bench line: config 5 at 4096 rows on this GPU in the fp32 mode
-    (the reference's arithmetic), the fp16-split mode (same parity tests) and the 16-bit mode BASELINE config 5 names, each
+    (the reference's arithmetic), the fp16-split mode (same rendering parity tests; its gradients are a looser tolerance class) and the 16-bit mode BASELINE config 5 names, each
     against its own MFMA ceiling."""
     dominant = {'fp32': 'wgrad_kernel<2,8,false> (weight gradients); forward mlp_forward_kernel<8,4,true,false,true>',
                 'f16x3': 'wgrad_kernel<2,8,true> (weight gradients); chain mlp_backward_chain_f16x3_kernel<8,4,true,3,8>',
