@@ -1136,6 +1136,16 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
     //    (128 chunks x 8 trunk layers was 256 MB per backward call; now 64 MB).
     //  * Small products (heads, encodings) are DMA-latency-bound with tiny epilogues: as many workgroups as there are
     //    8-block pieces, up to 512, so that every CU holds two of them.
+    // Workgroups of the large class as a whole: one per CU, but not fewer than 16 blocks each (round 5, VERDICT r4 #3 "workgroup
+    // counts scaled with rows").  Every workgroup ends with a 256 KB partial that is written once and read back by the reduction
+    // whatever it contracted over: one rank's share of a strong-scaled batch (256-512 rows x 64 samples = 512-1024 blocks) paid the
+    // full 64 MiB + reduction per level for 1/8 of the operands, and its levels run side by side (render.hip), so the CUs a level
+    // leaves are not idle.  SNERF_LARGE_MIN_BLOCKS for A/B builds (0 = the fixed 256 of rounds 3-4).
+#ifndef SNERF_LARGE_MIN_BLOCKS
+#define SNERF_LARGE_MIN_BLOCKS 16
+#endif
+    const long long large_budget = SNERF_LARGE_MIN_BLOCKS > 0
+        ? std::min<long long>(256, std::max<long long>(64, blocks / SNERF_LARGE_MIN_BLOCKS)) : 256;
     for (WgradJob& j : w.jobs) {
         int no, ni;
         wave_tile(j, &no, &ni);
@@ -1153,7 +1163,7 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
                 wave_tile(k, &ko, &ki);
                 if (ko == no && ki == ni && k.out_tiles * k.in_tiles >= 32 && k.launched) peers_weight += weight(k);
             }
-            chunks = 256 * weight(j) / peers_weight;   // rounded DOWN: 7 jobs x 37 chunks = 259 workgroups ran as 256 + a second round of 3
+            chunks = large_budget * weight(j) / peers_weight;   // rounded DOWN: 7 jobs x 37 chunks = 259 workgroups ran as 256 + a second round of 3
             // (a lone job of fewer than 64 tile products -- the views layer's 4 x 9 -- ends every workgroup with a 144 KB
             // partial: at least SNERF_MID_BLOCKS blocks of operands per workgroup; config 5: 128 instead of 256 workgroups
             // for a 64-samples-per-ray pass is worth 0.04 ms per iteration, 64 costs 0.25)
@@ -1183,7 +1193,7 @@ Workspace plan_workspace(const snerf::MlpPlan& p, long long total_samples, bool 
             wave_tile(j, &no, &ni);
             if (no == 2 && ni == 8 && j.launched && j.out_tiles * j.in_tiles >= 32) { used += j.chunks; ++members; }
         }
-        for (int spare = 256 - used; members > 1 && spare > 0;) {
+        for (int spare = (int)large_budget - used; members > 1 && spare > 0;) {
             bool given = false;
             for (int light = 1; light >= 0 && spare > 0; --light)
                 for (WgradJob& j : w.jobs) {
