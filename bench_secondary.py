@@ -135,13 +135,26 @@ def rank_share_record(device, steps=20, warmup=5, precisions=('f16', 'bf16s8')):
             for name, kwargs in (('sub_batched_eager', {}), ('sub_batched_graphed', {'graphed': True}),
                                  ('sub_batched_pass_graph', {'graphed': True, 'graph_scope': 'pass'}),
                                  ('single_pass_eager', {'single_pass': True}), ('single_pass_graphed', {'single_pass': True, 'graphed': True})):
-                full_ms, _, _, _ = time_training(precision, device, steps, warmup, collective=True, **kwargs)
+                def leg(**more):
+                    # (a leg whose slowest step took three times its median -- a host stall on a shared box: one 4096-row leg of
+                    # the round's last record read 9.3 ms where every other run reads 7.7-8.0 -- is timed once more and says so)
+                    ms, _, _, _ = time_training(precision, device, steps, warmup, collective=True, **kwargs, **more)
+                    spread = time_training.timing['step_ms']
+                    again = spread['max'] > 3.0 * spread['p50']
+                    if again:
+                        ms, _, _, _ = time_training(precision, device, steps, warmup, collective=True, **kwargs, **more)
+                    return ms, again
+                full_ms, full_again = leg()
                 rows_ms = {}
                 for rows in (1024, 512):
-                    ms, _, _, _ = time_training(precision, device, steps, warmup, rows_per_gpu=rows, collective=True, **kwargs)
+                    ms, again = leg(rows_per_gpu=rows)
                     rows_ms[str(rows)] = {'ms_per_step': ms, 'ranks': 4096 // rows, 'overhead': ms / (full_ms * rows / 4096),
                                           'job_rays_per_s_if_all_ranks_ran_at_this_rate': 4096 / (ms * 1e-3)}
+                    if again:
+                        rows_ms[str(rows)]['timed_again'] = True
                 entry[name] = {'ms_per_step_4096_rows': full_ms, 'rows': rows_ms}
+                if full_again:
+                    entry[name]['timed_again'] = True
             out['modes'][precision] = entry
     finally:
         dist.destroy_process_group()
