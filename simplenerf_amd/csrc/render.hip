@@ -229,9 +229,6 @@ extern "C" int snerf_render_forward(const snerf_render_config* cfg, const snerf_
     if (rc != SNERF_OK) return rc;
     // the coarse augmentation levels beside {main coarse -> fine} when the call is small (see side_by_side)
     SideStreams* side = side_by_side(cfg, mlps, n) && (mlps[1].desc || mlps[2].desc) ? side_streams((hipStream_t)stream) : nullptr;
-#ifdef SNERF_PROBE_SIDE_BWD_ONLY
-    side = nullptr;
-#endif
     int forked = 0;
     // (from the fork on every return joins the side streams first)
     auto done = [&](int status) { return side ? (join_streams(side, (hipStream_t)stream, forked) == SNERF_OK ? status : (status != SNERF_OK ? status : SNERF_E_HIP)) : status; };
@@ -327,9 +324,6 @@ extern "C" int snerf_render_backward(const snerf_render_config* cfg, const snerf
     int levels = 0;
     for (int l = 0; l < SNERF_RENDER_LEVELS; ++l) levels += wanted(l) ? 1 : 0;
     SideStreams* side = side_by_side(cfg, mlps, n) && levels > 1 ? side_streams((hipStream_t)stream) : nullptr;
-#ifdef SNERF_PROBE_SIDE_FWD_ONLY
-    side = nullptr;
-#endif
     if (!side) {
         float* d_sigma = workspace;
         float* d_rgb = workspace + samples_max;
@@ -363,60 +357,6 @@ extern "C" int snerf_render_backward(const snerf_render_config* cfg, const snerf
     // the kept (heaviest) level is enqueued first -- enqueued last, its kernels queued behind everybody else's and the call ended
     // with it -- then the others, each on its side stream
     int used = 0;
-#ifdef SNERF_PROBE_SIDE_MODES     // bisecting builds (tools/probes/side_by_side_determinism.py): which part of a level may run beside the others
-    {
-        const char* env = getenv("SNERF_SIDE_MODE");
-        const int mode = env ? atoi(env) : 0;
-        auto composite_part = [&](int l, snerf_stream_t s_l) -> int {
-            const snerf_render_level_grads& g = grads[l];
-            const int s = l < 3 ? cfg->num_coarse : cfg->num_coarse + cfg->num_fine;
-            const float* depths = l < 3 ? out->depths_coarse : (rays->depths_fine ? rays->depths_fine : out->depths_fine);
-            const snerf_render_level_out& o = out->level[l];
-            return snerf_composite_backward(o.sigma, o.raw_rgb, depths, march_d, cfg->ndc ? rays->rays_o : nullptr,
-                                            cfg->ndc ? rays->rays_d : nullptr, n, s, cfg->ndc, cfg->white_bkgd, g.rgb, g.acc, g.depth,
-                                            g.depth_ndc, d_sigma_of[l], d_sigma_of[l] + samples_of[l], s_l);
-        };
-        auto mlp_part = [&](int l, snerf_stream_t s_l) -> int {
-            const snerf_render_level_grads& g = grads[l];
-            const int s = l < 3 ? cfg->num_coarse : cfg->num_coarse + cfg->num_fine;
-            const snerf_render_level_out& o = out->level[l];
-            return snerf_mlp_backward(mlps[l].desc, mlps[l].packed, o.saved_acts, o.sigma, o.raw_rgb, d_sigma_of[l],
-                                      d_sigma_of[l] + samples_of[l], n, s, d_sigma_of[l] + 4 * samples_of[l], g.param_grads,
-                                      g.num_params, cfg->precision, g.accumulate, s_l);
-        };
-        auto side_of = [&](int) { return (snerf_stream_t)side->stream[used++ % forked]; };
-        if (mode == 3 || mode == 4) {
-            // 3: compositing backward of every level on the caller's stream BEFORE the fork, the MLP backwards side by side
-            // 4: compositing backwards side by side, joined, the MLP backwards in order on the caller's stream
-            if (mode == 3) {
-                for (int l = 0; l < SNERF_RENDER_LEVELS && rc == SNERF_OK; ++l) if (wanted(l)) rc = composite_part(l, stream);
-                if (rc == SNERF_OK) rc = fork_streams(side, (hipStream_t)stream, forked);
-                if (rc == SNERF_OK) rc = mlp_part(keep, stream);
-                for (int l = 0; l < SNERF_RENDER_LEVELS && rc == SNERF_OK; ++l) if (wanted(l) && l != keep) rc = mlp_part(l, side_of(l));
-                const int joined = join_streams(side, (hipStream_t)stream, forked);
-                return rc != SNERF_OK ? rc : joined;
-            }
-            rc = composite_part(keep, stream);
-            for (int l = 0; l < SNERF_RENDER_LEVELS && rc == SNERF_OK; ++l) if (wanted(l) && l != keep) rc = composite_part(l, side_of(l));
-            const int joined = join_streams(side, (hipStream_t)stream, forked);
-            for (int l = 0; l < SNERF_RENDER_LEVELS && rc == SNERF_OK; ++l) if (wanted(l)) rc = mlp_part(l, stream);
-            return rc != SNERF_OK ? rc : joined;
-        }
-        if (mode == 1 || mode == 2) {
-            // 1: the fine augmentation levels on the caller's stream after the kept level, the coarse levels on side streams
-            // 2: the coarse levels on the caller's stream after the kept level, the fine augmentation levels on side streams
-            rc = level_backward(keep, d_sigma_of[keep], d_sigma_of[keep] + samples_of[keep], d_sigma_of[keep] + 4 * samples_of[keep], stream);
-            for (int l = 0; l < SNERF_RENDER_LEVELS && rc == SNERF_OK; ++l) {
-                if (!wanted(l) || l == keep) continue;
-                const bool on_main = mode == 1 ? l > 3 : l < 3;
-                rc = level_backward(l, d_sigma_of[l], d_sigma_of[l] + samples_of[l], d_sigma_of[l] + 4 * samples_of[l],
-                                    on_main ? stream : side_of(l));
-            }
-            const int joined = join_streams(side, (hipStream_t)stream, forked);
-            return rc != SNERF_OK ? rc : joined;
-        }
-    }
-#endif
     rc = level_backward(keep, d_sigma_of[keep], d_sigma_of[keep] + samples_of[keep], d_sigma_of[keep] + 4 * samples_of[keep], stream);
     for (int l = 0; l < SNERF_RENDER_LEVELS && rc == SNERF_OK; ++l) {
         if (!wanted(l) || l == keep) continue;
