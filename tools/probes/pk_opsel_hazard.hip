@@ -565,6 +565,67 @@ MOV_VICTIM(mov_10, "op_sel:[1,0]", a.y, b.x)
 MOV_VICTIM(mov_01, "op_sel:[0,1]", a.x, b.y)
 MOV_VICTIM(mov_11, "op_sel:[1,1]", a.y, b.y)
 
+
+// The other instructions of the library that select a register half: the SDWA half-word read of the fp16 -> fp32 conversions
+// (6 287 sites), and the fp8 conversions of the s8 modes (word select on the source resp. the destination).
+__global__ void __launch_bounds__(256) cvt_sdwa_word1(unsigned long long* bad, float* sink, int iters) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned src = 0x3c003800u + 0x00010001u * (unsigned)(t & 1023);     // two fp16 values near 1 and 0.5
+    unsigned long long mine = 0;
+    float keep = 0.0f;
+    for (int i = 0; i < iters; ++i) {
+        float got, want;
+        unsigned hi;
+        asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(got) : "v"(src));
+        asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(hi) : "v"(src));
+        asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(want) : "v"(hi));
+        mine += __float_as_uint(got) != __float_as_uint(want);
+        keep += got;
+        src += 0x00010001u;
+        asm volatile("" : "+v"(src));
+    }
+    if (mine) atomicAdd(bad, mine);
+    if (keep == 123.456f) sink[t] = keep;
+}
+__global__ void __launch_bounds__(256) cvt_f16_fp8_word1(unsigned long long* bad, float* sink, int iters) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned src = 0x38304048u + 0x01010101u * (unsigned)(t & 7);        // four e4m3 values
+    const float scale = 1.0f;
+    unsigned long long mine = 0;
+    unsigned keep = 0;
+    for (int i = 0; i < iters; ++i) {
+        unsigned got, want, hi;
+        asm volatile("v_cvt_scalef32_pk_f16_fp8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(got) : "v"(src), "v"(scale));
+        asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(hi) : "v"(src));
+        asm volatile("v_cvt_scalef32_pk_f16_fp8 %0, %1, %2" : "=v"(want) : "v"(hi), "v"(scale));
+        mine += got != want;
+        keep ^= got;
+        src = (src + 0x01010101u) & 0x7f7f7f7fu;
+        asm volatile("" : "+v"(src));
+    }
+    if (mine) atomicAdd(bad, mine);
+    if (keep == 0x12345678u) sink[t] = 1.0f;
+}
+__global__ void __launch_bounds__(256) cvt_fp8_f16_word1(unsigned long long* bad, float* sink, int iters) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned src = 0x3c003800u + 0x00010001u * (unsigned)(t & 1023);     // two fp16 values
+    const float scale = 1.0f;
+    unsigned long long mine = 0;
+    unsigned keep = 0;
+    for (int i = 0; i < iters; ++i) {
+        unsigned got = 0x0000beefu, low = 0;
+        asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(got) : "v"(src), "v"(scale));
+        asm volatile("v_cvt_scalef32_pk_fp8_f16 %0, %1, %2" : "+v"(low) : "v"(src), "v"(scale));
+        const unsigned want = 0x0000beefu | (low << 16);
+        mine += got != want;
+        keep ^= got;
+        src += 0x00010001u;
+        asm volatile("" : "+v"(src));
+    }
+    if (mine) atomicAdd(bad, mine);
+    if (keep == 0x12345678u) sink[t] = 1.0f;
+}
+
 struct Form { void (*kernel)(unsigned long long*, float*, int); const char* name; };
 static const Form kForms[] = {
     {victim_0, "v_pk_mul_f32 "},
@@ -593,6 +654,9 @@ static const Form kForms[] = {
     {mov_10, "v_pk_mov_b32 op_sel:[1,0]"},
     {mov_01, "v_pk_mov_b32 op_sel:[0,1]"},
     {mov_11, "v_pk_mov_b32 op_sel:[1,1]"},
+    {cvt_sdwa_word1, "v_cvt_f32_f16_sdwa src0_sel:WORD_1"},
+    {cvt_f16_fp8_word1, "v_cvt_scalef32_pk_f16_fp8 op_sel:[1,0,0]"},
+    {cvt_fp8_f16_word1, "v_cvt_scalef32_pk_fp8_f16 op_sel:[0,0,1]"},
 };
 
 int main() {
