@@ -57,7 +57,19 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
     __shared__ float As[2][kBK][BM + kPad];
     __shared__ float Bs[2][kBK][BN + kPad];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // tile of this workgroup.  Workgroups go to the eight XCDs in turn (linear id mod 8) and every XCD has its own L2: with the
+    // plain (x = n tile, y = m tile) order the n tiles of one row block -- which all read the same rows of A -- land on different
+    // XCDs and A comes from HBM once per n tile (4 x at width 512).  When the m tiles divide by eight, XCD x takes the row blocks
+    // congruent to x and walks their n tiles one after the other: A's rows are fetched once and hit in that XCD's L2 afterwards.
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+#ifndef SNERF_PROBE_GEMM_PLAIN_ORDER
+    if ((gridDim.y & 7u) == 0) {
+        const unsigned linear = blockIdx.y * gridDim.x + blockIdx.x, xcd = linear & 7u, idx = linear >> 3;
+        tile_m = (int)((idx / gridDim.x) * 8u + xcd);
+        tile_n = (int)(idx % gridDim.x);
+    }
+#endif
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const long long k_lo = g.split_stride ? (long long)blockIdx.z * g.k_chunk : 0;
     const long long k_hi = g.split_stride ? (k_lo + g.k_chunk < g.K ? k_lo + g.k_chunk : g.K) : g.K;
     float* C = g.C + (g.split_stride ? (long long)blockIdx.z * g.split_stride : 0);
@@ -92,6 +104,10 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
         // WHEN IT IS STORED, after this stage's MFMAs (a predicated load per element compiles to one exec-masked basic block per
         // load, and a select right here makes the MFMAs wait for the loads they are meant to hide)
         a_inside = b_inside = 0;
+#ifdef SNERF_PROBE_GEMM_NOLOAD       // timing ablation (wrong results): nothing fetched from memory
+        (void)a_stage; (void)b_stage; (void)k_left;
+        return;
+#endif
 #pragma unroll
         for (int e = 0; e < LA; ++e) {
             const bool inside = a_m + e * a_dm < m_left && a_k + e * a_dk < k_left;
@@ -109,6 +125,9 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
     float* const bs0 = &Bs[0][b_k][b_n];
     const int as_step = a_dk * (BM + kPad) + a_dm, bs_step = b_dk * (BN + kPad) + b_dn;
     auto store_stage = [&](int buf) {
+#ifdef SNERF_PROBE_GEMM_NOSTORE      // timing ablation (wrong results): nothing staged into LDS
+        return;
+#endif
 #pragma unroll
         for (int e = 0; e < LA; ++e) as0[buf * (kBK * (BM + kPad)) + e * as_step] = (a_inside >> e) & 1u ? ra[e] : 0.0f;
 #pragma unroll
@@ -134,17 +153,34 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
             if (more) load_stage(k0 + kBK);                     // in flight during this stage's MFMAs
             const float* a_rd = &As[buf][h][wm + i];
             const float* b_rd = &Bs[buf][h][wn + i];
+            // the operands of k-pair p + 1 are requested BEFORE the MFMAs of pair p are issued (two register sets; the scheduling
+            // barrier keeps the compiler from sinking the reads back to their use): left alone it emitted read, wait, four MFMAs,
+            // read, wait ... with one register set, and the matrix pipe sat idle for an LDS round trip per pair -- 0.54 busy (PMC,
+            // profiles/r05_pmc_layered_gemm.json), 0.50 of the peak
+            float av[2][TM], bv[2][TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) av[0][tm] = a_rd[32 * tm];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bv[0][tn] = b_rd[32 * tn];
 #pragma unroll
             for (int p = 0; p < kBK / 2; ++p) {
-                float av[TM], bv[TN];
+                if (p + 1 < kBK / 2) {
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) av[tm] = a_rd[2 * p * (BM + kPad) + 32 * tm];
+                    for (int tm = 0; tm < TM; ++tm) av[(p + 1) & 1][tm] = a_rd[2 * (p + 1) * (BM + kPad) + 32 * tm];
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bv[tn] = b_rd[2 * p * (BN + kPad) + 32 * tn];
+                    for (int tn = 0; tn < TN; ++tn) bv[(p + 1) & 1][tn] = b_rd[2 * (p + 1) * (BN + kPad) + 32 * tn];
+                }
+#ifndef SNERF_PROBE_GEMM_NO_PREFETCH
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][tm], bv[p & 1][tn], acc[tm][tn], 0, 0, 0);
+#ifndef SNERF_PROBE_GEMM_NO_PREFETCH
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             if (more) {
                 store_stage(buf ^ 1);
@@ -198,6 +234,41 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ d
     sh[part][threadIdx.x & 63] = s;
     __syncthreads();
     if (part == 0 && col < cols) partial[(long long)blockIdx.y * cols + col] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+
+// The same sums for rows of whole 16-byte groups (ld and cols multiples of 4, dz 16-byte aligned: every Linear layer but the
+// heads).  Round 5: the scalar kernel above kept ONE 256-byte load per wave in flight -- 614 us per call at 262 144 x 512, 0.9 TB/s,
+// 17 % of the layered backward (rocprofv3, profiles/r05_layered_kernel_stats.csv).  Here a lane owns four columns, a wave 256, the
+// eight waves of a workgroup take the rows of their chunk in turn, eight rows (8 KiB per wave) in flight; a lane adds its rows in
+// order, the waves' sums are added in wave order: fixed, whatever the timing.
+__global__ void __launch_bounds__(512) colsum4_kernel(const float* __restrict__ dz, long long ld, long long rows, int cols,
+                                                      long long rows_per_split, float* __restrict__ partial) {
+    constexpr int kParts = 8, kAhead = 8;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * 4;
+    const long long lo = (long long)blockIdx.y * rows_per_split, hi = lo + rows_per_split < rows ? lo + rows_per_split : rows;
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (col < cols) {
+        const float* base = dz + col;
+        long long r = lo + part;
+        for (; r + (long long)(kAhead - 1) * kParts < hi; r += (long long)kAhead * kParts) {
+            f32x4 v[kAhead];
+#pragma unroll
+            for (int e = 0; e < kAhead; ++e) v[e] = *reinterpret_cast<const f32x4*>(base + (r + (long long)e * kParts) * ld);
+#pragma unroll
+            for (int e = 0; e < kAhead; ++e) s += v[e];
+        }
+        for (; r < hi; r += kParts) s += *reinterpret_cast<const f32x4*>(base + r * ld);
+    }
+    __shared__ f32x4 sh[kParts][64];
+    sh[part][lane] = s;
+    __syncthreads();
+    if (part == 0 && col < cols) {
+        f32x4 t = sh[0][lane];
+#pragma unroll
+        for (int q = 1; q < kParts; ++q) t += sh[q][lane];
+        *reinterpret_cast<f32x4*>(partial + (long long)blockIdx.y * cols + col) = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------ encoding + heads
@@ -542,7 +613,10 @@ int generic_backward(const GenericPlan& p, const float* packed, const float* act
         st = check_launch("mlp_generic(reduce)");
         if (st != SNERF_OK) return st;
         float* bpart = partial + (long long)splits * out * in;
-        hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64, splits), dim3(256), 0, s, dz, dz_ld, total, out, k_chunk, bpart);
+        if (out % 4 == 0 && dz_ld % 4 == 0 && reinterpret_cast<uintptr_t>(dz) % 16 == 0 && reinterpret_cast<uintptr_t>(bpart) % 16 == 0)
+            hipLaunchKernelGGL(colsum4_kernel, dim3((out + 255) / 256, splits), dim3(512), 0, s, dz, dz_ld, total, out, k_chunk, bpart);
+        else
+            hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64, splits), dim3(256), 0, s, dz, dz_ld, total, out, k_chunk, bpart);
         st = check_launch("mlp_generic(bias sums)");
         if (st != SNERF_OK) return st;
         hipLaunchKernelGGL(reduce_splits_kernel, dim3(1), dim3(256), 0, s, bpart, (long long)out, splits, (long long)out, gb, accumulate);

@@ -10,6 +10,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from simplenerf_amd import _lib  # noqa: E402
+
+if os.environ.get('SNERF_LIB'):           # A/B builds (tools/probes/build_variant.py)
+    _lib.LIB_PATH = os.path.abspath(os.environ['SNERF_LIB'])
 from simplenerf_amd import ops, synth  # noqa: E402
 from tests import util  # noqa: E402
 
