@@ -273,18 +273,6 @@ __global__ void __launch_bounds__(512) colsum4_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------------ encoding + heads
 // [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...] (PositionalEncoder :533-557) with the fused kernels' exact range reduction
-__device__ __forceinline__ void encode_row(const float (&x)[3], int degree, float* __restrict__ row) {
-    constexpr double kInvTwoPi = 0.15915494309189533576888;
-    for (int d = 0; d < 3; ++d) row[d] = x[d];
-    for (int k = 0; k < degree; ++k)
-        for (int d = 0; d < 3; ++d) {
-            float s, c;
-            sincos_turns((double)x[d] * kInvTwoPi * (double)(1 << k), s, c);
-            row[3 + 6 * k + d] = s;
-            row[3 + 6 * k + 3 + d] = c;
-        }
-}
-
 struct EncodeArgs {
     const float *origins, *dirs, *view_dirs, *depths;
     float* acts; long long row;
@@ -293,25 +281,46 @@ struct EncodeArgs {
     int c_pe, c_pev, c_x5, c_v0_extra, c_v0_views;       // -1 = block absent
 };
 
+// One thread per (sample, destination column): neighbouring lanes write neighbouring columns of one row.  (Round 4's kernel gave a
+// thread a whole sample: every store of a wave went to 64 different rows -- 0.62 ms of the 8 x 512 forward at 262 144 samples,
+// profiles/r05_layered_kernel_stats.csv.  The copies of the encoding a layer input needs -- skip layer, views layer -- are computed
+// again instead of read back: same function of the same inputs, same bits.)
+__device__ __forceinline__ float encode_column(const float (&x)[3], int c) {
+    constexpr double kInvTwoPi = 0.15915494309189533576888;
+    if (c < 3) return x[c];
+    const int k = (c - 3) / 6, r = (c - 3) % 6, d = r % 3;
+    float sn, cs;
+    sincos_turns((double)x[d] * kInvTwoPi * (double)(1 << k), sn, cs);
+    return r < 3 ? sn : cs;
+}
+
 __global__ void __launch_bounds__(256) encode_kernel(EncodeArgs a) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < a.total; s += stride) {
+    // destination blocks of a row, in order: [encoding | its first pts_in columns for the skip layer | its remaining columns for the
+    // views layer | view encoding | view encoding for the views layer]
+    const int n_pe = a.pe_full, n_x5 = a.c_x5 >= 0 ? a.pts_in : 0, n_extra = a.c_v0_extra >= 0 ? a.pe_full - a.pts_in : 0;
+    const int n_pev = a.views_pe > 0 ? a.views_pe : 0;
+    const int width = n_pe + n_x5 + n_extra + 2 * n_pev;
+    const long long count = a.total * width, stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
+        const long long s = e / width;
+        int j = (int)(e - s * width);
         const long long ray = s / a.samples;
-        const float z = a.depths[s];
-        float x[3];
-        for (int k = 0; k < 3; ++k) x[k] = a.origins[ray * 3 + k] + a.dirs[ray * 3 + k] * z;   // mul, then add (:140-142)
         float* row = a.acts + s * a.row;
-        encode_row(x, a.points_degree, row + a.c_pe);
-        if (a.c_x5 >= 0)
-            for (int c = 0; c < a.pts_in; ++c) row[a.c_x5 + c] = row[a.c_pe + c];
-        if (a.c_v0_extra >= 0)
-            for (int c = a.pts_in; c < a.pe_full; ++c) row[a.c_v0_extra + (c - a.pts_in)] = row[a.c_pe + c];
-        if (a.views_pe > 0) {
-            float v[3];
-            for (int k = 0; k < 3; ++k) v[k] = a.view_dirs[ray * 3 + k];
-            encode_row(v, a.views_degree, row + a.c_pev);
-            for (int c = 0; c < a.views_pe; ++c) row[a.c_v0_views + c] = row[a.c_pev + c];
+        int dest, c;
+        bool views = false;
+        if (j < n_pe) { dest = a.c_pe + j; c = j; }
+        else if ((j -= n_pe) < n_x5) { dest = a.c_x5 + j; c = j; }
+        else if ((j -= n_x5) < n_extra) { dest = a.c_v0_extra + j; c = a.pts_in + j; }
+        else if ((j -= n_extra) < n_pev) { dest = a.c_pev + j; c = j; views = true; }
+        else { j -= n_pev; dest = a.c_v0_views + j; c = j; views = true; }
+        float x[3];
+        if (views) {
+            for (int k = 0; k < 3; ++k) x[k] = a.view_dirs[ray * 3 + k];
+        } else {
+            const float z = a.depths[s];
+            for (int k = 0; k < 3; ++k) x[k] = a.origins[ray * 3 + k] + a.dirs[ray * 3 + k] * z;   // mul, then add (:140-142)
         }
+        row[dest] = encode_column(x, c);
     }
 }
 
@@ -436,7 +445,7 @@ int forward_rows(const GenericPlan& p, const float* packed, const float* origins
     e.views_pe = p.view_dep ? p.views_pe : 0;
     e.c_pe = p.c_pe; e.c_pev = p.c_pev; e.c_x5 = p.c_x5; e.c_v0_extra = p.view_dep && p.extra > 0 ? p.c_v0 + p.width : -1;
     e.c_v0_views = p.view_dep ? p.c_v0 + p.width + p.extra : -1;
-    hipLaunchKernelGGL(encode_kernel, dim3(snerf::stride_grid(total, 256)), dim3(256), 0, s, e);
+    hipLaunchKernelGGL(encode_kernel, dim3(snerf::stride_grid(total * (p.pe_full + (p.view_dep ? p.views_pe : 0)), 256)), dim3(256), 0, s, e);
     int rc = snerf::check_launch("mlp_generic(encode)");
     if (rc != SNERF_OK) return rc;
     for (int l = 0; l < p.depth; ++l) {
