@@ -211,6 +211,217 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
     }
 }
 
+
+// How an operand tile (TILE rows of m resp. n  x  kBK of k) gets from memory into LDS.  `st` = stride (floats) between neighbouring
+// m resp. n, `sk` = between neighbouring k.
+//   (element by element, any strides: gemm_kernel above -- one dword load and one ds_write_b32 per element; kept as written in
+//    rounds 4-5: the same staging expressed through this struct compiled to the same instructions and ran 3-4 % slower)
+//   MODE 1: sk == 1 -- 16-byte groups along k: four k of one row per load, four ds_write_b32 (row stride TILE + 1: conflict-free);
+//   MODE 2: st == 1 -- 16-byte groups along m / n: four neighbours of one k per load, ONE ds_write_b128 (row stride TILE + 4).
+// Round 5: with MODE 0 everywhere the staging cost 50 % on top of the MFMA loop (profiles/r05_layered_ablation.txt); every product
+// of the layered path has a contiguous direction in each operand, so launch_gemm picks MODE 1 / 2 whenever strides, sizes and
+// addresses are multiples of four floats, and gemm_kernel otherwise (ragged K such as the 63-wide encoding, odd row counts).
+template <int TILE, int MODE>
+struct Stager {
+    static_assert(MODE == 1 || MODE == 2, "16-byte staging only");
+    static constexpr int kRow = TILE + (MODE == 2 ? 4 : 1);            // floats per k-row of the tile in LDS
+    static constexpr int kElems = TILE * kBK / 256;                      // floats per thread and stage
+    static constexpr int kGroups = kElems / 4;                           // 16-byte groups per thread and stage
+    static constexpr int kStepK2 = 256 / (TILE / 4);                     // MODE 2: k rows covered per pass of the 256 threads
+    const char* tile;            // first element of the tile at k = 0
+    long long sk_bytes;
+    int left;                    // rows (m resp. n) of the tile inside the matrix
+    int t0, k0;                  // this thread's first group: tile index, k index of its first element
+    int dt, dk;                  // step to the thread's next group
+    unsigned byte0, step;        // byte offset of the first element / group inside a stage, and to the next one
+    unsigned inside;             // bit e: element / group e of the stage in flight lies inside the matrix
+    float r[kElems];
+    int lds0, lds_step;          // float offset of the first element inside a stage buffer, and to the next one
+
+    __device__ __forceinline__ void init(const float* first, long long st, long long sk, int left_, int tid) {
+        tile = reinterpret_cast<const char*>(first);
+        sk_bytes = sk * 4;
+        left = left_;
+        inside = 0;
+        if constexpr (MODE == 1) {
+            t0 = tid >> 3; k0 = (tid & 7) * 4; dt = 32; dk = 0;
+            byte0 = (unsigned)((long long)t0 * st + k0) * 4u;
+            step = (unsigned)(32 * st * 4);
+            lds0 = k0 * kRow + t0;
+            lds_step = 32;
+        } else {
+            t0 = (tid & (TILE / 4 - 1)) * 4; k0 = tid / (TILE / 4); dt = 0; dk = kStepK2;
+            byte0 = (unsigned)((long long)k0 * sk + t0) * 4u;
+            step = (unsigned)(kStepK2 * sk * 4);
+            lds0 = k0 * kRow + t0;
+            lds_step = kStepK2 * kRow;
+        }
+    }
+    // branch-free: an element outside the matrix reads the stage's first element (always inside) and is replaced by zero WHEN IT
+    // IS STORED, after this stage's MFMAs (a predicated load per element compiles to one exec-masked basic block per load, and a
+    // select right here makes the MFMAs wait for the loads they are meant to hide)
+    __device__ __forceinline__ void load(long long k_first, int k_left) {
+        const char* stage = tile + k_first * sk_bytes;
+        inside = 0;
+#ifdef SNERF_PROBE_GEMM_NOLOAD       // timing ablation (wrong results): nothing fetched from memory
+        (void)stage; (void)k_left;
+        return;
+#endif
+#pragma unroll
+        for (int e = 0; e < kGroups; ++e) {
+            const bool in = t0 + e * dt < left && k0 + e * dk < k_left;      // (sizes are multiples of four: all four or none)
+            inside |= in ? 1u << e : 0u;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (in ? byte0 + (unsigned)e * step : 0u));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[4 * e + q] = v[q];
+        }
+    }
+    __device__ __forceinline__ void store(float* buffer) {
+#ifdef SNERF_PROBE_GEMM_NOSTORE      // timing ablation (wrong results): nothing staged into LDS
+        return;
+#endif
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int e = 0; e < kGroups; ++e)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) buffer[lds0 + e * lds_step + q * kRow] = (inside >> e) & 1u ? r[4 * e + q] : 0.0f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < kGroups; ++e) {
+                const bool in = (inside >> e) & 1u;
+                const f32x4 v = {in ? r[4 * e] : 0.0f, in ? r[4 * e + 1] : 0.0f, in ? r[4 * e + 2] : 0.0f, in ? r[4 * e + 3] : 0.0f};
+                *reinterpret_cast<f32x4*>(buffer + lds0 + e * lds_step) = v;
+            }
+        }
+    }
+};
+
+// BM x BN output tile per 256-thread workgroup = a 2 x 2 grid of waves, each (BM / 2) x (BN / 2) = TM x TN MFMA tiles of 32 x 32.
+// <64, 64>: one tile per wave (the round-4 kernel: 0.40 of the fp32 matrix peak at width 512 -- per staged byte and per barrier
+// it does a quarter of the matrix work of) <128, 128> (round 5): four tiles per wave, every operand value read from LDS feeds
+// two MFMAs, 64 KiB of LDS for the two stages; used wherever the product is at least 128 x 128.  AV / BV: Stager modes.
+template <int BM, int BN, int AV, int BV>
+__global__ void __launch_bounds__(256, 2) gemm_vec_kernel(GemmArgs g) {
+    static_assert(AV > 0 && BV > 0, "element-by-element staging is gemm_kernel's");
+    constexpr int TM = BM / 64, TN = BN / 64;
+    using StageA = Stager<BM, AV>;
+    using StageB = Stager<BN, BV>;
+    constexpr int SA = StageA::kRow, SB = StageB::kRow;
+    __shared__ __attribute__((aligned(16))) float As[2][kBK * SA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kBK * SB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // tile of this workgroup.  Workgroups go to the eight XCDs in turn (linear id mod 8) and every XCD has its own L2: with the
+    // plain (x = n tile, y = m tile) order the n tiles of one row block -- which all read the same rows of A -- land on different
+    // XCDs and A comes from HBM once per n tile (4 x at width 512).  When the m tiles divide by eight, XCD x takes the row blocks
+    // congruent to x and walks their n tiles one after the other: A's rows are fetched once and hit in that XCD's L2 afterwards.
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+#ifndef SNERF_PROBE_GEMM_PLAIN_ORDER
+    if ((gridDim.y & 7u) == 0) {
+        const unsigned linear = blockIdx.y * gridDim.x + blockIdx.x, xcd = linear & 7u, idx = linear >> 3;
+        tile_m = (int)((idx / gridDim.x) * 8u + xcd);
+        tile_n = (int)(idx % gridDim.x);
+    }
+#endif
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long long k_lo = g.split_stride ? (long long)blockIdx.z * g.k_chunk : 0;
+    const long long k_hi = g.split_stride ? (k_lo + g.k_chunk < g.K ? k_lo + g.k_chunk : g.K) : g.K;
+    float* C = g.C + (g.split_stride ? (long long)blockIdx.z * g.split_stride : 0);
+
+    // thread -> elements of a stage, walking the contiguous dimension first: a thread's elements sit a FIXED step apart in memory and
+    // in LDS -- one 32-bit byte offset per operand and thread (computed once), a wave-uniform base per stage (scalar arithmetic),
+    // immediate LDS offsets.  (Round 4 computed m * a_rs + k * a_cs in 64 bits per element and stage: 1 021 vector instructions
+    // beside 16 MFMAs -- the kernel was bound by its address arithmetic, not by the matrix pipe.)
+    StageA sa;
+    StageB sb;
+    sa.init(g.A + (long long)m0 * g.a_rs, g.a_rs, g.a_cs, g.M - m0, tid);
+    sb.init(g.B + (long long)n0 * g.b_cs, g.b_cs, g.b_rs, g.N - n0, tid);
+    auto load_stage = [&](long long k0) {
+        const int k_left = (int)(k_hi - k0 < kBK ? k_hi - k0 : kBK);       // 32 except in the last stage of a ragged K
+        sa.load(k0, k_left);
+        sb.load(k0, k_left);
+    };
+    auto store_stage = [&](int buf) {
+        sa.store(As[buf]);
+        sb.store(Bs[buf]);
+    };
+
+    // wave (wm, wn) owns a (32 TM) x (32 TN) sub-tile; MFMA operands: A(m = lane & 31, k = lane >> 5), B(k = lane >> 5, n = lane & 31)
+    const int wm = (wave >> 1) * (32 * TM), wn = (wave & 1) * (32 * TN), i = lane & 31, h = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
+    if (k_lo < k_hi) {
+        load_stage(k_lo);
+        store_stage(0);
+        __syncthreads();
+        int buf = 0;
+        for (long long k0 = k_lo; k0 < k_hi; k0 += kBK) {
+            const bool more = k0 + kBK < k_hi;
+            if (more) load_stage(k0 + kBK);                     // in flight during this stage's MFMAs
+            const float* a_rd = &As[buf][h * SA + wm + i];
+            const float* b_rd = &Bs[buf][h * SB + wn + i];
+            // the operands of k-pair p + 1 are requested BEFORE the MFMAs of pair p are issued (two register sets; the scheduling
+            // barrier keeps the compiler from sinking the reads back to their use): left alone it emitted read, wait, four MFMAs,
+            // read, wait ... with one register set, and the matrix pipe sat idle for an LDS round trip per pair -- 0.54 busy (PMC,
+            // profiles/r05_pmc_layered_gemm.json), 0.50 of the peak
+            float av[2][TM], bv[2][TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) av[0][tm] = a_rd[32 * tm];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bv[0][tn] = b_rd[32 * tn];
+#pragma unroll
+            for (int p = 0; p < kBK / 2; ++p) {
+                if (p + 1 < kBK / 2) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) av[(p + 1) & 1][tm] = a_rd[2 * (p + 1) * SA + 32 * tm];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) bv[(p + 1) & 1][tn] = b_rd[2 * (p + 1) * SB + 32 * tn];
+                }
+#ifndef SNERF_PROBE_GEMM_NO_PREFETCH
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][tm], bv[p & 1][tn], acc[tm][tn], 0, 0, 0);
+#ifndef SNERF_PROBE_GEMM_NO_PREFETCH
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            if (more) {
+                store_stage(buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+            }
+        }
+    }
+    // D layout: lane (i = column, h), register r -> row (r & 3) + 8 (r >> 2) + 4 h of the 32 x 32 tile
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const long long n = n0 + wn + 32 * tn + i;
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                float v = acc[tm][tn][r] + bias;
+                float* dst = C + m * g.c_rs + n * g.c_cs;
+                if (g.accumulate) v += *dst;
+                if (g.relu) v = fmaxf(v, 0.0f);
+                if (g.mask) v = g.mask[m * g.mask_rs + n] > 0.0f ? v : 0.0f;
+                *dst = v;
+            }
+    }
+}
+
 // out[m][n] (+)= sum_z partial[z][m][n] in z order (bit-reproducible)
 __global__ void __launch_bounds__(256) reduce_splits_kernel(const float* __restrict__ partial, long long split_stride, int splits,
                                                             long long count, float* __restrict__ out, int accumulate) {
@@ -375,7 +586,23 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t s) {
     const long long large_tiles = (long long)((g.N + 127) / 128) * ((g.M + 127) / 128) * (splits > 0 ? splits : 1);
     if (g.M >= 128 && g.N >= 128 && large_tiles >= 512) {
         const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, splits > 0 ? splits : 1);
+        // 16-byte staging (Stager MODE 1 / 2) where everything it touches is a multiple of four floats; the three combinations are
+        // the path's three products: forward (A, B along k), input gradient (A along k, B along n), weight gradient (A along m,
+        // B along n)
+        auto aligned = [](const float* ptr) { return reinterpret_cast<uintptr_t>(ptr) % 16 == 0; };
+        const bool k_fours = g.K % 4 == 0 && (splits <= 0 || g.k_chunk % 4 == 0);
+        const bool a_along_k = g.a_cs == 1 && g.a_rs % 4 == 0 && aligned(g.A) && k_fours;
+        const bool a_along_m = g.a_rs == 1 && g.a_cs % 4 == 0 && aligned(g.A) && g.M % 4 == 0;
+        const bool b_along_k = g.b_rs == 1 && g.b_cs % 4 == 0 && aligned(g.B) && k_fours;
+        const bool b_along_n = g.b_cs == 1 && g.b_rs % 4 == 0 && aligned(g.B) && g.N % 4 == 0;
+#ifdef SNERF_PROBE_GEMM_SCALAR_STAGING
         hipLaunchKernelGGL((gemm_kernel<128, 128>), grid, dim3(256), 0, s, g);
+#else
+        if (a_along_k && b_along_k) hipLaunchKernelGGL((gemm_vec_kernel<128, 128, 1, 1>), grid, dim3(256), 0, s, g);
+        else if (a_along_k && b_along_n) hipLaunchKernelGGL((gemm_vec_kernel<128, 128, 1, 2>), grid, dim3(256), 0, s, g);
+        else if (a_along_m && b_along_n) hipLaunchKernelGGL((gemm_vec_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_kernel<128, 128>), grid, dim3(256), 0, s, g);
+#endif
     } else {
         const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, splits > 0 ? splits : 1);
         hipLaunchKernelGGL((gemm_kernel<64, 64>), grid, dim3(256), 0, s, g);
@@ -525,19 +752,27 @@ int generic_plan(const snerf_mlp_desc* d, GenericPlan* out) {
     }
     p.packed_floats = off;
     // activation row
+    // (every block a Linear layer reads starts at a multiple of four floats, so that the GEMM can stage it 16 bytes at a time --
+    // Stager MODE 1 / 2; H_4 follows the skip layer's encoding copy directly, as that layer reads [encoding | H_4] as ONE input)
     int c = 0;
+#ifdef SNERF_PROBE_GENERIC_PACKED_ROW     // A/B builds: the row of rounds 4-5, blocks back to back
+    auto four = [&]() {};
+#else
+    auto four = [&]() { c = (c + 3) / 4 * 4; };
+#endif
     p.c_pe = c; c += p.pe_full;
-    p.c_pev = c; c += p.views_pe;
+    four(); p.c_pev = c; c += p.views_pe;
     p.c_x5 = -1;
     p.c_h.assign(p.depth, 0);
     for (int l = 0; l < p.depth; ++l) {
+        four();
         if (l == 4 && p.depth > 5) { p.c_x5 = c; c += p.pts_in; }      // [encoding | H_4]: the skip layer's input (:662-663)
         p.c_h[l] = c; c += p.width;
     }
-    p.c_v0 = c; if (p.view_dep) c += p.views_in;
+    four(); p.c_v0 = c; if (p.view_dep) c += p.views_in;
     p.c_hv.assign(p.views_depth, 0);
-    for (int j = 0; j < p.views_depth; ++j) { p.c_hv[j] = c; c += p.views_width; }
-    p.c_out = c; c += 4;
+    for (int j = 0; j < p.views_depth; ++j) { four(); p.c_hv[j] = c; c += p.views_width; }
+    four(); p.c_out = c; c += 4;
     p.c_vout = c; c += 4;
     p.row = (c + 3) / 4 * 4;
     *out = p;

@@ -13,7 +13,7 @@
     defined(SNERF_ABL_CHAIN_NODMA) || defined(SNERF_ABL_CHAIN_NOBARRIER) || defined(SNERF_PROBE_SMALL_RING) ||                 \
     defined(SNERF_PROBE_NO_M16) || defined(SNERF_PROBE_HALF_DY) || defined(SNERF_PROBE_HALF_X) || defined(SNERF_PROBE_RING4) || \
     defined(SNERF_PROBE_NO_SMALL_FOLD) || defined(SNERF_PROBE_DEEP) || defined(SNERF_PROBE_WGRAD_NOMATH) ||                    \
-    defined(SNERF_PROBE_NO_K4K5_FUSION) || defined(SNERF_PROBE_M16_NOENCODE) || defined(SNERF_PROBE_NO_SIDE_BY_SIDE) || defined(SNERF_PROBE_M16_UNPAIRED) || defined(SNERF_PROBE_GEMM_PLAIN_ORDER) || defined(SNERF_PROBE_GEMM_NO_PREFETCH) || defined(SNERF_PROBE_GEMM_NOLOAD) || defined(SNERF_PROBE_GEMM_NOSTORE) || defined(SNERF_PROBE_NO_VMWAIT) || defined(SNERF_CLOCK_STAMP)
+    defined(SNERF_PROBE_NO_K4K5_FUSION) || defined(SNERF_PROBE_M16_NOENCODE) || defined(SNERF_PROBE_NO_SIDE_BY_SIDE) || defined(SNERF_PROBE_M16_UNPAIRED) || defined(SNERF_PROBE_GEMM_PLAIN_ORDER) || defined(SNERF_PROBE_GEMM_NO_PREFETCH) || defined(SNERF_PROBE_GEMM_NOLOAD) || defined(SNERF_PROBE_GEMM_SCALAR_STAGING) || defined(SNERF_PROBE_GENERIC_PACKED_ROW) || defined(SNERF_PROBE_GEMM_NOSTORE) || defined(SNERF_PROBE_NO_VMWAIT) || defined(SNERF_CLOCK_STAMP)
 #error "a diagnostic switch (SNERF_ABL_* / SNERF_PROBE_* / SNERF_CLOCK_STAMP) is defined in a build of the shipped library: these produce wrong results by design; build variants with tools/probes/build_variant.py (defines SNERF_PROBE_BUILD, writes gpurun_abl_<name>.so)"
 #endif
 #endif
