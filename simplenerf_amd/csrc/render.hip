@@ -39,7 +39,10 @@ struct Marching {
 // branches).  Side streams and events are created once per (device, caller's stream) and kept.  Above the threshold every CU is
 // busy with one level and the levels stay on the caller's stream, in order (two backward calls side by side measured the same
 // as back to back there: DESIGN_LOG 12.4).
-constexpr long long kSideBySideSamples = 65536;
+#ifndef SNERF_SIDE_BY_SIDE_SAMPLES          // (A/B builds: -DSNERF_SIDE_BY_SIDE_SAMPLES=n)
+#define SNERF_SIDE_BY_SIDE_SAMPLES 65536
+#endif
+constexpr long long kSideBySideSamples = SNERF_SIDE_BY_SIDE_SAMPLES;
 constexpr int kSideStreams = 3;
 
 struct SideStreams {
