@@ -46,6 +46,65 @@ struct GemmArgs {
 
 constexpr int kBK = 32, kPad = 1;
 
+// Accumulators -> C (+ bias, + C, ReLU, gate).  D layout: lane (i = column, h), register r -> row (r & 3) + 8 (r >> 2) + 4 h of the 32 x 32
+// tile.  A tile that lies wholly inside the matrix takes the branch-free path: the sixteen values of a register tile are read (C to add
+// to, the gate) in one batch, then computed, then stored -- with a bounds test per element every read was its own exec-masked block
+// and waited for its own round trip (64 of them per thread in the input-gradient products of the backward).
+template <int TM, int TN>
+__device__ __forceinline__ void write_tile(const f32x16 (&acc)[TM][TN], const GemmArgs& g, float* C, int m0, int n0, int wm, int wn, int i,
+                                           int h) {
+    const bool whole = m0 + 64 * TM <= g.M && n0 + 64 * TN <= g.N;
+    if (whole) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const long long n = n0 + wn + 32 * tn + i;
+            const float bias = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const long long m_first = m0 + wm + 32 * tm + 4 * h;
+                float* const dst = C + m_first * g.c_rs + n * g.c_cs;
+                const float* const gate = g.mask ? g.mask + m_first * g.mask_rs + n : nullptr;
+                float old[16], open[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long dm = (r & 3) + 8 * (r >> 2);
+                    old[r] = g.accumulate ? dst[dm * g.c_rs] : 0.0f;
+                    open[r] = gate ? gate[dm * g.mask_rs] : 1.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long dm = (r & 3) + 8 * (r >> 2);
+                    float v = acc[tm][tn][r] + bias;
+                    if (g.accumulate) v += old[r];
+                    if (g.relu) v = fmaxf(v, 0.0f);
+                    if (g.mask) v = open[r] > 0.0f ? v : 0.0f;
+                    dst[dm * g.c_rs] = v;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const long long n = n0 + wn + 32 * tn + i;
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                float v = acc[tm][tn][r] + bias;
+                float* dst = C + m * g.c_rs + n * g.c_cs;
+                if (g.accumulate) v += *dst;
+                if (g.relu) v = fmaxf(v, 0.0f);
+                if (g.mask) v = g.mask[m * g.mask_rs + n] > 0.0f ? v : 0.0f;
+                *dst = v;
+            }
+    }
+}
+
 // BM x BN output tile per 256-thread workgroup = a 2 x 2 grid of waves, each (BM / 2) x (BN / 2) = TM x TN MFMA tiles of 32 x 32.
 // <64, 64>: one tile per wave (the round-4 kernel: 0.40 of the fp32 matrix peak at width 512 -- per staged byte and per barrier
 // it does a quarter of the matrix work of) <128, 128> (round 5): four tiles per wave, every operand value read from LDS feeds
@@ -189,26 +248,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
             }
         }
     }
-    // D layout: lane (i = column, h), register r -> row (r & 3) + 8 (r >> 2) + 4 h of the 32 x 32 tile
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const long long n = n0 + wn + 32 * tn + i;
-        if (n >= g.N) continue;
-        const float bias = g.bias ? g.bias[n] : 0.0f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wm + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= g.M) continue;
-                float v = acc[tm][tn][r] + bias;
-                float* dst = C + m * g.c_rs + n * g.c_cs;
-                if (g.accumulate) v += *dst;
-                if (g.relu) v = fmaxf(v, 0.0f);
-                if (g.mask) v = g.mask[m * g.mask_rs + n] > 0.0f ? v : 0.0f;
-                *dst = v;
-            }
-    }
+    write_tile<TM, TN>(acc, g, C, m0, n0, wm, wn, i, h);
 }
 
 
@@ -400,26 +440,7 @@ __global__ void __launch_bounds__(256, 2) gemm_vec_kernel(GemmArgs g) {
             }
         }
     }
-    // D layout: lane (i = column, h), register r -> row (r & 3) + 8 (r >> 2) + 4 h of the 32 x 32 tile
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const long long n = n0 + wn + 32 * tn + i;
-        if (n >= g.N) continue;
-        const float bias = g.bias ? g.bias[n] : 0.0f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wm + 32 * tm + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= g.M) continue;
-                float v = acc[tm][tn][r] + bias;
-                float* dst = C + m * g.c_rs + n * g.c_cs;
-                if (g.accumulate) v += *dst;
-                if (g.relu) v = fmaxf(v, 0.0f);
-                if (g.mask) v = g.mask[m * g.mask_rs + n] > 0.0f ? v : 0.0f;
-                *dst = v;
-            }
-    }
+    write_tile<TM, TN>(acc, g, C, m0, n0, wm, wn, i, h);
 }
 
 // out[m][n] (+)= sum_z partial[z][m][n] in z order (bit-reproducible)
