@@ -350,19 +350,33 @@ __global__ void __launch_bounds__(256, 2) gemm_vec_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[2][kBK * SA];
     __shared__ __attribute__((aligned(16))) float Bs[2][kBK * SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // tile of this workgroup.  Workgroups go to the eight XCDs in turn (linear id mod 8) and every XCD has its own L2: with the
-    // plain (x = n tile, y = m tile) order the n tiles of one row block -- which all read the same rows of A -- land on different
-    // XCDs and A comes from HBM once per n tile (4 x at width 512).  When the m tiles divide by eight, XCD x takes the row blocks
-    // congruent to x and walks their n tiles one after the other: A's rows are fetched once and hit in that XCD's L2 afterwards.
-    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    // PERSISTENT workgroups: the grid is two per CU (launch_gemm) and a workgroup walks tiles `blockIdx.x, + gridDim.x, ...` of the
+    // tile sequence below -- the first stage of its NEXT tile is requested before the accumulators of this one are written out, so
+    // that neither the first loads' round trip nor the epilogue's stores stand alone between two tiles' MFMAs (the two workgroups of
+    // a CU run in step: what one tile spent outside its MFMA loop nobody covered -- 85 us per pair of tiles against 55 of matrix
+    // work, profiles/r05_layered_ablation.txt).
+    // Tile sequence.  Workgroups go to the eight XCDs in turn (linear id mod 8; the grid is a multiple of eight, so a workgroup stays
+    // on its XCD's residue) and every XCD has its own L2: with the plain (n tile fastest) order the n tiles of one row block -- which
+    // all read the same rows of A -- land on different XCDs and A comes from HBM once per n tile (4 x at width 512).  When the m tiles
+    // divide by eight, XCD x takes the row blocks congruent to x and walks their n tiles one after the other: A's rows are fetched
+    // once and hit in that XCD's L2 afterwards.
+    const unsigned tiles_n = (unsigned)((g.N + BN - 1) / BN), tiles_m = (unsigned)((g.M + BM - 1) / BM), tiles = tiles_n * tiles_m;
+    auto tile_of = [&](unsigned linear_id, int* m_first, int* n_first) {
+        unsigned tile_m = linear_id / tiles_n, tile_n = linear_id % tiles_n;
 #ifndef SNERF_PROBE_GEMM_PLAIN_ORDER
-    if ((gridDim.y & 7u) == 0) {
-        const unsigned linear = blockIdx.y * gridDim.x + blockIdx.x, xcd = linear & 7u, idx = linear >> 3;
-        tile_m = (int)((idx / gridDim.x) * 8u + xcd);
-        tile_n = (int)(idx % gridDim.x);
-    }
+        if ((tiles_m & 7u) == 0) {
+            const unsigned xcd = linear_id & 7u, idx = linear_id >> 3;
+            tile_m = (idx / tiles_n) * 8u + xcd;
+            tile_n = idx % tiles_n;
+        }
 #endif
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+        *m_first = (int)tile_m * BM;
+        *n_first = (int)tile_n * BN;
+    };
+    unsigned linear = blockIdx.x;
+    if (linear >= tiles) return;
+    int m0, n0;
+    tile_of(linear, &m0, &n0);
     const long long k_lo = g.split_stride ? (long long)blockIdx.z * g.k_chunk : 0;
     const long long k_hi = g.split_stride ? (k_lo + g.k_chunk < g.K ? k_lo + g.k_chunk : g.K) : g.K;
     float* C = g.C + (g.split_stride ? (long long)blockIdx.z * g.split_stride : 0);
@@ -394,53 +408,74 @@ __global__ void __launch_bounds__(256, 2) gemm_vec_kernel(GemmArgs g) {
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
-    if (k_lo < k_hi) {
-        load_stage(k_lo);
-        store_stage(0);
-        __syncthreads();
-        int buf = 0;
-        for (long long k0 = k_lo; k0 < k_hi; k0 += kBK) {
-            const bool more = k0 + kBK < k_hi;
-            if (more) load_stage(k0 + kBK);                     // in flight during this stage's MFMAs
-            const float* a_rd = &As[buf][h * SA + wm + i];
-            const float* b_rd = &Bs[buf][h * SB + wn + i];
-            // the operands of k-pair p + 1 are requested BEFORE the MFMAs of pair p are issued (two register sets; the scheduling
-            // barrier keeps the compiler from sinking the reads back to their use): left alone it emitted read, wait, four MFMAs,
-            // read, wait ... with one register set, and the matrix pipe sat idle for an LDS round trip per pair -- 0.54 busy (PMC,
-            // profiles/r05_pmc_layered_gemm.json), 0.50 of the peak
-            float av[2][TM], bv[2][TN];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) av[0][tm] = a_rd[32 * tm];
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) bv[0][tn] = b_rd[32 * tn];
-#pragma unroll
-            for (int p = 0; p < kBK / 2; ++p) {
-                if (p + 1 < kBK / 2) {
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) av[(p + 1) & 1][tm] = a_rd[2 * (p + 1) * SA + 32 * tm];
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) bv[(p + 1) & 1][tn] = b_rd[2 * (p + 1) * SB + 32 * tn];
+    const bool any_k = k_lo < k_hi;
+    if (any_k) load_stage(k_lo);
+    while (true) {
+        if (any_k) {
+            store_stage(0);
+            __syncthreads();
+            int buf = 0;
+            for (long long k0 = k_lo; k0 < k_hi; k0 += kBK) {
+                const bool more = k0 + kBK < k_hi;
+                if (more) load_stage(k0 + kBK);                     // in flight during this stage's MFMAs
+                const float* a_rd = &As[buf][h * SA + wm + i];
+                const float* b_rd = &Bs[buf][h * SB + wn + i];
+                // the operands of k-pair p + 1 are requested BEFORE the MFMAs of pair p are issued (two register sets; the scheduling
+                // barrier keeps the compiler from sinking the reads back to their use): left alone it emitted read, wait, four MFMAs,
+                // read, wait ... with one register set, and the matrix pipe sat idle for an LDS round trip per pair -- 0.54 busy (PMC,
+                // profiles/r05_pmc_layered_gemm.json), 0.50 of the peak
+                float av[2][TM], bv[2][TN];
+    #pragma unroll
+                for (int tm = 0; tm < TM; ++tm) av[0][tm] = a_rd[32 * tm];
+    #pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bv[0][tn] = b_rd[32 * tn];
+    #pragma unroll
+                for (int p = 0; p < kBK / 2; ++p) {
+                    if (p + 1 < kBK / 2) {
+    #pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) av[(p + 1) & 1][tm] = a_rd[2 * (p + 1) * SA + 32 * tm];
+    #pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) bv[(p + 1) & 1][tn] = b_rd[2 * (p + 1) * SB + 32 * tn];
+                    }
+    #ifndef SNERF_PROBE_GEMM_NO_PREFETCH
+                    __builtin_amdgcn_sched_barrier(0);
+    #endif
+    #pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+    #pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][tm], bv[p & 1][tn], acc[tm][tn], 0, 0, 0);
+    #ifndef SNERF_PROBE_GEMM_NO_PREFETCH
+                    __builtin_amdgcn_sched_barrier(0);
+    #endif
                 }
-#ifndef SNERF_PROBE_GEMM_NO_PREFETCH
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][tm], bv[p & 1][tn], acc[tm][tn], 0, 0, 0);
-#ifndef SNERF_PROBE_GEMM_NO_PREFETCH
-                __builtin_amdgcn_sched_barrier(0);
-#endif
+                if (more) {
+                    store_stage(buf ^ 1);
+                    __syncthreads();
+                    buf ^= 1;
+                }
             }
-            if (more) {
-                store_stage(buf ^ 1);
-                __syncthreads();
-                buf ^= 1;
-            }
+            __syncthreads();          // (every wave is done reading the buffers before the next tile's first stage overwrites buffer 0)
         }
+        // the next tile's first stage, in flight while this tile's accumulators go out
+        const unsigned next = linear + gridDim.x;
+        int m_next = 0, n_next = 0;
+        if (next < tiles) {
+            tile_of(next, &m_next, &n_next);
+            sa.init(g.A + (long long)m_next * g.a_rs, g.a_rs, g.a_cs, g.M - m_next, tid);
+            sb.init(g.B + (long long)n_next * g.b_cs, g.b_cs, g.b_rs, g.N - n_next, tid);
+            if (any_k) load_stage(k_lo);
+        }
+        write_tile<TM, TN>(acc, g, C, m0, n0, wm, wn, i, h);
+        if (next >= tiles) break;
+        linear = next; m0 = m_next; n0 = n_next;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
     }
-    write_tile<TM, TN>(acc, g, C, m0, n0, wm, wn, i, h);
 }
 
 // out[m][n] (+)= sum_z partial[z][m][n] in z order (bit-reproducible)
@@ -598,6 +633,18 @@ __global__ void __launch_bounds__(256) copy_kernel(float* __restrict__ dst, cons
 }
 
 // ------------------------------------------------------------------------------------------------------------ host side
+// two workgroups per CU of the current device, rounded down to a multiple of eight (512 on an MI355X)
+unsigned persistent_workgroups() {
+    int device = 0, cus = 256;
+    if (hipGetDevice(&device) == hipSuccess) {
+        int value = 0;
+        if (hipDeviceGetAttribute(&value, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && value > 0) cus = value;
+    }
+    (void)hipGetLastError();
+    const unsigned count = (unsigned)(2 * cus) & ~7u;
+    return count ? count : 8u;
+}
+
 int launch_gemm(const GemmArgs& g, int splits, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return SNERF_OK;
     // (the same arithmetic per output element either way: each is one fp32 FMA chain over k in order -- the tile only decides
@@ -619,9 +666,12 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t s) {
 #ifdef SNERF_PROBE_GEMM_SCALAR_STAGING
         hipLaunchKernelGGL((gemm_kernel<128, 128>), grid, dim3(256), 0, s, g);
 #else
-        if (a_along_k && b_along_k) hipLaunchKernelGGL((gemm_vec_kernel<128, 128, 1, 1>), grid, dim3(256), 0, s, g);
-        else if (a_along_k && b_along_n) hipLaunchKernelGGL((gemm_vec_kernel<128, 128, 1, 2>), grid, dim3(256), 0, s, g);
-        else if (a_along_m && b_along_n) hipLaunchKernelGGL((gemm_vec_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, g);
+        // (persistent workgroups: two per CU of the current device, a multiple of eight so that a workgroup's tiles stay on its XCD)
+        const unsigned tiles = grid.x * grid.y;
+        const dim3 walkers(tiles < persistent_workgroups() ? tiles : persistent_workgroups(), 1, grid.z);
+        if (a_along_k && b_along_k) hipLaunchKernelGGL((gemm_vec_kernel<128, 128, 1, 1>), walkers, dim3(256), 0, s, g);
+        else if (a_along_k && b_along_n) hipLaunchKernelGGL((gemm_vec_kernel<128, 128, 1, 2>), walkers, dim3(256), 0, s, g);
+        else if (a_along_m && b_along_n) hipLaunchKernelGGL((gemm_vec_kernel<128, 128, 2, 2>), walkers, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((gemm_kernel<128, 128>), grid, dim3(256), 0, s, g);
 #endif
     } else {
